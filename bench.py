@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py - CDR-residue denoise-steps/sec on synthetic K=128 patches (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: one reverse-diffusion step (Denoiser forward + Philox noise +
+IGSO3 draw + state update) for B patches of K residues on every rank.  residue-steps = n_gpus * B * K * steps.
+Workload at N=1: BASELINE.json configs[1] - batch=256 synthetic K=128 patches, 100-step sampling, benchmark model
+(reference train.py:62-70).  N>1: the same 256 patches PER GPU (weak scaling), no data-path collective; one RCCL
+all-gather of the sampled structures at the end of the timed region.
+
+    python bench.py --gpus 1 --steps 100 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract: task prompt section 4).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "diffab-pytorch_amd"))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_attention_launch(B, K, D, C):
+    """compulsory traffic of one IPA layer's attention kernel with perfect on-chip reuse:
+    the pair embedding e[b] streamed once (k4 + k8 fused), fp32.  Per patch K*K*C*4 bytes."""
+    return B * K * K * C * 4
+
+
+def algorithmic_bytes_per_residue_step(K, D, C, NL, V=21):
+    """NL*K^2*C*4 (pair stream) + K*D*4 (res ctx) + K*(8+12+36) in + K*(12+36+4V) out, per residue."""
+    per_patch = NL * K * K * C * 4 + K * D * 4 + K * (8 + 12 + 36) + K * (12 + 36 + 4 * V)
+    return per_patch / K
+
+
+def cpu_baseline(dims, sd, K, n_patches, n_steps, seed):
+    """The oracle (torch-CPU restatement of the reference's formulation, checked against the reference by the golden
+    vectors) timed on this host's cores on a bounded sample of the same workload: n_patches x K x n_steps."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+
+    import diffab_oracle as orc
+    from diffab_pytorch import synthetic as syn
+
+    threads = torch.get_num_threads()
+    inp = syn.patches(n_patches, K, dims, seed=seed, coord_sigma=10.0)
+    sched = orc.cosine_variance_schedule(100, s=0.01, beta_max=0.999)
+    sdo = {"denoiser." + k: v for k, v in sd.items()}
+    seq, x, O = inp["seq_idx"], inp["translations"], inp["orientations"]
+    gm = inp["generation_mask"]
+    patch = np.arange(n_patches)[:, None] + np.zeros((n_patches, K), dtype=np.int64)
+    res = np.zeros((n_patches, K), dtype=np.int64) + np.arange(K)[None, :]
+
+    def step(t, seq, x, O):
+        den = orc.denoiser(sdo, seq, x, O, inp["res_context_emb"], inp["pair_context_emb"], sched["beta"][t].expand(n_patches),
+                           dims["NL"], dims["H"])
+        z = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, 1)[:3], -1))
+        rv = 0.1 * torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, 2)[:3], -1))
+        u = torch.from_numpy(orc.philox_uniform4(seed, patch, res, t, 0)[0])
+        return orc.reverse_update(t, seq, x, O, den, gm, sched, z, rv, u)
+
+    with torch.no_grad():
+        seq, x, O = step(100, seq, x, O)  # warm-up
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            seq, x, O = step(100 - (i % 100), seq, x, O)
+        dt = time.perf_counter() - t0
+    return {
+        "value": n_patches * K * n_steps / dt,
+        "unit": "residue-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_patches} patches x K={K} x {n_steps} reverse steps, oracle/diffab_oracle.py (torch CPU fp32, "
+                  f"reference formulation), {dt:.1f} s on {threads} threads of {os.cpu_count()} logical CPUs",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="patches per GPU")
+    ap.add_argument("--k", type=int, default=128, help="residues per patch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    from diffab_pytorch import DiffAb, _hip, synthetic as syn
+    from diffab_pytorch.distributed import gather_samples
+
+    lib = _hip.lib()
+    dims = dict(syn.BENCH_DIMS)
+    B, K = args.batch, args.k
+    torch.manual_seed(0)  # default init of the boundary module, identical on every rank
+    model = DiffAb(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"]).cuda()
+    first_patch = rank * B  # global patch ids: rank r owns [r*B, (r+1)*B)
+    t_gen = time.perf_counter()
+    inp = syn.patches(B, K, dims, seed=0, coord_sigma=10.0, first_patch=first_patch)  # CPU-generated, then copied
+    dev = {k: v.cuda() for k, v in inp.items()}
+    t_gen = time.perf_counter() - t_gen
+    seq, x, O = dev["seq_idx"].clone(), dev["translations"].clone(), dev["orientations"].clone()
+    gm, rc, pc = dev["generation_mask"], dev["res_context_emb"], dev["pair_context_emb"]
+
+    hd = model.denoiser.hip_dims(B, K)
+    w = model.denoiser.hip_weights()
+    sd_dev = model._sched_on_device()
+    tab = model._reverse_so3().struct()
+    ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
+    flags = _hip.FLAG_FORCE_GENERIC if args.generic else 0
+    seed = 2024
+    _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, model.T,
+                                      _hip.stream_ptr()), "sample_init")
+
+    def run_steps(n, t_hi):
+        """n reverse steps starting at timestep t_hi, wrapping T..1; every launch enqueued by the C-ABI loop."""
+        t = t_hi
+        while n > 0:
+            m = min(n, t)
+            _hip.check(lib.diffab_sample_loop(C.byref(hd), C.byref(w.struct), C.byref(sd_dev.struct), C.byref(tab), _hip.ptr(seq),
+                                              _hip.ptr(x), _hip.ptr(O), _hip.ptr(rc), _hip.ptr(pc), _hip.ptr(gm), seed, first_patch, t, t - m,
+                                              _hip.ptr(ws), ws.numel(), flags, _hip.stream_ptr()), "sample_loop")
+            n -= m
+            t = t - m if t - m > 0 else model.T
+        return t
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_next = run_steps(args.warmup, model.T)
+    lib.diffab_kernel_timer_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps, t_next)
+    samples = gather_samples({"seq_idx": seq, "translations": x, "orientations": O}, dist)  # RCCL all-gather when N > 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, total_ms = C.c_int64(0), C.c_double(0.0)
+    _hip.check(lib.diffab_kernel_timer_read(C.byref(launches), C.byref(total_ms)), "kernel_timer_read")
+    lib.diffab_kernel_timer_enable(0)
+    assert samples["translations"].shape[0] == world * B
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(x).all() and torch.isfinite(O).all())
+
+    if rank == 0:
+        value = world * B * K * args.steps / elapsed
+        avg_ms = total_ms.value / max(launches.value, 1)
+        alg = algorithmic_bytes_per_attention_launch(B, K, dims["D"], dims["C"])
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("B") == B and tj.get("K") == K:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CDR-residue denoise-steps/sec (K=128 patch)",
+            "value": value,
+            "unit": "residue-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch={B}/GPU synthetic K={K} patches, reverse sampling steps (T=100 schedule), benchmark model "
+                            "D=128 C=64 NL=6 H=8 ds=32 P=8 (reference train.py:62-70), random-init weights",
+                "patches_per_gpu": B, "K": K, "global_batch": world * B, "parallelism": f"patch-sharded x{world}",
+                "path": "generic" if args.generic else "mfma",
+            },
+            "residue_steps_per_s_per_gpu": value / world,
+            "whole_path_hbm_frac": value / world * algorithmic_bytes_per_residue_step(K, dims["D"], dims["C"], dims["NL"]) / 1e9
+                                   / HBM_PEAK_GBPS,
+            "roofline": {
+                "kernel": "ipa_attention (pair-embedding stream: bias + softmax + attn-weighted pair/scalar/point sums)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "launches": launches.value,
+                "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": alg,
+            },
+            "outputs_finite": finite,
+            "input_gen_s": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            torch.manual_seed(0)
+            sd = {k: v.detach().cpu() for k, v in model.denoiser.state_dict().items()}
+            out["cpu_baseline"] = cpu_baseline(dims, sd, K, n_patches=2, n_steps=args.cpu_steps, seed=seed)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,243 @@
+// api.hip - C-ABI entry points for the denoise step, the IPA layer and the reverse sampling loop,
+// plus library plumbing (version, last error, device probe).
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "denoiser_internal.h"
+
+namespace diffab {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- opt-in launch timer for the dominant kernel (bench.py's roofline leg) ---------------------------------
+// When enabled, the attention-kernel launchers bracket each launch with a hipEvent pair recorded on the launch
+// stream; diffab_kernel_timer_read() synchronises the events and returns the launch count and the summed time.
+struct KernelTimer {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  size_t used = 0;
+};
+static KernelTimer g_timer;
+
+void timer_begin(hipStream_t st) {
+  if (!g_timer.on) return;
+  if (g_timer.used + 2 > g_timer.ev.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      g_timer.ev.push_back(e);
+    }
+  }
+  (void)hipEventRecord(g_timer.ev[g_timer.used], st);
+}
+void timer_end(hipStream_t st) {
+  if (!g_timer.on || g_timer.used + 2 > g_timer.ev.size()) return;
+  (void)hipEventRecord(g_timer.ev[g_timer.used + 1], st);
+  g_timer.used += 2;
+}
+
+static int check_dims(const diffab_dims* d, const char* who) {
+  DIFFAB_REQUIRE(d != nullptr, DIFFAB_ERR_ARG, "%s: dims is null", who);
+  DIFFAB_REQUIRE(d->B > 0 && d->K > 0 && d->D > 0 && d->C > 0 && d->H > 0 && d->DS > 0 && d->PQ > 0 && d->PV > 0 && d->NL >= 0 && d->V > 0,
+                 DIFFAB_ERR_ARG, "%s: non-positive dimension (B=%d K=%d D=%d C=%d H=%d DS=%d PQ=%d PV=%d NL=%d V=%d)", who, d->B, d->K, d->D,
+                 d->C, d->H, d->DS, d->PQ, d->PV, d->NL, d->V);
+  DIFFAB_REQUIRE(static_cast<int64_t>(d->B) * d->K < (1ll << 31), DIFFAB_ERR_UNSUPPORTED, "%s: B*K must be < 2^31", who);
+  return DIFFAB_OK;
+}
+
+struct StepBuffers {
+  float *cat2, *h1, *hA, *hB, *cat3, *t1, *t2, *vbuf, *logits, *ipa;
+  size_t bytes;
+};
+
+static StepBuffers carve_step(const diffab_dims* d, void* ws) {
+  Carver c(ws);
+  const size_t rows = static_cast<size_t>(d->B) * d->K;
+  StepBuffers b;
+  b.cat2 = c.take<float>(rows * 2 * d->D);
+  b.h1 = c.take<float>(rows * d->D);
+  b.hA = c.take<float>(rows * d->D);
+  b.hB = c.take<float>(rows * d->D);
+  b.cat3 = c.take<float>(rows * (d->D + 3));
+  b.t1 = c.take<float>(rows * d->D);
+  b.t2 = c.take<float>(rows * d->D);
+  b.vbuf = c.take<float>(rows * 3);
+  b.logits = c.take<float>(rows * d->V);
+  size_t ipa_floats = ipa_generic_workspace_floats(d);
+  if (fast_path_supported(d)) ipa_floats = ipa_floats > ipa_fast_workspace_floats(d) ? ipa_floats : ipa_fast_workspace_floats(d);
+  b.ipa = c.take<float>(ipa_floats);
+  b.bytes = c.bytes();
+  return b;
+}
+
+static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
+                              const float* t, float* y, float* ws, uint32_t flags, hipStream_t st) {
+  DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
+                 DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
+  if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d)) return ipa_layer_fast(d, w, x, e, R, t, y, ws, st);
+  return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
+}
+
+static int mlp3(const diffab_dims* d, const diffab_mlp3_weights* w, const float* cat3, float* t1, float* t2, float* out, int n_out,
+                hipStream_t st) {
+  DIFFAB_REQUIRE(w->w0 && w->b0 && w->w2 && w->b2 && w->w4 && w->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
+  const int rows = d->B * d->K, D = d->D;
+  if (int rc = launch_linear(cat3, D + 3, w->w0, w->b0, t1, D, rows, D, D + 3, true, st)) return rc;
+  if (int rc = launch_linear(t1, D, w->w2, w->b2, t2, D, rows, D, D, true, st)) return rc;
+  return launch_linear(t2, D, w->w4, w->b4, out, n_out, rows, n_out, D, false, st);
+}
+
+static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
+                        const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
+                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st) {
+  const StepBuffers b = carve_step(d, ws);
+  const int rows = d->B * d->K, D = d->D;
+  if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, b.cat2, st)) return rc;
+  if (int rc = launch_linear(b.cat2, 2 * D, w->res_w0, w->res_b0, b.h1, D, rows, D, 2 * D, true, st)) return rc;
+  if (int rc = launch_linear(b.h1, D, w->res_w2, w->res_b2, b.hA, D, rows, D, D, false, st)) return rc;
+  float *cur = b.hA, *nxt = b.hB;
+  for (int l = 0; l < d->NL; ++l) {
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st)) return rc;
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (out_res_emb) DIFFAB_HIP_CHECK(hipMemcpyAsync(out_res_emb, cur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
+  if (int rc = launch_beta_concat(cur, beta, D, d->K, rows, b.cat3, st)) return rc;
+  float* logits = out_logits ? out_logits : b.logits;
+  if (int rc = mlp3(d, &w->coord, b.cat3, b.t1, b.t2, out_eps, 3, st)) return rc;
+  if (int rc = mlp3(d, &w->orient, b.cat3, b.t1, b.t2, b.vbuf, 3, st)) return rc;
+  if (int rc = mlp3(d, &w->seq, b.cat3, b.t1, b.t2, logits, d->V, st)) return rc;
+  return launch_heads_finish(b.vbuf, O_t, logits, d->V, rows, out_O0, out_post, st);
+}
+
+static int check_denoiser_weights(const diffab_dims* d, const diffab_denoiser_weights* w) {
+  DIFFAB_REQUIRE(w && w->seq_emb && w->res_w0 && w->res_b0 && w->res_w2 && w->res_b2 && (d->NL == 0 || w->layers), DIFFAB_ERR_ARG,
+                 "denoiser: null weight pointer");
+  return DIFFAB_OK;
+}
+
+struct SampleBuffers {
+  float *beta, *eps, *O0, *post;
+  void* step;
+  size_t bytes;
+};
+
+static SampleBuffers carve_sample(const diffab_dims* d, void* ws) {
+  Carver c(ws);
+  const size_t rows = static_cast<size_t>(d->B) * d->K;
+  SampleBuffers s;
+  s.beta = c.take<float>(d->B);
+  s.eps = c.take<float>(rows * 3);
+  s.O0 = c.take<float>(rows * 9);
+  s.post = c.take<float>(rows * d->V);
+  const size_t step_bytes = carve_step(d, nullptr).bytes;
+  s.step = c.take<char>(step_bytes);
+  s.bytes = c.bytes();
+  return s;
+}
+
+}  // namespace diffab
+
+using namespace diffab;
+
+extern "C" {
+
+const char* diffab_version(void) { return "diffab_hip 0.1.0 (gfx950)"; }
+const char* diffab_last_error(void) { return g_err; }
+
+int diffab_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int diffab_kernel_timer_enable(int on) {
+  g_timer.on = on != 0;
+  g_timer.used = 0;
+  return DIFFAB_OK;
+}
+
+int diffab_kernel_timer_read(int64_t* launches, double* total_ms) {
+  DIFFAB_REQUIRE(launches && total_ms, DIFFAB_ERR_ARG, "kernel_timer_read: null pointer");
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < g_timer.used; i += 2) {
+    DIFFAB_HIP_CHECK(hipEventSynchronize(g_timer.ev[i + 1]));
+    float ms = 0.f;
+    DIFFAB_HIP_CHECK(hipEventElapsedTime(&ms, g_timer.ev[i], g_timer.ev[i + 1]));
+    tot += ms;
+  }
+  *launches = static_cast<int64_t>(g_timer.used / 2);
+  *total_ms = tot;
+  g_timer.used = 0;
+  return DIFFAB_OK;
+}
+
+size_t diffab_denoise_workspace_bytes(const diffab_dims* d) {
+  if (check_dims(d, "denoise_workspace_bytes")) return 0;
+  return carve_step(d, nullptr).bytes;
+}
+
+size_t diffab_sample_workspace_bytes(const diffab_dims* d) {
+  if (check_dims(d, "sample_workspace_bytes")) return 0;
+  return carve_sample(d, nullptr).bytes;
+}
+
+int diffab_ipa_layer_fwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
+                         const float* t, float* y, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+  if (int rc = check_dims(d, "ipa_layer_fwd")) return rc;
+  DIFFAB_REQUIRE(x && e && R && t && y && workspace, DIFFAB_ERR_ARG, "ipa_layer_fwd: null pointer");
+  const StepBuffers b = carve_step(d, workspace);
+  DIFFAB_REQUIRE(workspace_bytes >= b.bytes, DIFFAB_ERR_WORKSPACE, "ipa_layer_fwd: workspace %zu < %zu bytes", workspace_bytes, b.bytes);
+  return ipa_layer_dispatch(d, w, x, e, R, t, y, b.ipa, flags, as_stream(stream));
+}
+
+int diffab_denoise_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
+                            const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0,
+                            float* out_posterior, float* out_logits, float* out_res_emb, void* workspace, size_t workspace_bytes,
+                            uint32_t flags, void* stream) {
+  if (int rc = check_dims(d, "denoise_step_fwd")) return rc;
+  if (int rc = check_denoiser_weights(d, w)) return rc;
+  DIFFAB_REQUIRE(seq_t && x_t && O_t && res_ctx && pair_ctx && beta && out_eps && out_O0 && out_posterior && workspace, DIFFAB_ERR_ARG,
+                 "denoise_step_fwd: null pointer");
+  const size_t need = carve_step(d, nullptr).bytes;
+  DIFFAB_REQUIRE(workspace_bytes >= need, DIFFAB_ERR_WORKSPACE, "denoise_step_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+  return denoise_step(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, out_logits, out_res_emb, workspace,
+                      flags, as_stream(stream));
+}
+
+int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_sched* s, const diffab_igso3* rev_tab,
+                       int64_t* seq, float* x, float* O, const float* res_ctx, const float* pair_ctx, const uint8_t* gen_mask, uint64_t seed,
+                       int64_t first_patch, int32_t t_start, int32_t t_stop, void* workspace, size_t workspace_bytes, uint32_t flags,
+                       void* stream) {
+  if (int rc = check_dims(d, "sample_loop")) return rc;
+  if (int rc = check_denoiser_weights(d, w)) return rc;
+  DIFFAB_REQUIRE(s && s->T > 0 && s->alpha && s->beta && s->one_minus_alpha_bar_sqrt, DIFFAB_ERR_ARG, "sample_loop: bad schedule");
+  DIFFAB_REQUIRE(rev_tab && rev_tab->sigmas && rev_tab->cdf && rev_tab->n_sigmas >= s->T + 1 && rev_tab->n_bins > 0, DIFFAB_ERR_ARG,
+                 "sample_loop: reverse IGSO3 table must have T+1 rows");
+  DIFFAB_REQUIRE(seq && x && O && res_ctx && pair_ctx && gen_mask && workspace, DIFFAB_ERR_ARG, "sample_loop: null pointer");
+  DIFFAB_REQUIRE(t_start <= s->T && t_stop >= 0 && t_stop <= t_start, DIFFAB_ERR_ARG, "sample_loop: need T >= t_start >= t_stop >= 0");
+  const SampleBuffers sb = carve_sample(d, workspace);
+  DIFFAB_REQUIRE(workspace_bytes >= sb.bytes, DIFFAB_ERR_WORKSPACE, "sample_loop: workspace %zu < %zu bytes", workspace_bytes, sb.bytes);
+  hipStream_t st = as_stream(stream);
+  for (int t = t_start; t > t_stop; --t) {
+    if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st)) return rc;
+    if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st))
+      return rc;
+    if (int rc = launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K,
+                                              d->V, st))
+      return rc;
+  }
+  return DIFFAB_OK;
+}
+
+}  // extern "C"

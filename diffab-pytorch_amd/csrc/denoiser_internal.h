@@ -1,0 +1,36 @@
+// denoiser_internal.h - launchers shared between denoiser_generic.hip, denoiser_fast.hip and api.hip.
+#pragma once
+#include "common.h"
+
+namespace diffab {
+
+// generic (any dims)
+int launch_linear_generic(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
+                          hipStream_t st);
+size_t ipa_generic_workspace_floats(const diffab_dims* d);
+int ipa_layer_generic(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
+                      float* y, float* ws, hipStream_t st);
+int launch_embed_concat(const float* res_ctx, const float* emb, const int64_t* seq, int D, int64_t rows, float* out, hipStream_t st);
+int launch_beta_concat(const float* h, const float* beta, int D, int K, int64_t rows, float* out, hipStream_t st);
+int launch_heads_finish(const float* v, const float* O_t, const float* logits, int V, int64_t rows, float* O0, float* post, hipStream_t st);
+
+// MFMA path for the benchmark geometry (D=128, C=64, H=8, DS=32, PQ=PV=8, K % 16 == 0)
+bool fast_path_supported(const diffab_dims* d);
+size_t ipa_fast_workspace_floats(const diffab_dims* d);
+int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
+                   float* y, float* ws, hipStream_t st);
+// Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
+int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
+                  hipStream_t st);
+
+// api.hip: opt-in hipEvent bracket around the dominant (attention) kernel
+void timer_begin(hipStream_t st);
+void timer_end(hipStream_t st);
+
+// diffusion_kernels.hip
+int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
+                                 const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,
+                                 int64_t first_patch, int B, int K, int V, hipStream_t st);
+int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st);
+
+}  // namespace diffab

@@ -1,0 +1,626 @@
+// diffusion_kernels.hip - forward/reverse diffusion, SO(3)/IGSO3 and loss kernels + their C-ABI entries.
+// All of these are per-residue elementwise work (KBs per patch): one thread per residue (or per bin),
+// coalesced loads, no LDS except the loss and CDF reductions.  Compiled with -ffp-contract=off so that
+// a*x + b*y rounds like the reference's separate ATen ops.
+#include "common.h"
+#include "philox.h"
+#include "so3_math.h"
+
+namespace diffab {
+
+constexpr int kThreads = 256;
+static inline int blocks_for(int64_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
+constexpr float kPiF = 3.14159265358979323846f;
+constexpr double kPiD = 3.14159265358979323846;
+
+// Python-style negative indexing of the schedule (reference indexes sched[...][t - 1] with t = 0 -> last entry).
+__device__ inline int sched_index(int64_t t, int T) { return static_cast<int>(t < 0 ? t + (T + 1) : t); }
+
+// ------------------------------------------------------------------ SO(3) maps
+__global__ void so3_log_kernel(const float* __restrict__ R, float* __restrict__ S, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  float r[9], s[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r[k] = R[i * 9 + k];
+  so3_log(r, s);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) S[i * 9 + k] = s[k];
+}
+
+__global__ void so3_exp_kernel(const float* __restrict__ S, float* __restrict__ R, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  float s[9], r[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = S[i * 9 + k];
+  so3_exp(s, r);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[i * 9 + k] = r[k];
+}
+
+__global__ void so3_matrix_to_rotvec_kernel(const float* __restrict__ R, float* __restrict__ v, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  float r[9], s[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r[k] = R[i * 9 + k];
+  so3_log(r, s);
+  v[i * 3 + 0] = s[7];
+  v[i * 3 + 1] = s[2];
+  v[i * 3 + 2] = s[3];
+}
+
+__global__ void so3_rotvec_to_matrix_kernel(const float* __restrict__ v, float* __restrict__ R, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  float r[9];
+  so3_rotvec_to_matrix(v[i * 3 + 0], v[i * 3 + 1], v[i * 3 + 2], r);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[i * 9 + k] = r[k];
+}
+
+__global__ void so3_scale_rot_kernel(const float* __restrict__ R, const float* __restrict__ kk, float* __restrict__ out, int64_t n,
+                                     int64_t per_k) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  float r[9], o[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r[k] = R[i * 9 + k];
+  so3_scale(r, kk[i / per_k], o);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out[i * 9 + k] = o[k];
+}
+
+// ------------------------------------------------------------------ IGSO3 tables
+// pdf(theta; sigma) = (1 - cos theta)/pi * sum_l (2l+1) exp(-l(l+1) sigma^2) sin((l+1/2) theta)/sin(theta/2)
+// One thread per (sigma, bin); the series is summed in float64 and rounded once (the reference sums
+// 1024 float32 terms, so3.py:65-72; its result differs from this one by its own rounding error only).
+__global__ void igso3_pdf_kernel(const float* __restrict__ sigmas, int n_sigmas, int n_bins, int num_iters, float* __restrict__ pdf) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (gid >= static_cast<int64_t>(n_sigmas) * n_bins) return;
+  const int s = static_cast<int>(gid / n_bins), m = static_cast<int>(gid % n_bins);
+  const double width = kPiD / n_bins;
+  const double theta = static_cast<double>(static_cast<float>(m * width) + static_cast<float>(width / 2.0));
+  const double sg = static_cast<double>(sigmas[s]);
+  const double a = (1.0 - cos(theta)) / kPiD;
+  const double inv_sh = 1.0 / sin(theta / 2.0);
+  double acc = 0.0;
+  for (int l = 0; l < num_iters; ++l) {
+    const double ld = static_cast<double>(l);
+    acc += (2.0 * ld + 1.0) * exp(-ld * (ld + 1.0) * sg * sg) * sin((ld + 0.5) * theta) * inv_sh;
+  }
+  float v = static_cast<float>(a * acc);
+  if (!(v == v)) v = 0.0f;           // nan_to_num (so3.py:61)
+  if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  pdf[gid] = v < 0.0f ? 0.0f : v;    // clamp_min(0)
+}
+
+// One block per row: float64 inclusive prefix sum, normalised, last entry = 1.
+__global__ void igso3_cdf_kernel(const float* __restrict__ pdf, int n_bins, float* __restrict__ cdf) {
+  __shared__ double part[kThreads];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* p = pdf + static_cast<int64_t>(row) * n_bins;
+  float* c = cdf + static_cast<int64_t>(row) * n_bins;
+  const int per = (n_bins + kThreads - 1) / kThreads;
+  const int lo = tid * per, hi = min(lo + per, n_bins);
+  double s = 0.0;
+  for (int i = lo; i < hi; ++i) s += static_cast<double>(p[i]);
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double run = 0.0;
+    for (int i = 0; i < kThreads; ++i) {
+      const double v = part[i];
+      part[i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  __shared__ double total;
+  if (tid == kThreads - 1) total = part[tid] + s;
+  __syncthreads();
+  double run = part[tid];
+  const double inv = 1.0 / total;
+  for (int i = lo; i < hi; ++i) {
+    run += static_cast<double>(p[i]);
+    c[i] = (i == n_bins - 1) ? 1.0f : static_cast<float>(run * inv);
+  }
+}
+
+// first m with cdf[m] > u  (searchsorted right=True), clamped to n_bins-1
+__device__ inline int cdf_search(const float* __restrict__ row, int n_bins, float u) {
+  int lo = 0, hi = n_bins;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (row[mid] > u) hi = mid; else lo = mid + 1;
+  }
+  return min(lo, n_bins - 1);
+}
+
+__device__ inline float floor_mod_pi(float x) {
+  float r = fmodf(x, kPiF);
+  if (r != 0.0f && r < 0.0f) r += kPiF;
+  return r;
+}
+
+// theta for one draw (so3.py:74-96, 118-125)
+__device__ inline float igso3_theta(const float* __restrict__ cdf, int n_bins, float sigma, float thr, int row, float u_bin, float u_in,
+                                    float z) {
+  if (sigma < thr) {
+    const int m = cdf_search(cdf + static_cast<int64_t>(row) * n_bins, n_bins, u_bin);
+    const double width = kPiD / n_bins;
+    return static_cast<float>(m * width) + static_cast<float>(width) * u_in;
+  }
+  return floor_mod_pi(sigma * 2.0f + sigma * z);
+}
+
+__device__ inline void normalize3(float& x, float& y, float& z) {
+  const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);  // F.normalize eps (so3.py:114)
+  x /= n; y /= n; z /= n;
+}
+
+__global__ void igso3_sample_kernel(const float* __restrict__ sigmas, const float* __restrict__ cdf, int n_bins, float thr,
+                                    const int64_t* __restrict__ sigma_idx, int B, int K, const float* __restrict__ axis_raw,
+                                    const float* __restrict__ u_bin, const float* __restrict__ u_in, const float* __restrict__ z,
+                                    float* __restrict__ rotvec) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  const int b = static_cast<int>(i / K);
+  const int row = static_cast<int>(sigma_idx[b]);
+  const float theta = igso3_theta(cdf, n_bins, sigmas[row], thr, row, u_bin[i], u_in[i], z[i]);
+  float x = axis_raw[i * 3 + 0], y = axis_raw[i * 3 + 1], zz = axis_raw[i * 3 + 2];
+  normalize3(x, y, zz);
+  rotvec[i * 3 + 0] = x * theta;
+  rotvec[i * 3 + 1] = y * theta;
+  rotvec[i * 3 + 2] = zz * theta;
+}
+
+// ------------------------------------------------------------------ sequence diffusion
+constexpr int kV = 21;  // diffusion.py:47
+
+// centre weight w on the one-hot, (1-w)/21 uniform; exact one-hot when not generated.
+__device__ inline float seq_prob(int v, int64_t centre, float w_keep, float w_noise, bool gen) {
+  const float oh = (v == centre) ? 1.0f : 0.0f;
+  return gen ? (w_keep * oh + w_noise * (1.0f / 21.0f)) : oh;
+}
+
+__global__ void seq_forward_prob_kernel(const float* __restrict__ beta, const float* __restrict__ alpha_bar, int T, int mode,
+                                        const int64_t* __restrict__ seq, const int64_t* __restrict__ t, const uint8_t* __restrict__ mask,
+                                        int B, int K, float* __restrict__ prob) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  const int ti = sched_index(t[i / K], T);
+  float wk, wn;
+  if (mode == 0) { wn = beta[ti]; wk = 1.0f - wn; } else { wk = alpha_bar[ti]; wn = 1.0f - wk; }
+  const int64_t c = seq[i];
+  const bool g = mask[i] != 0;
+  for (int v = 0; v < kV; ++v) prob[i * kV + v] = seq_prob(v, c, wk, wn, g);
+}
+
+__global__ void seq_posterior_kernel(const float* __restrict__ beta, const float* __restrict__ alpha_bar, int T,
+                                     const int64_t* __restrict__ seq_t, const int64_t* __restrict__ seq_0, const int64_t* __restrict__ t,
+                                     const uint8_t* __restrict__ mask, int B, int K, float* __restrict__ post) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  const int64_t tt = t[i / K];
+  const float b = beta[sched_index(tt, T)];
+  const float ab = alpha_bar[sched_index(tt - 1, T)];
+  const int64_t ct = seq_t[i], c0 = seq_0[i];
+  const bool g = mask[i] != 0;
+  float p[kV];
+  float s = 0.0f;
+  for (int v = 0; v < kV; ++v) {
+    p[v] = seq_prob(v, ct, 1.0f - b, b, g) * seq_prob(v, c0, ab, 1.0f - ab, g);
+    s += p[v];
+  }
+  for (int v = 0; v < kV; ++v) post[i * kV + v] = p[v] / s;
+}
+
+__device__ inline int categorical_draw(const float* __restrict__ p, int V, float u) {
+  float tot = 0.0f;
+  for (int v = 0; v < V; ++v) tot += p[v];
+  const float thr = u * tot;
+  float acc = 0.0f;
+  for (int v = 0; v < V; ++v) {
+    acc += p[v];
+    if (acc > thr) return v;
+  }
+  return V - 1;
+}
+
+__global__ void categorical_sample_kernel(const float* __restrict__ prob, const float* __restrict__ u, int64_t n, int V,
+                                          int64_t* __restrict__ out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  out[i] = categorical_draw(prob + i * V, V, u[i]);
+}
+
+// ------------------------------------------------------------------ translation / orientation forward
+__global__ void coord_forward_kernel(const float* __restrict__ abs_, const float* __restrict__ omabs, int T, const float* __restrict__ x0,
+                                     const int64_t* __restrict__ t, const uint8_t* __restrict__ mask, const float* __restrict__ eps, int B,
+                                     int K, float* __restrict__ xt) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  const int ti = sched_index(t[i / K], T);
+  const float a = abs_[ti], b = omabs[ti];
+  const bool g = mask[i] != 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = x0[i * 3 + c];
+    xt[i * 3 + c] = g ? (a * x + b * eps[i * 3 + c]) : x;
+  }
+}
+
+__global__ void orient_forward_kernel(const float* __restrict__ abs_, int T, const float* __restrict__ O0, const uint8_t* __restrict__ mask,
+                                      const int64_t* __restrict__ t, const float* __restrict__ rotvec, int B, int K, float* __restrict__ Ot) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  float r[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r[k] = O0[i * 9 + k];
+  if (mask[i] != 0) {
+    float mean[9], noise[9], o[9];
+    so3_scale(r, abs_[sched_index(t[i / K], T)], mean);
+    so3_rotvec_to_matrix(rotvec[i * 3 + 0], rotvec[i * 3 + 1], rotvec[i * 3 + 2], noise);
+    mat3_mul(mean, noise, o);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = o[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Ot[i * 9 + k] = r[k];
+}
+
+// ------------------------------------------------------------------ Philox fill (tests / explicit-noise callers)
+__global__ void philox_fill_kernel(uint64_t seed, int64_t first_patch, int B, int K, int step, int stream_id, int kind,
+                                   float* __restrict__ out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  const uint32_t patch = static_cast<uint32_t>(first_patch + i / K), res = static_cast<uint32_t>(i % K);
+  const f32x4 u = philox_uniform4(seed, patch, res, static_cast<uint32_t>(step), static_cast<uint32_t>(stream_id));
+  const f32x4 r = kind == 0 ? normals_from_uniforms(u) : u;
+  reinterpret_cast<float4*>(out)[i] = make_float4(r.x, r.y, r.z, r.w);
+}
+
+// ------------------------------------------------------------------ losses
+// One block; deterministic tree reduction (diffab_pytorch.py:856-880).
+__global__ void losses_kernel(const float* __restrict__ pp, const float* __restrict__ tp, const float* __restrict__ pe,
+                              const float* __restrict__ te, const float* __restrict__ pO, const float* __restrict__ tO,
+                              const uint8_t* __restrict__ gm, const uint8_t* __restrict__ rm, int64_t n, int V, float* __restrict__ out3) {
+  __shared__ float red[4][1024];
+  float a_kl = 0.f, a_mse = 0.f, a_o = 0.f, a_n = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    if (!(gm[i] && rm[i])) continue;
+    a_n += 1.0f;
+    for (int v = 0; v < V; ++v) {
+      const float q = tp[i * V + v];
+      if (q > 0.0f) a_kl += q * logf(q) - q * logf(pp[i * V + v]);  // kl_div(log p, q): xlogy(q,q) - q log p
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = pe[i * 3 + c] - te[i * 3 + c];
+      a_mse += d * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) d += pO[i * 9 + r * 3 + j] * tO[i * 9 + r * 3 + k];  // pred^T target (:620-622)
+        d -= (j == k) ? 1.0f : 0.0f;
+        a_o += d * d;
+      }
+  }
+  red[0][threadIdx.x] = a_kl; red[1][threadIdx.x] = a_mse; red[2][threadIdx.x] = a_o; red[3][threadIdx.x] = a_n;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s)
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out3[threadIdx.x] = red[threadIdx.x][0] / red[3][0];
+}
+
+// (pred^T target - I)^2 element-wise (+ optional total), diffab_pytorch.py:610-625.  One block, fixed-order reduction.
+__global__ void orientation_loss_kernel(const float* __restrict__ pO, const float* __restrict__ tO, int64_t n, float* __restrict__ elems,
+                                        float* __restrict__ sum1) {
+  __shared__ float red[1024];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) d += pO[i * 9 + r * 3 + j] * tO[i * 9 + r * 3 + k];
+        d -= (j == k) ? 1.0f : 0.0f;
+        if (elems) elems[i * 9 + j * 3 + k] = d * d;
+        acc += d * d;
+      }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sum1) sum1[0] = red[0];
+}
+
+// ------------------------------------------------------------------ reverse update
+__device__ inline void reverse_update_one(int64_t i, int t, float beta, float alpha, float omabs, int64_t* seq, float* x, float* O,
+                                          const float* eps_hat, const float* O0_hat, const float* post, int V, float zx, float zy,
+                                          float zz, float rx, float ry, float rz, float u_seq) {
+  const float c = beta / omabs;
+  const float sa = sqrtf(alpha), sb = sqrtf(beta);
+  const float zn[3] = {zx, zy, zz};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = (x[i * 3 + k] - c * eps_hat[i * 3 + k]) / sa;
+    if (t > 1) v = v + sb * zn[k];
+    x[i * 3 + k] = v;
+  }
+  float o[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = O0_hat[i * 9 + k];
+  if (t > 1) {
+    float nz[9], r[9];
+    so3_rotvec_to_matrix(rx, ry, rz, nz);
+    mat3_mul(o, nz, r);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = r[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) O[i * 9 + k] = o[k];
+  seq[i] = categorical_draw(post + i * V, V, u_seq);
+}
+
+__global__ void reverse_update_kernel(const float* __restrict__ beta, const float* __restrict__ alpha, const float* __restrict__ omabs, int t,
+                                      int64_t* __restrict__ seq, float* __restrict__ x, float* __restrict__ O,
+                                      const float* __restrict__ eps_hat, const float* __restrict__ O0_hat, const float* __restrict__ post,
+                                      const uint8_t* __restrict__ gm, const float* __restrict__ z, const float* __restrict__ rotvec,
+                                      const float* __restrict__ u_seq, int B, int K, int V) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K || !gm[i]) return;
+  reverse_update_one(i, t, beta[t], alpha[t], omabs[t], seq, x, O, eps_hat, O0_hat, post, V, z[i * 3], z[i * 3 + 1], z[i * 3 + 2],
+                     rotvec[i * 3], rotvec[i * 3 + 1], rotvec[i * 3 + 2], u_seq[i]);
+}
+
+// Same update with the noise drawn in-kernel from Philox (the production sampler).
+__global__ void reverse_update_philox_kernel(const float* __restrict__ beta, const float* __restrict__ alpha, const float* __restrict__ omabs,
+                                             int t, const float* __restrict__ rev_sigmas, const float* __restrict__ rev_cdf, int n_bins,
+                                             float thr, int64_t* __restrict__ seq, float* __restrict__ x, float* __restrict__ O,
+                                             const float* __restrict__ eps_hat, const float* __restrict__ O0_hat,
+                                             const float* __restrict__ post, const uint8_t* __restrict__ gm, uint64_t seed,
+                                             int64_t first_patch, int B, int K, int V) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K || !gm[i]) return;
+  const uint32_t patch = static_cast<uint32_t>(first_patch + i / K), res = static_cast<uint32_t>(i % K), st = static_cast<uint32_t>(t);
+  const f32x4 zt = philox_normal4(seed, patch, res, st, STREAM_TRANS);
+  f32x4 ax = philox_normal4(seed, patch, res, st, STREAM_AXIS);
+  const f32x4 ua = philox_uniform4(seed, patch, res, st, STREAM_ANGLE);
+  const f32x4 na = normals_from_uniforms(ua);  // .z is the Box-Muller normal of (u2,u3)
+  const f32x4 us = philox_uniform4(seed, patch, res, st, STREAM_SEQ);
+  const float theta = igso3_theta(rev_cdf, n_bins, rev_sigmas[t], thr, t, ua.x, ua.y, na.z);
+  normalize3(ax.x, ax.y, ax.z);
+  reverse_update_one(i, t, beta[t], alpha[t], omabs[t], seq, x, O, eps_hat, O0_hat, post, V, zt.x, zt.y, zt.z, ax.x * theta,
+                     ax.y * theta, ax.z * theta, us.x);
+}
+
+__global__ void sample_init_kernel(int64_t* __restrict__ seq, float* __restrict__ x, float* __restrict__ O, const uint8_t* __restrict__ gm,
+                                   uint64_t seed, int64_t first_patch, int B, int K, int T) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K || !gm[i]) return;
+  const uint32_t patch = static_cast<uint32_t>(first_patch + i / K), res = static_cast<uint32_t>(i % K), st = static_cast<uint32_t>(T + 1);
+  const f32x4 nx = philox_normal4(seed, patch, res, st, STREAM_INIT_X);
+  x[i * 3 + 0] = nx.x; x[i * 3 + 1] = nx.y; x[i * 3 + 2] = nx.z;
+  f32x4 q = philox_normal4(seed, patch, res, st, STREAM_INIT_O);
+  const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+  const float w = q.x / qn, a = q.y / qn, b = q.z / qn, c = q.w / qn;  // (w, x, y, z)
+  float* o = O + i * 9;
+  o[0] = 1 - 2 * (b * b + c * c); o[1] = 2 * (a * b - c * w);     o[2] = 2 * (a * c + b * w);
+  o[3] = 2 * (a * b + c * w);     o[4] = 1 - 2 * (a * a + c * c); o[5] = 2 * (b * c - a * w);
+  o[6] = 2 * (a * c - b * w);     o[7] = 2 * (b * c + a * w);     o[8] = 1 - 2 * (a * a + b * b);
+  const f32x4 us = philox_uniform4(seed, patch, res, st, STREAM_INIT_S);
+  seq[i] = min(static_cast<int>(us.x * 20.0f), 19);
+}
+
+__global__ void fill_beta_kernel(const float* __restrict__ beta, int t, int B, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = beta[t];
+}
+
+// launchers used by api.hip (sample loop)
+int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
+                                 const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,
+                                 int64_t first_patch, int B, int K, int V, hipStream_t st) {
+  const int64_t n = static_cast<int64_t>(B) * K;
+  hipLaunchKernelGGL(reverse_update_philox_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, st, s->beta, s->alpha,
+                     s->one_minus_alpha_bar_sqrt, t, tab->sigmas, tab->cdf, tab->n_bins, tab->sigma_threshold, seq, x, O, eps_hat, O0_hat,
+                     post, gm, seed, first_patch, B, K, V);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(fill_beta_kernel, dim3((B + 255) / 256), dim3(256), 0, st, s->beta, t, B, out);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // namespace diffab
+
+using namespace diffab;
+
+static int check_sched(const diffab_sched* s) {
+  DIFFAB_REQUIRE(s && s->T > 0 && s->alpha && s->alpha_bar && s->alpha_bar_sqrt && s->one_minus_alpha_bar_sqrt && s->beta, DIFFAB_ERR_ARG,
+                 "schedule: null table or T <= 0");
+  return DIFFAB_OK;
+}
+
+#define ELEMENTWISE_ENTRY(NAME, KERNEL, NPTR_OK, N, ...)                                              \
+  DIFFAB_REQUIRE((NPTR_OK) && (N) >= 0, DIFFAB_ERR_ARG, NAME ": null pointer or negative count");     \
+  if ((N) == 0) return DIFFAB_OK;                                                                     \
+  hipLaunchKernelGGL(KERNEL, dim3(blocks_for(N)), dim3(kThreads), 0, as_stream(stream), __VA_ARGS__); \
+  DIFFAB_LAUNCH_CHECK();                                                                              \
+  return DIFFAB_OK;
+
+extern "C" {
+
+int diffab_so3_log(const float* R, float* S, int64_t n, void* stream) {
+  ELEMENTWISE_ENTRY("so3_log", so3_log_kernel, R && S, n, R, S, n)
+}
+int diffab_so3_exp(const float* S, float* R, int64_t n, void* stream) {
+  ELEMENTWISE_ENTRY("so3_exp", so3_exp_kernel, R && S, n, S, R, n)
+}
+int diffab_so3_matrix_to_rotvec(const float* R, float* v, int64_t n, void* stream) {
+  ELEMENTWISE_ENTRY("so3_matrix_to_rotvec", so3_matrix_to_rotvec_kernel, R && v, n, R, v, n)
+}
+int diffab_so3_rotvec_to_matrix(const float* v, float* R, int64_t n, void* stream) {
+  ELEMENTWISE_ENTRY("so3_rotvec_to_matrix", so3_rotvec_to_matrix_kernel, R && v, n, v, R, n)
+}
+int diffab_so3_scale_rot(const float* R, const float* k, float* out, int64_t n, int64_t per_k, void* stream) {
+  DIFFAB_REQUIRE(per_k > 0, DIFFAB_ERR_ARG, "so3_scale_rot: per_k must be positive");
+  ELEMENTWISE_ENTRY("so3_scale_rot", so3_scale_rot_kernel, R && k && out, n, R, k, out, n, per_k)
+}
+
+int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream) {
+  DIFFAB_REQUIRE(sigmas && pdf && n_sigmas > 0 && n_bins > 0 && num_iters > 0, DIFFAB_ERR_ARG, "igso3_table_build: bad argument");
+  const int64_t n = static_cast<int64_t>(n_sigmas) * n_bins;
+  hipLaunchKernelGGL(igso3_pdf_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), sigmas, n_sigmas, n_bins, num_iters, pdf);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, float* cdf, void* stream) {
+  DIFFAB_REQUIRE(pdf && cdf && n_sigmas > 0 && n_bins > 0, DIFFAB_ERR_ARG, "igso3_cdf_build: bad argument");
+  hipLaunchKernelGGL(igso3_cdf_kernel, dim3(n_sigmas), dim3(kThreads), 0, as_stream(stream), pdf, n_bins, cdf);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw, const float* u_bin,
+                        const float* u_in, const float* z, float* rotvec, void* stream) {
+  DIFFAB_REQUIRE(tab && tab->sigmas && tab->cdf && tab->n_bins > 0 && sigma_idx && axis_raw && u_bin && u_in && z && rotvec && B >= 0 &&
+                     K > 0,
+                 DIFFAB_ERR_ARG, "igso3_sample: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(igso3_sample_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), tab->sigmas, tab->cdf, tab->n_bins,
+                     tab->sigma_threshold, sigma_idx, B, K, axis_raw, u_bin, u_in, z, rotvec);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq, const int64_t* t, const uint8_t* mask, int32_t B,
+                            int32_t K, float* prob, void* stream) {
+  if (int rc = check_sched(s)) return rc;
+  DIFFAB_REQUIRE(seq && t && mask && prob && B >= 0 && K > 0 && (mode == 0 || mode == 1), DIFFAB_ERR_ARG, "seq_forward_prob: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(seq_forward_prob_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->beta, s->alpha_bar, s->T, mode,
+                     seq, t, mask, B, K, prob);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_seq_posterior(const diffab_sched* s, const int64_t* seq_t, const int64_t* seq_0, const int64_t* t, const uint8_t* mask,
+                         int32_t B, int32_t K, float* post, void* stream) {
+  if (int rc = check_sched(s)) return rc;
+  DIFFAB_REQUIRE(seq_t && seq_0 && t && mask && post && B >= 0 && K > 0, DIFFAB_ERR_ARG, "seq_posterior: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(seq_posterior_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->beta, s->alpha_bar, s->T, seq_t,
+                     seq_0, t, mask, B, K, post);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_categorical_sample(const float* prob, const float* u, int64_t n_rows, int32_t V, int64_t* out, void* stream) {
+  DIFFAB_REQUIRE(V > 0, DIFFAB_ERR_ARG, "categorical_sample: V must be positive");
+  ELEMENTWISE_ENTRY("categorical_sample", categorical_sample_kernel, prob && u && out, n_rows, prob, u, n_rows, V, out)
+}
+
+int diffab_coord_forward(const diffab_sched* s, const float* x0, const int64_t* t, const uint8_t* mask, const float* eps, int32_t B,
+                         int32_t K, float* xt, void* stream) {
+  if (int rc = check_sched(s)) return rc;
+  DIFFAB_REQUIRE(x0 && t && mask && eps && xt && B >= 0 && K > 0, DIFFAB_ERR_ARG, "coord_forward: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(coord_forward_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->alpha_bar_sqrt,
+                     s->one_minus_alpha_bar_sqrt, s->T, x0, t, mask, eps, B, K, xt);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_orient_forward(const diffab_sched* s, const float* O0, const uint8_t* mask, const int64_t* t, const float* rotvec, int32_t B,
+                          int32_t K, float* Ot, void* stream) {
+  if (int rc = check_sched(s)) return rc;
+  DIFFAB_REQUIRE(O0 && t && mask && rotvec && Ot && B >= 0 && K > 0, DIFFAB_ERR_ARG, "orient_forward: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(orient_forward_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->alpha_bar_sqrt, s->T, O0, mask, t,
+                     rotvec, B, K, Ot);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_philox_fill(uint64_t seed, int64_t first_patch, int32_t B, int32_t K, int32_t step, int32_t stream_id, int kind, float* out,
+                       void* stream) {
+  DIFFAB_REQUIRE(out && B >= 0 && K > 0 && (kind == 0 || kind == 1), DIFFAB_ERR_ARG, "philox_fill: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(philox_fill_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), seed, first_patch, B, K, step, stream_id,
+                     kind, out);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_losses_fwd(const float* pred_post, const float* true_post, const float* pred_eps, const float* true_eps, const float* pred_O0,
+                      const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, int32_t B, int32_t K, int32_t V,
+                      float* losses3, void* stream) {
+  DIFFAB_REQUIRE(pred_post && true_post && pred_eps && true_eps && pred_O0 && true_O0 && gen_mask && res_mask && losses3 && B > 0 && K > 0 &&
+                     V > 0,
+                 DIFFAB_ERR_ARG, "losses_fwd: bad argument");
+  hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(1024), 0, as_stream(stream), pred_post, true_post, pred_eps, true_eps, pred_O0, true_O0,
+                     gen_mask, res_mask, static_cast<int64_t>(B) * K, V, losses3);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream) {
+  DIFFAB_REQUIRE(pred && target && n > 0 && (elems || sum1), DIFFAB_ERR_ARG, "orientation_loss: bad argument");
+  hipLaunchKernelGGL(orientation_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), pred, target, n, elems, sum1);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_reverse_update(const diffab_sched* s, int32_t t, int64_t* seq, float* x, float* O, const float* eps_hat, const float* O0_hat,
+                          const float* posterior, const uint8_t* gen_mask, const float* z, const float* rotvec, const float* u_seq,
+                          int32_t B, int32_t K, int32_t V, void* stream) {
+  if (int rc = check_sched(s)) return rc;
+  DIFFAB_REQUIRE(seq && x && O && eps_hat && O0_hat && posterior && gen_mask && z && rotvec && u_seq && B >= 0 && K > 0 && V > 0 && t >= 1 &&
+                     t <= s->T,
+                 DIFFAB_ERR_ARG, "reverse_update: bad argument (t must be in [1, T])");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(reverse_update_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->beta, s->alpha,
+                     s->one_minus_alpha_bar_sqrt, t, seq, x, O, eps_hat, O0_hat, posterior, gen_mask, z, rotvec, u_seq, B, K, V);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_sample_init(int64_t* seq, float* x, float* O, const uint8_t* gen_mask, uint64_t seed, int64_t first_patch, int32_t B, int32_t K,
+                       int32_t T, void* stream) {
+  DIFFAB_REQUIRE(seq && x && O && gen_mask && B >= 0 && K > 0 && T > 0, DIFFAB_ERR_ARG, "sample_init: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(sample_init_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), seq, x, O, gen_mask, seed, first_patch, B,
+                     K, T);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // extern "C"

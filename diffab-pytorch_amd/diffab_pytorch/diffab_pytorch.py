@@ -1,0 +1,365 @@
+"""DiffAb module surface over the HIP engine (libdiffab_hip.so, gfx950).
+
+Mirrors the reference's ``diffab_pytorch/diffab_pytorch.py`` for the diffusion / denoise hot path:
+InvariantPointAttentionLayer (:339-465), InvariantPointAttentionModule (:468-498), Denoiser (:501-607),
+OrientationLoss (:610-625) and DiffAb (:628-931) keep their constructor signatures, method names,
+output dict keys and ``state_dict`` keys/shapes, so a checkpoint of the
+reference loads unchanged and callers need no edits.  The ``nn.Module`` objects only own the
+parameters; every forward is one C-ABI call into the HIP library - there is no ATen fallback.
+
+Not on this path ("next"): the context encoders ResidueEmbedding /
+PairEmbedding keep their parameters (so state_dicts round-trip) but ``encode_context`` is not yet
+implemented here; callers pass precomputed context embeddings.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from .diffusion import CoordinateDiffuser, OrientationDiffuser, SequenceDiffuser, cosine_variance_schedule
+from . import so3 as _so3
+
+try:  # LightningModule hooks when Lightning is installed; a plain nn.Module otherwise
+    import pytorch_lightning as pl
+
+    _ModuleBase = pl.LightningModule
+except ImportError:  # pragma: no cover - this image has no pytorch_lightning
+
+    class _ModuleBase(nn.Module):
+        def log_dict(self, *args, **kwargs):
+            pass
+
+        def log(self, *args, **kwargs):
+            pass
+
+
+CA_IDX = 1  # protstruc.general.ATOM.CA (reference diffab_pytorch.py:9, :820)
+
+
+def _named(module: nn.Module) -> Dict[str, torch.Tensor]:
+    return dict(module.named_parameters())
+
+
+class InvariantPointAttentionLayer(nn.Module):
+    """Reference IPA layer: no LayerNorm/residual/transition, raw gamma, unmasked (diffab_pytorch.py:339-465)."""
+
+    def __init__(self, d_residue_emb, d_pair_emb, d_scalar_per_head=16, n_query_point_per_head=4, n_value_point_per_head=4, n_head=8,
+                 use_pair_bias=True):
+        super().__init__()
+        if not use_pair_bias:
+            raise NotImplementedError("use_pair_bias=False is not on the DiffAb path and has no HIP kernel")
+        self.n_head = n_head
+        self.use_pair_bias = use_pair_bias
+        self.dims = dict(D=d_residue_emb, C=d_pair_emb, H=n_head, DS=d_scalar_per_head, PQ=n_query_point_per_head,
+                         PV=n_value_point_per_head)
+        d_scalar = d_scalar_per_head * n_head
+        # creation order = the reference's, so a seeded construction draws identical initial weights
+        self.to_q_scalar = nn.Linear(d_residue_emb, d_scalar, bias=False)
+        self.to_k_scalar = nn.Linear(d_residue_emb, d_scalar, bias=False)
+        self.to_v_scalar = nn.Linear(d_residue_emb, d_scalar, bias=False)
+        self.to_pair_bias = nn.Linear(d_pair_emb, n_head, bias=False)
+        self.to_q_point = nn.Linear(d_residue_emb, n_query_point_per_head * 3 * n_head, bias=False)
+        self.to_k_point = nn.Linear(d_residue_emb, n_query_point_per_head * 3 * n_head, bias=False)
+        self.to_v_point = nn.Linear(d_residue_emb, n_value_point_per_head * 3 * n_head, bias=False)
+        self.gamma = nn.Parameter(torch.log(torch.exp(torch.ones(n_head)) - 1.0))
+        self.to_out = nn.Linear(d_scalar + d_pair_emb * n_head + n_value_point_per_head * 3 * n_head + n_value_point_per_head * n_head,
+                                d_residue_emb)
+
+    def forward(self, x, e, r, t, *, flags: int = 0):
+        lib = _hip.lib()
+        xd, ed, rd, td = (_hip.dev_f32(a) for a in (x, e, r, t))
+        B, K = xd.shape[:2]
+        d = self.dims
+        dims = _hip.make_dims(B, K, d["D"], d["C"], d["H"], d["DS"], d["PQ"], d["PV"], 1)
+        keep: list = []
+        w = _hip.ipa_layer_weights(_named(self), keep)
+        ws = _hip.workspace(lib.diffab_denoise_workspace_bytes(C.byref(dims)))
+        y = torch.empty_like(xd)
+        _hip.check(lib.diffab_ipa_layer_fwd(C.byref(dims), C.byref(w), _hip.ptr(xd), _hip.ptr(ed), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(y),
+                                            _hip.ptr(ws), ws.numel(), flags, _hip.stream_ptr()), "diffab_ipa_layer_fwd")
+        return y.to(x.device)
+
+
+class InvariantPointAttentionModule(nn.Module):
+    """x <- layer(x, e, R, t) for each layer, same e/R/t (diffab_pytorch.py:468-498)."""
+
+    def __init__(self, n_layers, d_residue_emb, d_pair_emb, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head, n_head):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            InvariantPointAttentionLayer(d_residue_emb, d_pair_emb, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head, n_head)
+            for _ in range(n_layers)
+        ])
+
+    def forward(self, res_emb, pair_emb, orientations, translations, *, flags: int = 0):
+        dev = res_emb.device
+        x, e, r, t = (_hip.dev_f32(a) for a in (res_emb, pair_emb, orientations, translations))
+        for layer in self.layers:
+            x = layer(x, e, r, t, flags=flags)
+        return x.to(dev)
+
+
+class Denoiser(nn.Module):
+    """eps-hat, O0-hat and the aa posterior from (s_t, x_t, O_t, contexts, beta) (diffab_pytorch.py:501-607)."""
+
+    def __init__(self, d_residue_emb, d_pair_emb, n_ipa_layers, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head, n_head,
+                 aa_vocab_size):
+        super().__init__()
+        D = d_residue_emb
+        self.dims = dict(D=D, C=d_pair_emb, H=n_head, DS=d_scalar_per_head, PQ=n_query_point_per_head, PV=n_value_point_per_head,
+                         NL=n_ipa_layers, V=aa_vocab_size)
+        self.sequence_embedding = nn.Embedding(25, D)
+        self.to_res_emb = nn.Sequential(nn.Linear(D * 2, D), nn.ReLU(), nn.Linear(D, D))
+        self.ipa = InvariantPointAttentionModule(n_ipa_layers, D, d_pair_emb, d_scalar_per_head, n_query_point_per_head,
+                                                 n_value_point_per_head, n_head)
+
+        def head(n_out, softmax=False):
+            mods = [nn.Linear(D + 3, D), nn.ReLU(), nn.Linear(D, D), nn.ReLU(), nn.Linear(D, n_out)]
+            if softmax:
+                mods.append(nn.Softmax(dim=-1))
+            return nn.Sequential(*mods)
+
+        self.coordinate_denoising = head(3)
+        self.orientation_denoising = head(3)
+        self.sequence_denoising = head(aa_vocab_size, softmax=True)
+
+    def hip_weights(self) -> _hip.DenoiserWeightsOnDevice:
+        return _hip.DenoiserWeightsOnDevice(_named(self), self.dims["NL"])
+
+    def hip_dims(self, B: int, K: int) -> _hip.Dims:
+        d = self.dims
+        return _hip.make_dims(B, K, d["D"], d["C"], d["H"], d["DS"], d["PQ"], d["PV"], d["NL"], d["V"])
+
+    def forward(self, seq_idx_t, translations_t, orientations_t, res_context_emb, pair_context_emb, beta, generation_mask=None,
+                residue_mask=None, *, return_logits: bool = False, flags: int = 0) -> Dict[str, torch.Tensor]:
+        # generation_mask / residue_mask are accepted and ignored, exactly like the reference (:566-567).
+        lib = _hip.lib()
+        out_dev = translations_t.device
+        seq = _hip.dev_i64(seq_idx_t)
+        x, O, rc, pc, bt = (_hip.dev_f32(a) for a in (translations_t, orientations_t, res_context_emb, pair_context_emb, beta))
+        B, K = seq.shape
+        dims = self.hip_dims(B, K)
+        w = self.hip_weights()
+        ws = _hip.workspace(lib.diffab_denoise_workspace_bytes(C.byref(dims)))
+        dev = seq.device
+        eps = torch.empty(B, K, 3, dtype=torch.float32, device=dev)
+        O0 = torch.empty(B, K, 3, 3, dtype=torch.float32, device=dev)
+        post = torch.empty(B, K, dims.V, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, K, dims.V, dtype=torch.float32, device=dev) if return_logits else None
+        h = torch.empty(B, K, dims.D, dtype=torch.float32, device=dev) if return_logits else None
+        _hip.check(lib.diffab_denoise_step_fwd(C.byref(dims), C.byref(w.struct), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(rc),
+                                               _hip.ptr(pc), _hip.ptr(bt), _hip.ptr(eps), _hip.ptr(O0), _hip.ptr(post), _hip.ptr(logits),
+                                               _hip.ptr(h), _hip.ptr(ws), ws.numel(), flags, _hip.stream_ptr()), "diffab_denoise_step_fwd")
+        out = {"translations_eps": eps.to(out_dev), "orientations_t0": O0.to(out_dev), "seq_posterior": post.to(out_dev)}
+        if return_logits:
+            out["aa_logits"] = logits.to(out_dev)
+            out["res_emb"] = h.to(out_dev)
+        return out
+
+
+class OrientationLoss(nn.Module):
+    """(pred^T target - I)^2; reduction 'none' | 'mean' | 'sum' (diffab_pytorch.py:610-625)."""
+
+    def __init__(self, reduction="mean"):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, pred_rotmat: torch.Tensor, target_rotmat: torch.Tensor) -> torch.Tensor:
+        lib = _hip.lib()
+        p, t = _hip.dev_f32(pred_rotmat), _hip.dev_f32(target_rotmat)
+        n = p.numel() // 9
+        elems = torch.empty_like(p) if self.reduction == "none" else None
+        total = torch.empty(1, dtype=torch.float32, device=p.device)
+        _hip.check(lib.diffab_orientation_loss(_hip.ptr(p), _hip.ptr(t), n, _hip.ptr(elems), _hip.ptr(total), _hip.stream_ptr()),
+                   "diffab_orientation_loss")
+        if self.reduction == "none":
+            out = elems
+        elif self.reduction == "mean":
+            out = total[0] / float(9 * n)
+        else:
+            out = total[0]
+        return out.to(device=pred_rotmat.device, dtype=pred_rotmat.dtype)
+
+
+class _ParamsOnly(nn.Module):
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"{type(self).__name__} is a context encoder (reference diffab_pytorch.py:57-312): outside the hot path, "
+            "next on the list (SURVEY.md 8f-1).  Its parameters are kept so state_dicts round-trip; pass precomputed "
+            "res_context_emb / pair_context_emb instead.")
+
+
+class ResidueEmbedding(_ParamsOnly):
+    """Parameter container with the reference's keys/shapes/creation order (diffab_pytorch.py:57-79)."""
+
+    def __init__(self, max_n_atoms_per_residue, d_feat):
+        super().__init__()
+        self.max_n_aa_types = 21
+        self.max_n_atoms_per_residue = max_n_atoms_per_residue
+        self.amino_acid_type_embedding = nn.Embedding(self.max_n_aa_types, d_feat)
+        self.chain_embedding = nn.Embedding(10, d_feat, padding_idx=0)
+        d_in = d_feat + self.max_n_aa_types * max_n_atoms_per_residue * 3 + 3 * (3 * 2 * 2 + 1) + d_feat
+        self.mlp = nn.Sequential(nn.Linear(d_in, d_feat * 2), nn.ReLU(), nn.Linear(d_feat * 2, d_feat), nn.ReLU(),
+                                 nn.Linear(d_feat, d_feat), nn.ReLU(), nn.Linear(d_feat, d_feat))
+
+
+class PairEmbedding(_ParamsOnly):
+    """Parameter container with the reference's keys/shapes/creation order (diffab_pytorch.py:186-218)."""
+
+    def __init__(self, max_n_atoms_per_residue, d_feat, max_dist_to_consider=32):
+        super().__init__()
+        self.d_feat = d_feat
+        self.max_dist_to_consider = max_dist_to_consider
+        self.max_n_aa_types = 21
+        self.aa_pair_type_embedding = nn.Embedding(self.max_n_aa_types**2, d_feat)
+        self.relpos_embedding = nn.Embedding(2 * max_dist_to_consider + 1, d_feat)
+        self.pair2distcoef = nn.Embedding(self.max_n_aa_types**2, max_n_atoms_per_residue**2)
+        nn.init.zeros_(self.pair2distcoef.weight)
+        self.distance_embedding = nn.Sequential(nn.Linear(max_n_atoms_per_residue**2, d_feat), nn.ReLU(), nn.Linear(d_feat, d_feat),
+                                                nn.ReLU())
+        self.mlp = nn.Sequential(nn.Linear(3 * d_feat + 2 * (2 * 2 * 2 + 1), d_feat), nn.ReLU(), nn.Linear(d_feat, d_feat), nn.ReLU(),
+                                 nn.Linear(d_feat, d_feat))
+
+
+class DiffAb(_ModuleBase):
+    """Drop-in for ``diffab_pytorch.DiffAb`` on the diffusion hot path (reference diffab_pytorch.py:628-931)."""
+
+    def __init__(self, d_residue_emb, d_pair_emb, n_ipa_layers, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head, n_head,
+                 T=100, s=0.01, beta_max=0.999, n_atoms=15, aa_vocab_size=21, max_dist_to_consider=32, lr=1e-4, weight_decay=0.0,
+                 betas=(0.9, 0.999)):
+        super().__init__()
+        self.sched = cosine_variance_schedule(T=T, s=s, beta_max=beta_max)
+        self.residue_context_embedding = ResidueEmbedding(n_atoms, d_residue_emb)
+        self.pair_context_embedding = PairEmbedding(n_atoms, d_pair_emb, max_dist_to_consider)
+        self.denoiser = Denoiser(d_residue_emb, d_pair_emb, n_ipa_layers, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head,
+                                 n_head, aa_vocab_size)
+        self.seq_diffuser = SequenceDiffuser(T, s, beta_max, aa_vocab_size)
+        self.coordinate_diffuser = CoordinateDiffuser(T, s, beta_max)
+        self.orientation_diffuser = OrientationDiffuser(T, s, beta_max)
+        self.aa_loss = nn.KLDivLoss(reduction="none")
+        self.coordinate_loss = nn.MSELoss(reduction="none")
+        self.orientation_loss = OrientationLoss(reduction="none")
+        self.T = T
+        self.lr = lr
+        self.weight_decay = weight_decay
+        self.betas = betas
+        self._sched_dev: Optional[_hip.SchedOnDevice] = None
+        self._rev_so3: Optional[_so3.SO3] = None
+
+    # ------------------------------------------------------------------ device-side tables
+    def _sched_on_device(self) -> _hip.SchedOnDevice:
+        if self._sched_dev is None or self._sched_dev.tensors["beta"].device != _hip.device():
+            self._sched_dev = _hip.SchedOnDevice(self.sched)
+        return self._sched_dev
+
+    def _reverse_so3(self) -> _so3.SO3:
+        """IGSO3 table over sigma_t = sqrt(beta_t) for the reverse step (build-defined)."""
+        if self._rev_so3 is None or self._rev_so3.histograms.device != _hip.device():
+            self._rev_so3 = _so3.SO3(self.sched["beta"].sqrt(), sigma_threshold=0.1, n_bins=8192, num_iters=1024)
+        return self._rev_so3
+
+    # ------------------------------------------------------------------ reference API
+    def encode_context(self, seq_idx_t0, xyz_t0, orientations_t0, backbone_dihedrals, distmat, pairwise_dihedrals, atom_mask, chain_idx,
+                       residue_idx, generation_mask, residue_mask, generate_structure: bool = True, generate_sequence: bool = True):
+        raise NotImplementedError("encode_context (reference diffab_pytorch.py:680-724) is outside the hot path - SURVEY.md 8f-1, next; "
+                                  "pass res_context_emb / pair_context_emb")
+
+    def denoise(self, seq_idx_t, translations_t, orientations_t, res_context_emb, pair_context_emb, beta, generation_mask, residue_mask
+                ) -> Dict[str, torch.Tensor]:
+        """seq_posterior, translations_eps, orientations_t0 for a noisy state (diffab_pytorch.py:726-768)."""
+        return self.denoiser(seq_idx_t, translations_t, orientations_t, res_context_emb, pair_context_emb, beta, generation_mask,
+                             residue_mask)
+
+    def _add_noise(self, seq_idx_t0, translations_t0, orientations_t0, generation_mask, t) -> Dict[str, torch.Tensor]:
+        """Forward-noise all three modalities to timestep t (diffab_pytorch.py:778-806)."""
+        seq_idx_t, seq_posterior = self.seq_diffuser.diffuse_from_t0(seq_idx_t0, t, generation_mask, return_posterior=True)
+        translations_t, translations_eps = self.coordinate_diffuser.diffuse_from_t0(translations_t0, t, generation_mask, return_eps=True)
+        orientations_t = self.orientation_diffuser.diffuse_from_t0(orientations_t0, generation_mask, t)
+        return {"seq_idx_t": seq_idx_t, "seq_posterior": seq_posterior, "translations_t": translations_t,
+                "translations_eps": translations_eps, "orientations_t": orientations_t}
+
+    def hotpath_losses(self, denoised, noised, orientations_t0, generation_mask, residue_mask):
+        """(seq KL, translation MSE, orientation) each over masked residues / #masked residues (diffab_pytorch.py:856-880)."""
+        lib = _hip.lib()
+        pp, tp = _hip.dev_f32(denoised["seq_posterior"]), _hip.dev_f32(noised["seq_posterior"])
+        pe, te = _hip.dev_f32(denoised["translations_eps"]), _hip.dev_f32(noised["translations_eps"])
+        pO, tO = _hip.dev_f32(denoised["orientations_t0"]), _hip.dev_f32(orientations_t0)
+        gm, rm = _hip.dev_mask(generation_mask), _hip.dev_mask(residue_mask)
+        B, K, V = pp.shape
+        out = torch.empty(3, dtype=torch.float32, device=pp.device)
+        _hip.check(lib.diffab_losses_fwd(_hip.ptr(pp), _hip.ptr(tp), _hip.ptr(pe), _hip.ptr(te), _hip.ptr(pO), _hip.ptr(tO), _hip.ptr(gm),
+                                         _hip.ptr(rm), B, K, V, _hip.ptr(out), _hip.stream_ptr()), "diffab_losses_fwd")
+        return out[0], out[1], out[2]
+
+    def _shared_step(self, batch, batch_idx):
+        """t ~ U[1,T]; noise; denoise; three losses (diffab_pytorch.py:808-880).  Context embeddings are taken from
+        batch['res_context_emb'] / batch['pair_context_emb'] until encode_context lands on this path."""
+        dev_in = batch["generation_mask"].device
+        bsz = batch["generation_mask"].size(0)
+        t = torch.randint(low=1, high=self.T + 1, size=(bsz,)).to(dev_in)
+        beta = self.sched["beta"][t.cpu()].to(dev_in)
+        xyz_t0 = batch["xyz"]
+        translations_t0 = xyz_t0[:, :, CA_IDX] if xyz_t0.dim() == 4 else xyz_t0
+        noised = self._add_noise(batch["seq_idx"], translations_t0, batch["orientations"], batch["generation_mask"], t)
+        if "res_context_emb" in batch and "pair_context_emb" in batch:
+            res_ctx, pair_ctx = batch["res_context_emb"], batch["pair_context_emb"]
+        else:
+            res_ctx, pair_ctx = self.encode_context(batch["seq_idx"], xyz_t0, batch["orientations"], batch["backbone_dihedrals"],
+                                                    batch["distmat"], batch["pairwise_dihedrals"], batch["atom_mask"], batch["chain_idx"],
+                                                    batch["residue_idx"], batch["generation_mask"], batch["residue_mask"])
+        denoised = self.denoise(noised["seq_idx_t"], noised["translations_t"], noised["orientations_t"], res_ctx, pair_ctx, beta,
+                                batch["generation_mask"], batch["residue_mask"])
+        return self.hotpath_losses(denoised, noised, batch["orientations"], batch["generation_mask"], batch["residue_mask"])
+
+    def training_step(self, batch, batch_idx):
+        raise NotImplementedError("the backward kernels of the denoise step are not built yet (DESIGN.md, 'what comes next'); "
+                                  "validation_step / sample run on HIP today")
+
+    def validation_step(self, batch, batch_idx):
+        seq_loss, translations_loss, orientations_loss = self._shared_step(batch, batch_idx)
+        loss = seq_loss + translations_loss + orientations_loss
+        self.log_dict({"val/seq_loss": seq_loss, "val/translations_loss": translations_loss, "val/orientations_loss": orientations_loss,
+                       "val/loss": loss}, on_step=False, on_epoch=True, prog_bar=False, logger=True)
+        return loss
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay, betas=self.betas)
+
+    # ------------------------------------------------------------------ reverse process (the reference has a stub, :770-776)
+    @torch.no_grad()
+    def sample(self, seq_idx: torch.LongTensor, xyz: torch.FloatTensor, orientations: torch.FloatTensor, *, res_context_emb=None,
+               pair_context_emb=None, generation_mask=None, seed: Optional[int] = None, first_patch: int = 0, t_start: Optional[int] = None,
+               t_stop: int = 0, init: bool = True, flags: int = 0) -> Dict[str, torch.Tensor]:
+        """Reverse diffusion t_start .. t_stop+1 (default T .. 1) on the generated residues.
+
+        seq_idx (B,K), xyz (B,K,3) CA translations or (B,K,A,3) atoms, orientations (B,K,3,3): the ground-truth
+        context; generated residues are re-initialised (x ~ N(0,I), O ~ U(SO3), s ~ U{0..19}) when ``init``.
+        Noise is Philox keyed by (seed, first_patch + b, residue, t): any sharding of a batch over ranks gives
+        the same samples.  All T steps are enqueued on the current stream by ONE C-ABI call, no host sync."""
+        if res_context_emb is None or pair_context_emb is None or generation_mask is None:
+            raise NotImplementedError("sample() needs res_context_emb, pair_context_emb and generation_mask until encode_context "
+                                      "is on this path (SURVEY.md 8f-1)")
+        lib = _hip.lib()
+        out_dev = seq_idx.device
+        seq = _hip.dev_i64(seq_idx).clone()
+        x = _hip.dev_f32(xyz[:, :, CA_IDX] if xyz.dim() == 4 else xyz).clone()
+        O = _hip.dev_f32(orientations).clone()
+        rc, pc, gm = _hip.dev_f32(res_context_emb), _hip.dev_f32(pair_context_emb), _hip.dev_mask(generation_mask)
+        B, K = seq.shape
+        seed = _so3._draw_seed() if seed is None else int(seed)
+        t_start = self.T if t_start is None else int(t_start)
+        dims = self.denoiser.hip_dims(B, K)
+        w = self.denoiser.hip_weights()
+        sd = self._sched_on_device()
+        tab = self._reverse_so3().struct()
+        ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(dims)))
+        if init:
+            _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, self.T,
+                                              _hip.stream_ptr()), "diffab_sample_init")
+        _hip.check(lib.diffab_sample_loop(C.byref(dims), C.byref(w.struct), C.byref(sd.struct), C.byref(tab), _hip.ptr(seq), _hip.ptr(x),
+                                          _hip.ptr(O), _hip.ptr(rc), _hip.ptr(pc), _hip.ptr(gm), seed, first_patch, t_start, t_stop,
+                                          _hip.ptr(ws), ws.numel(), flags, _hip.stream_ptr()), "diffab_sample_loop")
+        return {"seq_idx": seq.to(out_dev), "translations": x.to(out_dev), "orientations": O.to(out_dev)}

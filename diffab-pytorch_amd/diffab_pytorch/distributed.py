@@ -1,0 +1,56 @@
+"""Patch sharding over ranks (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+Patches are independent everywhere on the hot path (reference: every einsum carries the batch index,
+diffab_pytorch.py:416-457), so the path shards with NO data-path collective: rank r owns a contiguous range of
+global patch ids, noise is keyed by the global id (csrc/philox.h), and the only exchange is ONE all-gather of the
+sampled structures at the end - 7 168 B per K=128 patch (s int64 + x 3 f32 + O 9 f32 per residue), a single
+fixed-size buffer per rank so RCCL moves it in one collective over xGMI.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+
+def shard_range(n_patches: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, even split of [0, n_patches): the first n % world ranks get one extra patch."""
+    q, r = divmod(n_patches, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def pack_samples(s: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """(B,K) int64 + (B,K,3) f32 + (B,K,3,3) f32 -> one (B,K,14) int32 buffer (bit-exact round trip)."""
+    seq = s["seq_idx"].contiguous().view(torch.int32).view(*s["seq_idx"].shape, 2)
+    x = s["translations"].contiguous().view(torch.int32)
+    O = s["orientations"].contiguous().view(torch.int32).flatten(-2)
+    return torch.cat([seq, x, O], dim=-1).contiguous()
+
+
+def unpack_samples(buf: torch.Tensor) -> Dict[str, torch.Tensor]:
+    B, K = buf.shape[:2]
+    return {
+        "seq_idx": buf[..., 0:2].contiguous().view(torch.int64).view(B, K),
+        "translations": buf[..., 2:5].contiguous().view(torch.float32),
+        "orientations": buf[..., 5:14].contiguous().view(torch.float32).view(B, K, 3, 3),
+    }
+
+
+def gather_samples(local: Dict[str, torch.Tensor], dist=None, sizes: Optional[list] = None) -> Dict[str, torch.Tensor]:
+    """All ranks' samples in global patch order.  `dist` is torch.distributed (initialised) or None for one process.
+    Equal shard sizes use one all_gather_into_tensor; ragged shards (sizes = patches per rank) pad to the maximum."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    buf = pack_samples(local)
+    B = buf.shape[0]
+    if sizes is None:
+        sizes = [B] * world
+    Bmax = max(sizes)
+    if B < Bmax:
+        buf = torch.cat([buf, buf.new_zeros(Bmax - B, *buf.shape[1:])])
+    out = buf.new_empty(world * Bmax, *buf.shape[1:])
+    dist.all_gather_into_tensor(out, buf.contiguous())
+    parts = [out[r * Bmax: r * Bmax + sizes[r]] for r in range(world)]
+    return unpack_samples(torch.cat(parts))

@@ -1,0 +1,213 @@
+/*
+ * diffab_hip.h - C ABI of libdiffab_hip.so: the MI355X (gfx950) engine under the
+ * DiffAb diffusion / denoise hot path.
+ *
+ * The reference (dohlee/diffab-pytorch) is pure Python on stock ATen ops and has
+ * no FFI of its own; its boundary for this path is the
+ * Python class surface of diffab_pytorch.DiffAb.  This header is the C ABI a
+ * maintainer binds underneath that surface (ctypes stub: INTEGRATION.md).  Each
+ * entry point cites the reference code it replaces, file:line relative to the
+ * reference repository root.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers and sizes; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*, NULL = default stream);
+ *   - row-major, contiguous, float32 unless stated; residue/aa indices and
+ *     timesteps are int64 (torch.LongTensor), masks are 1 byte per element
+ *     (torch.bool);
+ *   - the caller owns every buffer including the workspace (size from the
+ *     matching *_workspace_bytes query); kernels are enqueued on `stream` and
+ *     never synchronise; no hidden global state; re-entrant across streams;
+ *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
+ *     diffab_last_error() gives the thread's last message.
+ */
+#ifndef DIFFAB_HIP_H
+#define DIFFAB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIFFAB_OK 0
+#define DIFFAB_ERR_ARG (-1)         /* null pointer / non-positive size / inconsistent dims */
+#define DIFFAB_ERR_UNSUPPORTED (-2) /* dims outside what the kernels cover */
+#define DIFFAB_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define DIFFAB_ERR_WORKSPACE (-4)   /* workspace too small */
+
+/* flags */
+#define DIFFAB_FLAG_FORCE_GENERIC 1u /* skip the MFMA kernels specialised for D=128,C=64,H=8,DS=32,P=8 */
+
+/* Model and batch geometry.  Reference ctor: diffab_pytorch.py:629-647. */
+typedef struct {
+  int32_t B;  /* patches in this call */
+  int32_t K;  /* residues per patch */
+  int32_t D;  /* d_residue_emb */
+  int32_t C;  /* d_pair_emb */
+  int32_t H;  /* n_head */
+  int32_t DS; /* d_scalar_per_head */
+  int32_t PQ; /* n_query_point_per_head */
+  int32_t PV; /* n_value_point_per_head */
+  int32_t NL; /* n_ipa_layers */
+  int32_t V;  /* aa vocabulary (21; reference diffusion.py:47) */
+} diffab_dims;
+
+/* One InvariantPointAttentionLayer's parameters in nn.Linear layout (out x in),
+ * i.e. pointers straight into the reference's state_dict tensors
+ * (diffab_pytorch.py:354-379; keys: SURVEY Appendix B.3). */
+typedef struct {
+  const float* gamma;  /* (H)                     raw, no softplus (:373) */
+  const float* wq_s;   /* (H*DS, D)  to_q_scalar.weight */
+  const float* wk_s;   /* (H*DS, D)  to_k_scalar.weight */
+  const float* wv_s;   /* (H*DS, D)  to_v_scalar.weight */
+  const float* w_bias; /* (H, C)     to_pair_bias.weight */
+  const float* wq_p;   /* (H*PQ*3, D) to_q_point.weight */
+  const float* wk_p;   /* (H*PQ*3, D) to_k_point.weight */
+  const float* wv_p;   /* (H*PV*3, D) to_v_point.weight */
+  const float* w_out;  /* (D, H*DS + H*C + H*PV*3 + H*PV) to_out.weight */
+  const float* b_out;  /* (D) to_out.bias */
+} diffab_ipa_layer_weights;
+
+/* Linear-ReLU-Linear-ReLU-Linear head (diffab_pytorch.py:533-556). */
+typedef struct {
+  const float *w0, *b0; /* (D, D+3), (D) */
+  const float *w2, *b2; /* (D, D), (D) */
+  const float *w4, *b4; /* (n_out, D), (n_out) */
+} diffab_mlp3_weights;
+
+/* Denoiser parameters (diffab_pytorch.py:501-556). `layers` is a HOST array of NL. */
+typedef struct {
+  const float* seq_emb;           /* (25, D) sequence_embedding.weight (:514) */
+  const float *res_w0, *res_b0;   /* (D, 2D), (D)  to_res_emb.0 */
+  const float *res_w2, *res_b2;   /* (D, D), (D)   to_res_emb.2 */
+  const diffab_ipa_layer_weights* layers;
+  diffab_mlp3_weights coord;      /* coordinate_denoising  -> 3 */
+  diffab_mlp3_weights orient;     /* orientation_denoising -> 3 */
+  diffab_mlp3_weights seq;        /* sequence_denoising    -> V (softmax applied by the kernel) */
+} diffab_denoiser_weights;
+
+/* Variance schedule on the device: five (T+1) float arrays
+ * (diffusion.py:11-35; keys alpha, alpha_bar, alpha_bar_sqrt,
+ * one_minus_alpha_bar_sqrt, beta). */
+typedef struct {
+  int32_t T;
+  const float* alpha;
+  const float* alpha_bar;
+  const float* alpha_bar_sqrt;
+  const float* one_minus_alpha_bar_sqrt;
+  const float* beta;
+} diffab_sched;
+
+/* IGSO3 tables on the device (so3.py:9-72): one row per sigma. */
+typedef struct {
+  int32_t n_sigmas;
+  int32_t n_bins;
+  const float* sigmas;   /* (n_sigmas) */
+  const float* cdf;      /* (n_sigmas, n_bins) normalised inclusive prefix sums of the pdf rows */
+  float sigma_threshold; /* histogram branch iff sigma < threshold (so3.py:122-125) */
+} diffab_igso3;
+
+const char* diffab_version(void);
+const char* diffab_last_error(void);
+/* 1 if a gfx950 device is visible to this process, else 0 (no error). */
+int diffab_device_ok(void);
+
+/* Opt-in diagnostics for bench.py's roofline leg: while enabled, every launch of the dominant kernel (the IPA
+ * attention kernel) is bracketed by a hipEvent pair recorded on its launch stream.  read() waits for the events,
+ * returns the number of launches and their summed duration, and resets the counter.  Not thread-safe; off by default. */
+int diffab_kernel_timer_enable(int on);
+int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
+
+/* ---- SO(3) maps, n matrices/vectors each --------------------------------- */
+/* so3.py:146-162  log R = theta/(2 sin theta) (R - R^T); NaN at theta = 0 like the reference */
+int diffab_so3_log(const float* R, float* S, int64_t n, void* stream);
+/* so3.py:219-237  exp of a skew-symmetric matrix (Rodrigues); NaN at |v| = 0 like the reference */
+int diffab_so3_exp(const float* S, float* R, int64_t n, void* stream);
+/* so3.py:173-182 */
+int diffab_so3_matrix_to_rotvec(const float* R, float* v, int64_t n, void* stream);
+/* so3.py:207-216 */
+int diffab_so3_rotvec_to_matrix(const float* v, float* R, int64_t n, void* stream);
+/* so3.py:240-259  exp(k log R); k has n/per_k entries, k[i / per_k] scales matrix i */
+int diffab_so3_scale_rot(const float* R, const float* k, float* out, int64_t n, int64_t per_k, void* stream);
+
+/* ---- IGSO3 ---------------------------------------------------------------- */
+/* so3.py:52-72  pdf[n_sigmas][n_bins] at the bin centres, series of num_iters terms, NaN->0, <0 -> 0 */
+int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream);
+/* build-defined: cdf rows = normalised inclusive prefix sums (float64 accumulate) of the pdf rows */
+int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, float* cdf, void* stream);
+/* so3.py:98-126  rot-vectors (B,K,3) = normalize(axis_raw) * theta, theta from the histogram row
+ * sigma_idx[b] (inverse CDF on u_bin, uniform in the bin by u_in) if sigma < threshold, else
+ * (2 sigma + sigma z) mod pi.  axis_raw (B,K,3), u_bin/u_in/z (B,K). */
+int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
+                        const float* u_bin, const float* u_in, const float* z, float* rotvec, void* stream);
+
+/* ---- forward (noising) process, explicit noise ----------------------------- */
+/* diffusion.py:49-79 (mode 0: q(s_t|s_{t-1}), beta_t), :105-135 (mode 1: q(s_t|s_0), alpha_bar_t) */
+int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq, const int64_t* t, const uint8_t* mask,
+                            int32_t B, int32_t K, float* prob /* (B,K,21) */, void* stream);
+/* diffusion.py:168-192 */
+int diffab_seq_posterior(const diffab_sched* s, const int64_t* seq_t, const int64_t* seq_0, const int64_t* t,
+                         const uint8_t* mask, int32_t B, int32_t K, float* post /* (B,K,21) */, void* stream);
+/* diffusion.py:156-158 (torch.multinomial replaced by inverse CDF on the given uniforms) */
+int diffab_categorical_sample(const float* prob, const float* u, int64_t n_rows, int32_t V, int64_t* out, void* stream);
+/* diffusion.py:199-236 */
+int diffab_coord_forward(const diffab_sched* s, const float* x0, const int64_t* t, const uint8_t* mask, const float* eps,
+                         int32_t B, int32_t K, float* xt, void* stream);
+/* diffusion.py:262-294 */
+int diffab_orient_forward(const diffab_sched* s, const float* O0, const uint8_t* mask, const int64_t* t,
+                          const float* rotvec, int32_t B, int32_t K, float* Ot, void* stream);
+
+/* ---- counter-based noise (Philox4x32-10) ------------------------------------ */
+/* out[(b*K + k)*4 + c], c = 0..3: normals (kind 0) or uniforms in (0,1) (kind 1) for
+ * counter (residue k, patch first_patch + b, step, stream_id), key = seed. */
+int diffab_philox_fill(uint64_t seed, int64_t first_patch, int32_t B, int32_t K, int32_t step, int32_t stream_id, int kind,
+                       float* out, void* stream);
+
+/* ---- IPA / denoiser --------------------------------------------------------- */
+size_t diffab_denoise_workspace_bytes(const diffab_dims* d);
+size_t diffab_sample_workspace_bytes(const diffab_dims* d); /* for diffab_sample_loop */
+/* diffab_pytorch.py:389-465  one InvariantPointAttentionLayer.forward */
+int diffab_ipa_layer_fwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x /* (B,K,D) */,
+                         const float* e /* (B,K,K,C) */, const float* R /* (B,K,3,3) */, const float* t /* (B,K,3) */,
+                         float* y /* (B,K,D) */, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+/* diffab_pytorch.py:558-607  Denoiser.forward == DiffAb.denoise (:726-768).
+ * out_logits (B,K,V) pre-softmax and out_res_emb (B,K,D) post-IPA are optional (NULL to skip). */
+int diffab_denoise_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
+                            const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta /* (B) */,
+                            float* out_eps, float* out_O0, float* out_posterior, float* out_logits, float* out_res_emb,
+                            void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
+/* ---- losses (diffab_pytorch.py:610-625, 856-880) ----------------------------- */
+/* losses[3] = (seq KL, translation MSE, orientation) each summed over masked residues / #masked residues.
+ * One work-group, fixed-order tree reduction: bitwise reproducible. */
+int diffab_losses_fwd(const float* pred_post, const float* true_post, const float* pred_eps, const float* true_eps,
+                      const float* pred_O0, const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask,
+                      int32_t B, int32_t K, int32_t V, float* losses3, void* stream);
+
+/* diffab_pytorch.py:610-625  OrientationLoss: elems (n,3,3) = (pred^T target - I)^2 and/or their total (either may be NULL) */
+int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream);
+
+/* ---- reverse process (build-defined; reference stub diffab_pytorch.py:770-776) -- */
+/* One update t -> t-1 from denoiser outputs with explicit noise (z (B,K,3), rotvec (B,K,3), u_seq (B,K)),
+ * in place on (seq, x, O), only where gen_mask is set. */
+int diffab_reverse_update(const diffab_sched* s, int32_t t, int64_t* seq, float* x, float* O, const float* eps_hat,
+                          const float* O0_hat, const float* posterior, const uint8_t* gen_mask, const float* z,
+                          const float* rotvec, const float* u_seq, int32_t B, int32_t K, int32_t V, void* stream);
+/* The whole reverse trajectory t = t_start .. t_stop+1 (normally T .. 1) for B patches, all launches
+ * enqueued on `stream` with no host synchronisation: denoise step + Philox noise + IGSO3 draw (table
+ * over sqrt(beta)) + update.  State (seq, x, O) is updated in place.  Noise is keyed by
+ * (seed, first_patch + b, residue, t), so any sharding of a batch over ranks gives identical samples. */
+int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_sched* s,
+                       const diffab_igso3* rev_tab, int64_t* seq, float* x, float* O, const float* res_ctx,
+                       const float* pair_ctx, const uint8_t* gen_mask, uint64_t seed, int64_t first_patch, int32_t t_start,
+                       int32_t t_stop, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+/* Initial state at t = T on generated residues: x ~ N(0,I), O ~ uniform SO(3), s ~ U{0..19} (Philox, step = T+1). */
+int diffab_sample_init(int64_t* seq, float* x, float* O, const uint8_t* gen_mask, uint64_t seed, int64_t first_patch,
+                       int32_t B, int32_t K, int32_t T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFAB_HIP_H */

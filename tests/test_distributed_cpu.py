@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the sampler - shard ranges, bit-exact packing, and the single
+all-gather that collects sampled structures in global patch order (ragged shards included)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffab_pytorch.distributed import gather_samples, pack_samples, shard_range, unpack_samples
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(2048, 3, 8) == (768, 1024)
+
+
+def _fake(lo, hi, K=16):
+    g = torch.Generator().manual_seed(1234)
+    seq = torch.randint(0, 21, (10, K), generator=g)
+    x = torch.randn(10, K, 3, generator=g)
+    O = torch.randn(10, K, 3, 3, generator=g)
+    x[0, 0, 0] = float("nan")  # packing must be a bit copy, NaN payloads included
+    return {"seq_idx": seq[lo:hi], "translations": x[lo:hi], "orientations": O[lo:hi]}
+
+
+def test_pack_roundtrip_bit_exact():
+    s = _fake(0, 10)
+    r = unpack_samples(pack_samples(s))
+    assert torch.equal(r["seq_idx"], s["seq_idx"])
+    assert torch.equal(r["translations"].view(torch.int32), s["translations"].view(torch.int32))
+    assert torch.equal(r["orientations"].view(torch.int32), s["orientations"].view(torch.int32))
+    assert pack_samples(s).shape == (10, 16, 14) and pack_samples(s).element_size() * 14 * 128 == 7168  # 7 168 B / K=128 patch
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(n, rank, world)
+        sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+        out = gather_samples(_fake(lo, hi), dist, sizes=sizes)
+        full = _fake(0, n)
+        ok = all(torch.equal(out[k].view(torch.int32) if out[k].dtype.is_floating_point else out[k],
+                             full[k].view(torch.int32) if full[k].dtype.is_floating_point else full[k]) for k in full)
+        q.put((rank, ok, tuple(out["translations"].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10, 7])
+def test_gather_world2_gloo(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape[0] == n for _, _, shape in res)
