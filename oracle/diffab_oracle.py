@@ -225,7 +225,11 @@ def igso3_bin_from_cdf(cdf_rows: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     cdf[m] > u.  cdf_rows (..., n_bins) matches u (...,) on the leading dims.
     The reference draws K bins per row WITHOUT replacement with
     torch.multinomial (so3.py:78); see DESIGN.md."""
-    idx = torch.searchsorted(cdf_rows, u[..., None].contiguous(), right=True)[..., 0]
+    cdf_rows = cdf_rows.contiguous()
+    if cdf_rows.ndim == u.ndim + 1:  # one table row per draw
+        idx = torch.searchsorted(cdf_rows, u[..., None].contiguous(), right=True)[..., 0]
+    else:  # one table row per leading index, many draws per row
+        idx = torch.searchsorted(cdf_rows, u.contiguous(), right=True)
     return idx.clamp_max(cdf_rows.shape[-1] - 1)
 
 
