@@ -48,7 +48,6 @@ def cpu_baseline(dims, sd, K, n_patches, n_steps, seed):
     import diffab_oracle as orc
     from diffab_pytorch import synthetic as syn
 
-    threads = torch.get_num_threads()
     inp = syn.patches(n_patches, K, dims, seed=seed, coord_sigma=10.0)
     sched = orc.cosine_variance_schedule(100, s=0.01, beta_max=0.999)
     sdo = {"denoiser." + k: v for k, v in sd.items()}
@@ -65,19 +64,31 @@ def cpu_baseline(dims, sd, K, n_patches, n_steps, seed):
         u = torch.from_numpy(orc.philox_uniform4(seed, patch, res, t, 0)[0])
         return orc.reverse_update(t, seq, x, O, den, gm, sched, z, rv, u)
 
-    with torch.no_grad():
-        seq, x, O = step(100, seq, x, O)  # warm-up
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            seq, x, O = step(100 - (i % 100), seq, x, O)
-        dt = time.perf_counter() - t0
+    # torch's default thread count (all physical cores) oversubscribes a box whose CPU share is smaller than the
+    # machine; time the default and a 16-thread run (the 1-GPU box's share) and report the faster one.
+    default_threads = torch.get_num_threads()
+    best = None
+    for threads in sorted({default_threads, min(16, default_threads)}):
+        torch.set_num_threads(threads)
+        s0, x0, O0 = seq, x, O
+        with torch.no_grad():
+            s0, x0, O0 = step(100, s0, x0, O0)  # warm-up
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                s0, x0, O0 = step(100 - (i % 100), s0, x0, O0)
+            dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    torch.set_num_threads(default_threads)
+    dt, threads = best
     return {
         "value": n_patches * K * n_steps / dt,
         "unit": "residue-steps/s",
         "cores": threads,
         "kind": "port",
         "sample": f"{n_patches} patches x K={K} x {n_steps} reverse steps, oracle/diffab_oracle.py (torch CPU fp32, "
-                  f"reference formulation), {dt:.1f} s on {threads} threads of {os.cpu_count()} logical CPUs",
+                  f"reference formulation), {dt:.1f} s on {threads} threads (best of default {default_threads} and 16) of "
+                  f"{os.cpu_count()} logical CPUs",
     }
 
 
@@ -89,7 +100,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="patches per GPU")
     ap.add_argument("--k", type=int, default=128, help="residues per patch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
     args = ap.parse_args()
 

@@ -1,19 +1,443 @@
-// denoiser_fast.hip - MFMA kernels for the benchmark geometry (placeholder: generic dispatch).
+// denoiser_fast.hip - MFMA (fp32-in / fp32-accumulate, exact fp32) kernels for the benchmark geometry
+// D=128, C=64, H=8, DS=32, PQ=PV=8 (reference train.py:62-70), any K that is a multiple of 16.
+//
+//  * linear_mfma_kernel: Y = act(X W^T + b) on v_mfma_f32_32x32x2_f32, LDS-staged 128 x {64,128} x 32 tiles.  Both
+//    operands are K-contiguous (X rows and nn.Linear weight rows), so one 16-byte LDS read per lane feeds four
+//    MFMA k-steps (k order inside a step is permuted identically for A and B, which a dot product does not see).
+//  * ipa_attn_fast_kernel: one work-group (8 waves) per (patch, 16 query residues):
+//      phase 1 (wave = head):   scalar logits q.k on MFMA 16x16x4, point logits as direct differences on the VALU
+//                               (the |q|^2+|k|^2-2qk form loses ~1e-5) -> S in LDS
+//      phase 2 (wave = 2 rows): pair bias e.Wb on MFMA with e streamed global->VGPR (each e element read exactly once
+//                               from HBM), softmax over the 128 keys in registers, attn-weighted pair sum o_e on MFMA
+//                               with e re-read through L2 in the transposed fragment order -> P in LDS
+//      phase 3 (wave = head):   attn-weighted scalar / point sums on MFMA (P from LDS, V side from L2), global->local
+//                               frames and norms -> feature row (1024) for the output projection.
+//    K/V-side operands (448 KiB per patch) are produced once per layer by the projection GEMM and re-read by the 8
+//    row tiles of a patch, which the blockIdx map places on one XCD so the re-reads are L2 hits.
+//
+// Reference: InvariantPointAttentionLayer.forward, diffab_pytorch.py:389-465.
 #include "common.h"
 #include "denoiser_internal.h"
 
 namespace diffab {
 
-bool fast_path_supported(const diffab_dims*) { return false; }
-size_t ipa_fast_workspace_floats(const diffab_dims*) { return 0; }
-int ipa_layer_fast(const diffab_dims*, const diffab_ipa_layer_weights*, const float*, const float*, const float*, const float*, float*,
-                   float*, hipStream_t) {
-  set_error("fast path not built");
-  return DIFFAB_ERR_UNSUPPORTED;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ================================================================== Y = act(X W^T + b) on MFMA 32x32x2
+constexpr int LBM = 128, LBK = 32, LLD = LBK + 4;  // LDS row stride 36 floats: ds_read_b128 conflict-free
+
+struct LinearSegs {  // up to 6 weight matrices sharing X, written side by side into Y (the IPA projections)
+  const float* W[6];
+  int n_end[6];  // exclusive end column of each segment in Y
+  int nseg;
+};
+
+template <int BN, bool RELU, bool VEC>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ X, int ldx, LinearSegs segs,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int ldy, int M, int N,
+                                                          int Kd) {
+  __shared__ __attribute__((aligned(16))) float As[LBM * LLD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LLD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * BN;
+  // which weight matrix this column block belongs to (segments are multiples of BN wide, or there is one segment)
+  int seg = 0;
+  while (seg + 1 < segs.nseg && n0 >= segs.n_end[seg]) ++seg;
+  const int seg_begin = seg == 0 ? 0 : segs.n_end[seg - 1];
+  const float* __restrict__ W = segs.W[seg];
+  const int seg_rows = segs.n_end[seg] - seg_begin;  // rows of this weight matrix
+  const int wrow0 = n0 - seg_begin;
+
+  constexpr int NT = BN / 32;  // 32-column accumulator tiles per wave
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  constexpr int A_F4 = LBM * LBK / 4 / 256;  // float4 per thread for the A tile (4)
+  constexpr int B_F4 = BN * LBK / 4 / 256;   // (2 or 4)
+  f32x4 ra[A_F4], rb[B_F4];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+      const int gm = m0 + row, gk = k0 + c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gm < M) {
+        const float* p = X + static_cast<int64_t>(gm) * ldx + gk;
+        if (VEC) {
+          if (gk < Kd) v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gk + q < Kd) v[q] = p[q];
+        }
+      }
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < B_F4; ++r) {
+      const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+      const int wr = wrow0 + row, gk = k0 + c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wr < seg_rows) {
+        const float* p = W + static_cast<int64_t>(wr) * Kd + gk;
+        if (VEC) {
+          if (gk < Kd) v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (gk + q < Kd) v[q] = p[q];
+        }
+      }
+      rb[r] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int r = 0; r < A_F4; ++r) {
+      const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+      *reinterpret_cast<f32x4*>(&As[row * LLD + c4]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B_F4; ++r) {
+      const int idx = tid + r * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+      *reinterpret_cast<f32x4*>(&Bs[row * LLD + c4]) = rb[r];
+    }
+  };
+
+  load_tile(0);
+  for (int k0 = 0; k0 < Kd; k0 += LBK) {
+    __syncthreads();  // previous tile's reads are done
+    store_tile();
+    __syncthreads();
+    if (k0 + LBK < Kd) load_tile(k0 + LBK);  // next tile's global loads fly under the MFMAs
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t4 = 0; t4 < LBK / 8; ++t4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[(wv * 32 + l31) * LLD + t4 * 8 + hh * 4]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[(t * 32 + l31) * LLD + t4 * 8 + hh * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D layout 32x32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n0 + t * 32 + (lane & 31);
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= M) continue;
+      float v = acc[t][r] + bv;
+      if (RELU) v = fmaxf(v, 0.0f);
+      Y[static_cast<int64_t>(row) * ldy + col] = v;
+    }
+  }
 }
+
+template <int BN>
+static int launch_linear_bn(const float* X, int ldx, const LinearSegs& segs, const float* bias, float* Y, int ldy, int M, int N, int Kd,
+                            bool relu, bool vec, hipStream_t st) {
+  dim3 grid((N + BN - 1) / BN, (M + LBM - 1) / LBM);
+#define LAUNCH(R, V) hipLaunchKernelGGL((linear_mfma_kernel<BN, R, V>), grid, dim3(256), 0, st, X, ldx, segs, bias, Y, ldy, M, N, Kd)
+  if (relu) { if (vec) LAUNCH(true, true); else LAUNCH(true, false); }
+  else      { if (vec) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st) {
-  return launch_linear_generic(X, ldx, W, bias, Y, ldy, M, N, Kd, relu, st);
+  LinearSegs segs{};
+  segs.W[0] = W;
+  segs.n_end[0] = N;
+  segs.nseg = 1;
+  const bool vec = (ldx % 4 == 0) && (Kd % 4 == 0) && aligned16(X) && aligned16(W);
+  if (N > 64) return launch_linear_bn<128>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
+  return launch_linear_bn<64>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
+}
+
+// ================================================================== fused IPA attention (benchmark geometry)
+constexpr int AH = 8, ADS = 32, AP = 8, AC = 64;
+constexpr int ANP = 3 * AH * ADS + 3 * AH * AP * 3;               // 1344 projection columns
+constexpr int AF = AH * ADS + AH * AC + AH * AP * 3 + AH * AP;    // 1024 feature columns
+constexpr int OFF_QS = 0, OFF_KS = 256, OFF_VS = 512, OFF_GQ = 768, OFF_GK = 960, OFF_GV = 1152;
+constexpr int FOFF_OS = 0, FOFF_OE = 256, FOFF_OL = 768, FOFF_ON = 960;
+constexpr int TI = 16;  // query residues per work-group
+
+__device__ inline int s_hstride(int K) { return K + 8; }                 // == 8 (mod 64) for K % 64 == 0: conflict-free b128 reads
+__device__ inline int s_istride(int K) { return AH * (K + 8) + 8; }
+
+template <int NT>  // NT = K / 16 key tiles; compile-time so the per-lane logit array stays in registers
+__global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
+                                                            const float* __restrict__ R, const float* __restrict__ t,
+                                                            const float* __restrict__ Wb, const float* __restrict__ gamma,
+                                                            float* __restrict__ feat, int B) {
+  extern __shared__ __attribute__((aligned(16))) float S[];  // [TI][AH][K+8] (+8 per i): logits, then probabilities
+  constexpr int K = NT * 16;
+  constexpr int ntile = NT;
+  // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give the 8.. tiles of one patch to one XCD.
+  int b, tile;
+  if ((B & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    b = (slot / ntile) * 8 + xcd;
+    tile = slot % ntile;
+  } else {
+    b = blockIdx.x / ntile;
+    tile = blockIdx.x % ntile;
+  }
+  const int i0 = tile * TI;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int HS = s_hstride(K), IS = s_istride(K);
+  const int64_t prow0 = static_cast<int64_t>(b) * K;  // first projection row of this patch
+  const float scale_t = 0.57735026918962576f;         // 3^-1/2   (diffab_pytorch.py:387, :439)
+
+  // ---------------------------------------------------------------- phase 1: wave = head
+  {
+    const int h = wv;
+    const float scale_s = 0.17677669529663687f;  // 32^-1/2  (:353)
+    const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
+    // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
+    f32x4 qa[2];
+    const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
+    qa[0] = *reinterpret_cast<const f32x4*>(qrow);
+    qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
+    // query points of the 4 rows this lane accumulates (rows i0 + 4q + r)
+    float gq[4][24];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* p = proj + (prow0 + i0 + 4 * q + r) * ANP + OFF_GQ + h * 24;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * c);
+        gq[r][4 * c] = v[0]; gq[r][4 * c + 1] = v[1]; gq[r][4 * c + 2] = v[2]; gq[r][4 * c + 3] = v[3];
+      }
+    }
+#pragma unroll 1
+    for (int jt = 0; jt < ntile; ++jt) {
+      const float* krow = proj + (prow0 + jt * 16 + l15) * ANP;
+      const f32x4 kb0 = *reinterpret_cast<const f32x4*>(krow + OFF_KS + h * ADS + 4 * q);
+      const f32x4 kb1 = *reinterpret_cast<const f32x4*>(krow + OFF_KS + h * ADS + 16 + 4 * q);
+      f32x4 gk[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) gk[c] = *reinterpret_cast<const f32x4*>(krow + OFF_GK + h * 24 + 4 * c);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
+      // acc[r] = q_s[i0+4q+r] . k_s[16jt+l15]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float dd = gq[r][4 * c + s] - gk[c][s];
+            d2 += dd * dd;
+          }
+        S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
+  {
+    const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
+    f32x4 wb[4];            // B operand of the bias product: Wb[h][16 sg + 4 q + s], zero in the padding columns
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+      wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
+      if (l15 >= 8) wb[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int ii = 0; ii < 2; ++ii) {
+      const int il = 2 * wv + ii;  // local row
+      const float* erow = e + ((prow0 + i0 + il) * K) * AC;  // e[b, i, :, :]
+      float* Srow = S + il * IS + h * HS;
+      // ---- bias + logits, 32 keys per lane: j = 16 jt + 4 q + r
+      float lg[NT][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < ntile; ++jt) {
+        const float* ep = erow + (jt * 16 + l15) * AC + 4 * q;
+        f32x4 ea[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) ea[sg] = *reinterpret_cast<const f32x4*>(ep + 16 * sg);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[sg][s], wb[sg][s], acc, 0, 0, 0);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = sv[r] + scale_t * acc[r];
+          lg[jt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < ntile; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = expf(lg[jt][r] - mx);
+          lg[jt][r] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      // ---- probabilities: to LDS for phase 3, and straight into the o_e product as its B operand
+      f32x4 oe[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jt = 0; jt < ntile; ++jt) {
+        f32x4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = lg[jt][r] * inv;
+        if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + jt * 16 + 4 * q) = pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // A operand: e[i][j = 16 jt + 4 q + r][c = 4 l15 + ct]  (1 KiB contiguous per wave instruction)
+          const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + (jt * 16 + 4 * q + r) * AC + 4 * l15);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[ct], pv[r], oe[ct], 0, 0, 0);
+        }
+      }
+      // D: column h = l15, row m = 4 q + r' <-> c = 4 m + ct = 16 q + 4 r' + ct
+      if (l15 < 8) {
+        float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 16 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(fo + 4 * r) = f32x4{oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase 3: wave = head
+  {
+    const int h = wv;
+    f32x4 os[2], og[3];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) og[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 16 jt + 4 q + r]
+    const int pp = l15 & 7;
+#pragma unroll 2
+    for (int jt = 0; jt < ntile; ++jt) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vrow = proj + (prow0 + jt * 16 + 4 * q + r) * ANP;
+        const float2 vs = *reinterpret_cast<const float2*>(vrow + OFF_VS + h * ADS + 2 * l15);  // d = 2 l15 + dt
+        const float* gp = vrow + OFF_GV + h * 24 + 3 * pp;                                        // point pp, coords 0..2
+        const float gx = gp[0], gy = gp[1], gz = gp[2];
+        os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs.x, os[0], 0, 0, 0);
+        os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs.y, os[1], 0, 0, 0);
+        og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gx, og[0], 0, 0, 0);
+        og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gy, og[1], 0, 0, 0);
+        og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz, og[2], 0, 0, 0);
+      }
+    }
+    // D rows i = 4 q + r, column n = l15
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = prow0 + i0 + 4 * q + r;
+      float* fr = feat + row * AF;
+      *reinterpret_cast<float2*>(fr + FOFF_OS + h * ADS + 2 * l15) = make_float2(os[0][r], os[1][r]);
+      if (l15 < 8) {
+        const float* Rr = R + row * 9;
+        const float* tr = t + row * 3;
+        const float dx = og[0][r] - tr[0], dy = og[1][r] - tr[1], dz = og[2][r] - tr[2];
+        const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
+        const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
+        const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
+        float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
+        fo[0] = lx; fo[1] = ly; fo[2] = lz;
+        fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
+      }
+    }
+  }
+}
+
+// in-place local -> global for the three point blocks of the projection buffer (row-vector convention, :324)
+__global__ void points_to_global_fast_kernel(float* __restrict__ proj, const float* __restrict__ R, const float* __restrict__ t, int rows) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (row, point 0..191)
+  if (gid >= rows * 192) return;
+  const int r = gid / 192, p = gid % 192;
+  float* qv = proj + static_cast<int64_t>(r) * ANP + OFF_GQ + p * 3;
+  const float* Rr = R + static_cast<int64_t>(r) * 9;
+  const float x = qv[0], y = qv[1], z = qv[2];
+  qv[0] = (x * Rr[0] + y * Rr[3] + z * Rr[6]) + t[r * 3 + 0];
+  qv[1] = (x * Rr[1] + y * Rr[4] + z * Rr[7]) + t[r * 3 + 1];
+  qv[2] = (x * Rr[2] + y * Rr[5] + z * Rr[8]) + t[r * 3 + 2];
+}
+
+bool fast_path_supported(const diffab_dims* d) {
+  return d->D == 128 && d->C == AC && d->H == AH && d->DS == ADS && d->PQ == AP && d->PV == AP && d->K % 64 == 0 && d->K >= 64 &&
+         d->K <= 256;
+}
+
+size_t ipa_fast_workspace_floats(const diffab_dims* d) {
+  const size_t rows = static_cast<size_t>(d->B) * d->K;
+  return rows * (ANP + AF) + 128;
+}
+
+int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
+                   float* y, float* ws, hipStream_t st) {
+  const int rows = d->B * d->K, D = d->D;
+  float* proj = ws;
+  float* feat = ws + static_cast<size_t>(rows) * ANP;
+  // one GEMM for the six projections: Y[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T
+  LinearSegs segs{};
+  segs.W[0] = w->wq_s; segs.W[1] = w->wk_s; segs.W[2] = w->wv_s; segs.W[3] = w->wq_p; segs.W[4] = w->wk_p; segs.W[5] = w->wv_p;
+  segs.n_end[0] = 256; segs.n_end[1] = 512; segs.n_end[2] = 768; segs.n_end[3] = 960; segs.n_end[4] = 1152; segs.n_end[5] = 1344;
+  segs.nseg = 6;
+  bool vec = aligned16(x);
+  for (int s = 0; s < 6; ++s) vec = vec && aligned16(segs.W[s]);
+  if (int rc = launch_linear_bn<64>(x, D, segs, nullptr, proj, ANP, rows, ANP, D, false, vec, st)) return rc;
+  hipLaunchKernelGGL(points_to_global_fast_kernel, dim3((rows * 192 + 255) / 256), dim3(256), 0, st, proj, R, t, rows);
+  DIFFAB_LAUNCH_CHECK();
+  const size_t lds = static_cast<size_t>(TI) * (AH * (d->K + 8) + 8) * sizeof(float);
+  const dim3 grid(d->B * (d->K / TI));
+#define ATTN_LAUNCH(NT_)                                                                                                              \
+  do {                                                                                                                                \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_>),                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
+    timer_begin(st);                                                                                                                  \
+    hipLaunchKernelGGL(ipa_attn_fast_kernel<NT_>, grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, d->B);          \
+    timer_end(st);                                                                                                                    \
+  } while (0)
+  switch (d->K / 16) {
+    case 4: ATTN_LAUNCH(4); break;
+    case 8: ATTN_LAUNCH(8); break;
+    case 12: ATTN_LAUNCH(12); break;
+    case 16: ATTN_LAUNCH(16); break;
+    default: set_error("fast attention: unsupported K=%d", d->K); return DIFFAB_ERR_UNSUPPORTED;
+  }
+#undef ATTN_LAUNCH
+  DIFFAB_LAUNCH_CHECK();
+  return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
 }
 
 }  // namespace diffab
