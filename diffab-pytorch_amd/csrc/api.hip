@@ -161,6 +161,11 @@ int diffab_device_ok(void) {
   return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
+int diffab_debug_set_attn_stamps(void* device_buffer) {
+  set_attn_stamps(device_buffer);
+  return DIFFAB_OK;
+}
+
 int diffab_kernel_timer_enable(int on) {
   g_timer.on = on != 0;
   g_timer.used = 0;

@@ -177,63 +177,134 @@ constexpr int OFF_QS = 0, OFF_KS = 256, OFF_VS = 512, OFF_GQ = 768, OFF_GK = 960
 constexpr int FOFF_OS = 0, FOFF_OE = 256, FOFF_OL = 768, FOFF_ON = 960;
 constexpr int TI = 16;  // query residues per work-group
 
-__device__ inline int s_hstride(int K) { return K + 8; }                 // == 8 (mod 64) for K % 64 == 0: conflict-free b128 reads
-__device__ inline int s_istride(int K) { return AH * (K + 8) + 8; }
+// LDS strides of the logits/probabilities image: head stride K + 8 (== 8 mod 64 for K % 64 == 0) and row stride
+// 8 (K + 8) + 8 keep both the (head, quarter)-lane and the (row, quarter)-lane ds_read_b128 patterns conflict-free.
 
-template <int NT>  // NT = K / 16 key tiles; compile-time so the per-lane logit array stays in registers
+// Compile-time fence for memory operations: keeps the hand-placed prefetch loads where they are written (hipcc otherwise
+// sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
+#define MEM_FENCE() asm volatile("" ::: "memory")
+
+template <int NT>  // NT = K / 16 key tiles; compile-time so every per-lane array is register-allocated (static indices only)
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
-                                                            float* __restrict__ feat, int B) {
+                                                            float* __restrict__ feat, int B,
+                                                            unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) float S[];  // [TI][AH][K+8] (+8 per i): logits, then probabilities
   constexpr int K = NT * 16;
-  constexpr int ntile = NT;
-  // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give the 8.. tiles of one patch to one XCD.
+  constexpr int NS = NT * 4;  // (jt, r) key steps of 4 keys each
+  // diagnostic s_memtime stamps (stamps == nullptr in every production launch: nothing below executes)
+  auto stamp = [&](int k) {
+    if (stamps != nullptr) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long tnow = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
+  // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
   if ((B & 7) == 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    b = (slot / ntile) * 8 + xcd;
-    tile = slot % ntile;
+    b = (slot / NT) * 8 + xcd;
+    tile = slot % NT;
   } else {
-    b = blockIdx.x / ntile;
-    tile = blockIdx.x % ntile;
+    b = blockIdx.x / NT;
+    tile = blockIdx.x % NT;
   }
   const int i0 = tile * TI;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int HS = s_hstride(K), IS = s_istride(K);
+  constexpr int HS = K + 8, IS = AH * (K + 8) + 8;
   const int64_t prow0 = static_cast<int64_t>(b) * K;  // first projection row of this patch
   const float scale_t = 0.57735026918962576f;         // 3^-1/2   (diffab_pytorch.py:387, :439)
+
+  // Per-wave LDS scratch behind the logits image.  Every global load below is issued in full 128-byte lines (consecutive
+  // lanes on consecutive 16-byte chunks): the texture addresser serves one line per lane quad, whereas MFMA-fragment-shaped
+  // loads (adjacent lanes on different rows) cost four lines per quad and made this kernel addresser-bound (4x the issue
+  // time, measured).  Data is re-oriented into fragments through this scratch; a wave reads only what it wrote, and LDS
+  // operations of one wave complete in order, so no barrier is involved.
+  constexpr int KLD = 40, GLD = 28;                       // key-tile strides (floats): ds_read_b128 conflict-free
+  constexpr int P1_TILE = 16 * KLD + 16 * GLD;            // 1088 floats per staged key tile
+  constexpr int ELD = 72;                                 // pair-tile stride (floats)
+  constexpr int SCR_FLOATS = 2 * 16 * ELD;                // 2304 floats per wave (>= 2 * P1_TILE = 2176)
+  float* scr = S + TI * IS + wv * SCR_FLOATS;
+
+  // e[b, i0 + 2 wv + ii, :, :]: the two pair-embedding rows this wave owns in phase 2.  Streamed once (non-temporal: it
+  // must not evict the K/V-side operands, re-read by the other row tiles of the patch, from L2), in the orientation of
+  // the o_e product: lane (l15, q) holds e[i][j = 16 jt + 4 q + r][c = 4 l15 .. 4 l15 + 3] - 1 KiB contiguous per load.
+  const float* erow[2];
+  erow[0] = e + ((prow0 + i0 + 2 * wv) * K) * AC;
+  erow[1] = erow[0] + K * AC;
+  constexpr bool RESIDENT = NT <= 8;   // a whole e row (16 NT VGPRs) stays in registers from the bias to the o_e product
+  constexpr int PFE = RESIDENT ? NT : 3;  // non-resident: rolling window, PFE key tiles of lookahead, second pass via L2
+  f32x4 ev[2][NT][4];
+  auto load_e_tile = [&](int ii, int jt) {
+    const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii] + (jt * 16 + 4 * q) * AC + 4 * l15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
+  };
 
   // ---------------------------------------------------------------- phase 1: wave = head
   {
     const int h = wv;
-    const float scale_s = 0.17677669529663687f;  // 32^-1/2  (:353)
+    const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
     const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
+    // line-shaped loads of one key tile (16 keys): k_s 16 x 128 B (8 lanes per key), gk 16 x 96 B (6 lanes per key)
+    const float* ks_src = proj + (prow0 + (lane >> 3)) * ANP + OFF_KS + h * ADS + 4 * (lane & 7);  // + 8 t keys, + 16 jt keys
+    const int g0 = lane, g1 = lane + 64;  // gk chunk ids (0..95): key = id / 6, chunk = id % 6
+    const float* gk_src0 = proj + (prow0 + g0 / 6) * ANP + OFF_GK + h * 24 + 4 * (g0 % 6);
+    const float* gk_src1 = proj + (prow0 + g1 / 6) * ANP + OFF_GK + h * 24 + 4 * (g1 % 6);
+    const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
+    const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
+    f32x4 st[2][4];  // register staging, two tiles in flight
+    auto load_keys = [&](int sb, int jt) {
+      const int64_t o = static_cast<int64_t>(jt) * 16 * ANP;
+      st[sb][0] = *reinterpret_cast<const f32x4*>(ks_src + o);
+      st[sb][1] = *reinterpret_cast<const f32x4*>(ks_src + o + 8 * ANP);
+      st[sb][2] = *reinterpret_cast<const f32x4*>(gk_src0 + o);
+      if (g1 < 96) st[sb][3] = *reinterpret_cast<const f32x4*>(gk_src1 + o);
+    };
+    auto stage_keys = [&](int sb, int lb) {
+      float* t_ = scr + lb * P1_TILE;
+      *reinterpret_cast<f32x4*>(t_ + ks_dst) = st[sb][0];
+      *reinterpret_cast<f32x4*>(t_ + ks_dst + 8 * KLD) = st[sb][1];
+      *reinterpret_cast<f32x4*>(t_ + gk_dst0) = st[sb][2];
+      if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
+    };
+    load_keys(0, 0);
+    load_keys(1, 1);
     // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
     f32x4 qa[2];
     const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
     qa[0] = *reinterpret_cast<const f32x4*>(qrow);
     qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
-    // query points of the 4 rows this lane accumulates (rows i0 + 4q + r)
-    float gq[4][24];
+    // query points of the 4 rows this lane accumulates (rows i0 + 4q + r); the 16 lanes of a quarter share each address
+    f32x4 gq[4][6];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float* p = proj + (prow0 + i0 + 4 * q + r) * ANP + OFF_GQ + h * 24;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * c);
-        gq[r][4 * c] = v[0]; gq[r][4 * c + 1] = v[1]; gq[r][4 * c + 2] = v[2]; gq[r][4 * c + 3] = v[3];
-      }
+      for (int c = 0; c < 6; ++c) gq[r][c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
     }
-#pragma unroll 1
-    for (int jt = 0; jt < ntile; ++jt) {
-      const float* krow = proj + (prow0 + jt * 16 + l15) * ANP;
-      const f32x4 kb0 = *reinterpret_cast<const f32x4*>(krow + OFF_KS + h * ADS + 4 * q);
-      const f32x4 kb1 = *reinterpret_cast<const f32x4*>(krow + OFF_KS + h * ADS + 16 + 4 * q);
+    MEM_FENCE();
+    stage_keys(0, 0);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      if (jt + 1 < NT) stage_keys((jt + 1) & 1, (jt + 1) & 1);  // tile jt+1: registers -> LDS (its loads were issued a tile ago)
+      if (jt + 2 < NT) {
+        load_keys(jt & 1, jt + 2);
+      } else if constexpr (RESIDENT) {
+        load_e_tile(0, jt + 2 - NT);  // no more key tiles: start the pair-embedding stream of phase 2 under this tile
+      }
+      MEM_FENCE();
+      const float* t_ = scr + (jt & 1) * P1_TILE;
+      const f32x4 kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
+      const f32x4 kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
       f32x4 gk[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) gk[c] = *reinterpret_cast<const f32x4*>(krow + OFF_GK + h * 24 + 4 * c);
+      for (int c = 0; c < 6; ++c) gk[c] = *reinterpret_cast<const f32x4*>(t_ + 16 * KLD + l15 * GLD + 4 * c);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
@@ -247,42 +318,66 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int c = 0; c < 6; ++c)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const float dd = gq[r][4 * c + s] - gk[c][s];
+            const float dd = gq[r][c][s] - gk[c][s];
             d2 += dd * dd;
           }
         S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
       }
     }
   }
-  __syncthreads();
+  stamp(1);
 
   // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
   {
     const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
-    f32x4 wb[4];            // B operand of the bias product: Wb[h][16 sg + 4 q + s], zero in the padding columns
+    if constexpr (RESIDENT) {
+#pragma unroll
+      for (int jt = 2; jt < NT; ++jt) load_e_tile(0, jt);  // tiles 0, 1 were started under the last two key tiles of phase 1
+    } else {
+#pragma unroll
+      for (int jt = 0; jt < PFE; ++jt) load_e_tile(0, jt);
+    }
+    f32x4 wb[4];  // B operand of the bias product: Wb[h][16 sg + 4 q + s], zero in the padding columns
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {
       wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
-      if (l15 >= 8) wb[sg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
     }
+    MEM_FENCE();
+    __syncthreads();  // phase-1 logits of all heads are in LDS (and every wave is done with its key-tile scratch)
+    stamp(2);
+    // tile re-orientation for the bias product: write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
+    auto stage_e = [&](int ii, int jt) {
+      float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[ii][jt][r];
+    };
+
+#pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
       const int il = 2 * wv + ii;  // local row
-      const float* erow = e + ((prow0 + i0 + il) * K) * AC;  // e[b, i, :, :]
       float* Srow = S + il * IS + h * HS;
-      // ---- bias + logits, 32 keys per lane: j = 16 jt + 4 q + r
-      float lg[NT][4];
+      float lg[NT][4];  // logits, then probabilities, of keys j = 16 jt + 4 q + r for head h
       float mx = -INFINITY;
+      stage_e(ii, 0);
 #pragma unroll
-      for (int jt = 0; jt < ntile; ++jt) {
-        const float* ep = erow + (jt * 16 + l15) * AC + 4 * q;
-        f32x4 ea[4];
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg) ea[sg] = *reinterpret_cast<const f32x4*>(ep + 16 * sg);
+      for (int jt = 0; jt < NT; ++jt) {
+        if (jt + 1 < NT) stage_e(ii, jt + 1);
+        if constexpr (!RESIDENT) {
+          if (jt + PFE < NT) {
+            load_e_tile(ii, jt + PFE);
+            MEM_FENCE();
+          }
+        }
+        const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg)
+        for (int sg = 0; sg < 4; ++sg) {
+          const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[sg][s], wb[sg][s], acc, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wb[sg][s], acc, 0, 0, 0);
+        }
         const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -291,11 +386,16 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           mx = fmaxf(mx, v);
         }
       }
+      if constexpr (!RESIDENT) {  // second pass over the row (L2 / Infinity Cache), same rolling window
+#pragma unroll
+        for (int jt = 0; jt < PFE; ++jt) load_e_tile(ii, jt);
+        MEM_FENCE();
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       float sum = 0.f;
 #pragma unroll
-      for (int jt = 0; jt < ntile; ++jt)
+      for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = expf(lg[jt][r] - mx);
@@ -310,17 +410,29 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jt = 0; jt < ntile; ++jt) {
+      for (int jt = 0; jt < NT; ++jt) {
         f32x4 pv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pv[r] = lg[jt][r] * inv;
         if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + jt * 16 + 4 * q) = pv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // A operand: e[i][j = 16 jt + 4 q + r][c = 4 l15 + ct]  (1 KiB contiguous per wave instruction)
-          const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + (jt * 16 + 4 * q + r) * AC + 4 * l15);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[ct], pv[r], oe[ct], 0, 0, 0);
+          for (int ct = 0; ct < 4; ++ct)  // A: e[i][j = 16 jt + 4 q + r][c = 4 l15 + ct]
+            oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[ii][jt][r][ct], pv[r], oe[ct], 0, 0, 0);
+        if constexpr (RESIDENT) {
+          if (ii == 0) {  // this tile's registers are free: start the next row's copy of it
+            load_e_tile(1, jt);
+            MEM_FENCE();
+          }
+        } else {
+          if (jt + PFE < NT) {
+            load_e_tile(ii, jt + PFE);
+            MEM_FENCE();
+          } else if (ii == 0) {
+            load_e_tile(1, jt + PFE - NT);  // next row's first tiles
+            MEM_FENCE();
+          }
         }
       }
       // D: column h = l15, row m = 4 q + r' <-> c = 4 m + ct = 16 q + 4 r' + ct
@@ -331,32 +443,50 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       }
     }
   }
-  __syncthreads();
 
+  stamp(3);
   // ---------------------------------------------------------------- phase 3: wave = head
   {
+    constexpr int PFV = 8;  // value prefetch distance, key steps
     const int h = wv;
+    const int pp = l15 & 7;
+    const float* vbase = proj + (prow0 + 4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;  // + (16 jt + r) rows; d = 2 l15 + dt
+    const float* gbase = proj + (prow0 + 4 * q) * ANP + OFF_GV + h * 24 + 3 * pp;    // point pp, coords 0..2
+    float2 vs[NS];
+    float gx[NS], gy[NS], gz[NS];
+    auto load_vals = [&](int st) {
+      const int64_t o = static_cast<int64_t>((st >> 2) * 16 + (st & 3)) * ANP;
+      vs[st] = *reinterpret_cast<const float2*>(vbase + o);
+      gx[st] = gbase[o];
+      gy[st] = gbase[o + 1];
+      gz[st] = gbase[o + 2];
+    };
+#pragma unroll
+    for (int st = 0; st < PFV; ++st) load_vals(st);
+    MEM_FENCE();
+    __syncthreads();  // probabilities of all rows are in LDS
+    stamp(4);
     f32x4 os[2], og[3];
 #pragma unroll
     for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) og[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 16 jt + 4 q + r]
-    const int pp = l15 & 7;
-#pragma unroll 2
-    for (int jt = 0; jt < ntile; ++jt) {
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
       const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* vrow = proj + (prow0 + jt * 16 + 4 * q + r) * ANP;
-        const float2 vs = *reinterpret_cast<const float2*>(vrow + OFF_VS + h * ADS + 2 * l15);  // d = 2 l15 + dt
-        const float* gp = vrow + OFF_GV + h * 24 + 3 * pp;                                        // point pp, coords 0..2
-        const float gx = gp[0], gy = gp[1], gz = gp[2];
-        os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs.x, os[0], 0, 0, 0);
-        os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs.y, os[1], 0, 0, 0);
-        og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gx, og[0], 0, 0, 0);
-        og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gy, og[1], 0, 0, 0);
-        og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz, og[2], 0, 0, 0);
+        const int st = jt * 4 + r;
+        if (st + PFV < NS) {
+          load_vals(st + PFV);
+          MEM_FENCE();
+        }
+        os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[st].x, os[0], 0, 0, 0);
+        os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[st].y, os[1], 0, 0, 0);
+        og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gx[st], og[0], 0, 0, 0);
+        og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gy[st], og[1], 0, 0, 0);
+        og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz[st], og[2], 0, 0, 0);
       }
     }
     // D rows i = 4 q + r, column n = l15
@@ -378,7 +508,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       }
     }
   }
+  stamp(5);
 }
+
+static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
+void set_attn_stamps(void* p) { g_attn_stamps = static_cast<unsigned long long*>(p); }
 
 // in-place local -> global for the three point blocks of the projection buffer (row-vector convention, :324)
 __global__ void points_to_global_fast_kernel(float* __restrict__ proj, const float* __restrict__ R, const float* __restrict__ t, int rows) {
@@ -395,7 +529,7 @@ __global__ void points_to_global_fast_kernel(float* __restrict__ proj, const flo
 
 bool fast_path_supported(const diffab_dims* d) {
   return d->D == 128 && d->C == AC && d->H == AH && d->DS == ADS && d->PQ == AP && d->PV == AP && d->K % 64 == 0 && d->K >= 64 &&
-         d->K <= 256;
+         d->K <= 128;  // K = 192/256: logits image + per-wave scratch exceed the 160 KiB LDS (generic path until re-tiled)
 }
 
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
@@ -418,14 +552,15 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   if (int rc = launch_linear_bn<64>(x, D, segs, nullptr, proj, ANP, rows, ANP, D, false, vec, st)) return rc;
   hipLaunchKernelGGL(points_to_global_fast_kernel, dim3((rows * 192 + 255) / 256), dim3(256), 0, st, proj, R, t, rows);
   DIFFAB_LAUNCH_CHECK();
-  const size_t lds = static_cast<size_t>(TI) * (AH * (d->K + 8) + 8) * sizeof(float);
+  const size_t lds = (static_cast<size_t>(TI) * (AH * (d->K + 8) + 8) + 8 * 2 * 16 * 72) * sizeof(float);  // logits + per-wave scratch
   const dim3 grid(d->B * (d->K / TI));
 #define ATTN_LAUNCH(NT_)                                                                                                              \
   do {                                                                                                                                \
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_>),                                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL(ipa_attn_fast_kernel<NT_>, grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, d->B);          \
+    hipLaunchKernelGGL(ipa_attn_fast_kernel<NT_>, grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, d->B,           \
+                       g_attn_stamps);                                                                                                \
     timer_end(st);                                                                                                                    \
   } while (0)
   switch (d->K / 16) {

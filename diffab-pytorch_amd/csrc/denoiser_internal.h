@@ -23,6 +23,8 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);
 
+void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
+
 // api.hip: opt-in hipEvent bracket around the dominant (attention) kernel
 void timer_begin(hipStream_t st);
 void timer_end(hipStream_t st);

@@ -118,6 +118,9 @@ int diffab_device_ok(void);
  * attention kernel) is bracketed by a hipEvent pair recorded on its launch stream.  read() waits for the events,
  * returns the number of launches and their summed duration, and resets the counter.  Not thread-safe; off by default. */
 int diffab_kernel_timer_enable(int on);
+/* Diagnostics only: while a device buffer of (work-groups x 8 waves x 8) uint64 is registered, the fused attention kernel
+ * writes s_memtime stamps at its phase boundaries into it (tools/attn_phase_profile.py).  NULL (default) disables it. */
+int diffab_debug_set_attn_stamps(void* device_buffer);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
 
 /* ---- SO(3) maps, n matrices/vectors each --------------------------------- */

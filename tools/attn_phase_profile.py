@@ -1,0 +1,44 @@
+"""Diagnostic: where does the fused IPA attention kernel spend its cycles?  Runs one IPA layer at the benchmark
+geometry with s_memtime stamps enabled (never enabled in production) and prints per-phase shader-cycle averages."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "diffab-pytorch_amd"))
+import torch  # noqa: E402
+
+from diffab_pytorch import _hip, synthetic as syn  # noqa: E402
+from diffab_pytorch.diffab_pytorch import InvariantPointAttentionLayer  # noqa: E402
+
+B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 128
+lib = _hip.lib()
+d = syn.BENCH_DIMS
+torch.manual_seed(0)
+layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(B, K, d["D"], device="cuda", generator=g)
+e = torch.randn(B, K, K, d["C"], device="cuda", generator=g)
+t = 10 * torch.randn(B, K, 3, device="cuda", generator=g)
+q = torch.nn.functional.normalize(torch.randn(B, K, 4, device="cuda", generator=g), dim=-1)
+w_, x_, y_, z_ = q.unbind(-1)
+R = torch.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_), 2 * (x_ * y_ + z_ * w_),
+                 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_), 2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_),
+                 1 - 2 * (x_ * x_ + y_ * y_)], -1).view(B, K, 3, 3).contiguous()
+for _ in range(3):
+    layer(x, e, R, t)
+nwg = B * (K // 16)
+stamps = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
+lib.diffab_debug_set_attn_stamps(_hip.ptr(stamps))
+layer(x, e, R, t)
+torch.cuda.synchronize()
+lib.diffab_debug_set_attn_stamps(None)
+s = stamps.view(nwg, 8, 8).cpu().double()
+names = ["phase1 (S: q.k MFMA + point VALU)", "phase2 prologue + barrier", "phase2 (bias, softmax, o_e)", "phase3 prologue + barrier",
+         "phase3 (o_s, o_p, epilogue)"]
+tot = (s[..., 5] - s[..., 0])
+print(f"B={B} K={K}: {nwg} work-groups; per-wave lifetime mean {tot.mean():.0f} cycles (min {tot.min():.0f}, max {tot.max():.0f})")
+for k, n in enumerate(names):
+    dlt = s[..., k + 1] - s[..., k]
+    print(f"  {n:42s} mean {dlt.mean():9.0f}  min {dlt.min():9.0f}  max {dlt.max():9.0f}  ({100 * dlt.mean() / tot.mean():.1f} %)")
+span = s[..., 5].max() - s[..., 0].min()
+print(f"  kernel span (first stamp to last stamp): {span:.0f} cycles; 100 MHz-based? memtime ticks are shader cycles")
