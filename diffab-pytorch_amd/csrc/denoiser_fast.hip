@@ -202,7 +202,15 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // Waves 4-7 share SIMDs with waves 0-3 and run the same program: delayed by part of an iteration, one partner's LDS /
+  // addresser stage overlaps the other's VALU / MFMA stage instead of both queueing on the same unit (measured).
+  auto stagger = [&]() {
+#ifdef DIFFAB_STAGGER
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_sleep(DIFFAB_STAGGER);
+#endif
+  };
   stamp(0);
+  stagger();
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
   if ((B & 7) == 0) {
@@ -258,8 +266,12 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     const float* gk_src1 = proj + (prow0 + g1 / 6) * ANP + OFF_GK + h * 24 + 4 * (g1 % 6);
     const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
     const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
-    f32x4 st[2][4];  // register staging, two tiles in flight
+    constexpr int SD = 4;  // register staging depth: SD - 1 key tiles of lookahead (loaded L2 latency is ~2.5k cycles here)
+    f32x4 st[SD][4];
     auto load_keys = [&](int sb, int jt) {
+#ifdef DIFFAB_ABLATE_P1_LOADS
+      return;
+#endif
       const int64_t o = static_cast<int64_t>(jt) * 16 * ANP;
       st[sb][0] = *reinterpret_cast<const f32x4*>(ks_src + o);
       st[sb][1] = *reinterpret_cast<const f32x4*>(ks_src + o + 8 * ANP);
@@ -267,14 +279,17 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       if (g1 < 96) st[sb][3] = *reinterpret_cast<const f32x4*>(gk_src1 + o);
     };
     auto stage_keys = [&](int sb, int lb) {
+#ifdef DIFFAB_ABLATE_P1_LOADS
+      return;
+#endif
       float* t_ = scr + lb * P1_TILE;
       *reinterpret_cast<f32x4*>(t_ + ks_dst) = st[sb][0];
       *reinterpret_cast<f32x4*>(t_ + ks_dst + 8 * KLD) = st[sb][1];
       *reinterpret_cast<f32x4*>(t_ + gk_dst0) = st[sb][2];
       if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
     };
-    load_keys(0, 0);
-    load_keys(1, 1);
+#pragma unroll
+    for (int jt = 0; jt < SD - 1 && jt < NT; ++jt) load_keys(jt, jt);
     // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
     f32x4 qa[2];
     const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
@@ -292,13 +307,17 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     stage_keys(0, 0);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
-      if (jt + 1 < NT) stage_keys((jt + 1) & 1, (jt + 1) & 1);  // tile jt+1: registers -> LDS (its loads were issued a tile ago)
-      if (jt + 2 < NT) {
-        load_keys(jt & 1, jt + 2);
+      if (jt + 1 < NT) stage_keys((jt + 1) % SD, (jt + 1) & 1);  // tile jt+1: registers -> LDS (loads issued SD-2 tiles ago)
+      if (jt + SD - 1 < NT) {
+        load_keys((jt + SD - 1) % SD, jt + SD - 1);
       } else if constexpr (RESIDENT) {
-        load_e_tile(0, jt + 2 - NT);  // no more key tiles: start the pair-embedding stream of phase 2 under this tile
+        if (jt + 2 >= NT) load_e_tile(0, jt + 2 - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
       }
       MEM_FENCE();
+#ifdef DIFFAB_ABLATE_P1_COMPUTE
+      asm volatile("" ::"v"(st[jt % SD][0][0]), "v"(st[jt % SD][1][0]), "v"(st[jt % SD][2][0]));
+      continue;
+#endif
       const float* t_ = scr + (jt & 1) * P1_TILE;
       const f32x4 kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
       const f32x4 kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
@@ -314,6 +333,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float d2 = 0.f;
+#ifndef DIFFAB_ABLATE_P1_VALU
 #pragma unroll
         for (int c = 0; c < 6; ++c)
 #pragma unroll
@@ -321,6 +341,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
             const float dd = gq[r][c][s] - gk[c][s];
             d2 += dd * dd;
           }
+#else
+        d2 = gq[r][0][0] - gk[r][1];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) asm volatile("" ::"v"(gk[c][0]), "v"(gk[c][1]), "v"(gk[c][2]), "v"(gk[c][3]));
+#endif
         S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
       }
     }
@@ -347,6 +372,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     MEM_FENCE();
     __syncthreads();  // phase-1 logits of all heads are in LDS (and every wave is done with its key-tile scratch)
     stamp(2);
+    stagger();
     // tile re-orientation for the bias product: write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
     auto stage_e = [&](int ii, int jt) {
       float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
@@ -447,7 +473,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   stamp(3);
   // ---------------------------------------------------------------- phase 3: wave = head
   {
-    constexpr int PFV = 8;  // value prefetch distance, key steps
+    constexpr int PFV = 16;  // value prefetch distance, key steps (16 x 160 MFMA cycles ~ the loaded L2 latency)
     const int h = wv;
     const int pp = l15 & 7;
     const float* vbase = proj + (prow0 + 4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;  // + (16 jt + r) rows; d = 2 l15 + dt
@@ -466,6 +492,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     MEM_FENCE();
     __syncthreads();  // probabilities of all rows are in LDS
     stamp(4);
+    stagger();
     f32x4 os[2], og[3];
 #pragma unroll
     for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -14,7 +14,8 @@ from typing import Dict, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdiffab_hip.so")
+# DIFFAB_HIP_LIB: developer override used by tools/ to load an experimental build of the same C ABI
+LIB_PATH = os.environ.get("DIFFAB_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdiffab_hip.so")
 
 FLAG_FORCE_GENERIC = 1
 
