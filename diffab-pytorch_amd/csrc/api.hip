@@ -117,6 +117,30 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   return launch_heads_finish(b.vbuf, O_t, logits, d->V, rows, out_O0, out_post, st);
 }
 
+// Training forward: the same launches as denoise_step, but every intermediate lands in its own slot of the tape.
+static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
+                              const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps,
+                              float* out_O0, float* out_post, const TrainTape& tp, uint32_t flags, hipStream_t st) {
+  const int rows = d->B * d->K, D = d->D;
+  if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, tp.cat2, st)) return rc;
+  if (int rc = launch_linear(tp.cat2, 2 * D, w->res_w0, w->res_b0, tp.h1, D, rows, D, 2 * D, true, st)) return rc;
+  if (int rc = launch_linear(tp.h1, D, w->res_w2, w->res_b2, tp.x[0], D, rows, D, D, false, st)) return rc;
+  for (int l = 0; l < d->NL; ++l)
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], tp.x[l], pair_ctx, O_t, x_t, tp.x[l + 1], tp.ipa_ws[l], flags, st)) return rc;
+  if (int rc = launch_beta_concat(tp.x[d->NL], beta, D, d->K, rows, tp.cat3, st)) return rc;
+  const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
+  float* outs[3] = {out_eps, tp.vbuf, tp.logits};
+  const int nout[3] = {3, 3, d->V};
+  for (int hd = 0; hd < 3; ++hd) {
+    DIFFAB_REQUIRE(hw[hd]->w0 && hw[hd]->b0 && hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG,
+                   "denoiser head: null weight pointer");
+    if (int rc = launch_linear(tp.cat3, D + 3, hw[hd]->w0, hw[hd]->b0, tp.t1[hd], D, rows, D, D + 3, true, st)) return rc;
+    if (int rc = launch_linear(tp.t1[hd], D, hw[hd]->w2, hw[hd]->b2, tp.t2[hd], D, rows, D, D, true, st)) return rc;
+    if (int rc = launch_linear(tp.t2[hd], D, hw[hd]->w4, hw[hd]->b4, outs[hd], nout[hd], rows, nout[hd], D, false, st)) return rc;
+  }
+  return launch_heads_finish(tp.vbuf, O_t, tp.logits, d->V, rows, out_O0, out_post, st);
+}
+
 static int check_denoiser_weights(const diffab_dims* d, const diffab_denoiser_weights* w) {
   DIFFAB_REQUIRE(w && w->seq_emb && w->res_w0 && w->res_b0 && w->res_w2 && w->res_b2 && (d->NL == 0 || w->layers), DIFFAB_ERR_ARG,
                  "denoiser: null weight pointer");
@@ -218,6 +242,54 @@ int diffab_denoise_step_fwd(const diffab_dims* d, const diffab_denoiser_weights*
   DIFFAB_REQUIRE(workspace_bytes >= need, DIFFAB_ERR_WORKSPACE, "denoise_step_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
   return denoise_step(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, out_logits, out_res_emb, workspace,
                       flags, as_stream(stream));
+}
+
+size_t diffab_train_tape_bytes(const diffab_dims* d) {
+  if (check_dims(d, "train_tape_bytes") || d->NL > kMaxLayers) return 0;
+  return train_tape_floats(d) * sizeof(float);
+}
+
+size_t diffab_train_workspace_bytes(const diffab_dims* d) {
+  if (check_dims(d, "train_workspace_bytes")) return 0;
+  return train_bwd_workspace_floats(d) * sizeof(float);
+}
+
+int diffab_train_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
+                          const float* res_ctx, const float* pair_ctx, const float* beta, const float* true_post, const float* true_eps,
+                          const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, float* out_eps, float* out_O0,
+                          float* out_posterior, float* losses3, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
+  if (int rc = check_dims(d, "train_step_fwd")) return rc;
+  if (int rc = check_denoiser_weights(d, w)) return rc;
+  DIFFAB_REQUIRE(d->NL <= kMaxLayers, DIFFAB_ERR_UNSUPPORTED, "train_step_fwd: at most %d IPA layers", kMaxLayers);
+  DIFFAB_REQUIRE(seq_t && x_t && O_t && res_ctx && pair_ctx && beta && true_post && true_eps && true_O0 && gen_mask && res_mask && out_eps &&
+                     out_O0 && out_posterior && losses3 && tape,
+                 DIFFAB_ERR_ARG, "train_step_fwd: null pointer");
+  DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "train_step_fwd: tape %zu < %zu bytes", tape_bytes,
+                 train_tape_floats(d) * sizeof(float));
+  const TrainTape tp = carve_tape(d, static_cast<float*>(tape));
+  hipStream_t st = as_stream(stream);
+  if (int rc = denoise_step_taped(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, tp, flags, st)) return rc;
+  return launch_losses_fwd(out_posterior, true_post, out_eps, true_eps, out_O0, true_O0, gen_mask, res_mask, d->B, d->K, d->V, losses3, st);
+}
+
+int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
+                          const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_eps,
+                          const float* out_O0, const float* out_posterior, const float* true_post, const float* true_eps,
+                          const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, const float* upstream3, float* d_res_ctx,
+                          float* d_pair_ctx, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_dims(d, "train_step_bwd")) return rc;
+  if (int rc = check_denoiser_weights(d, w)) return rc;
+  if (int rc = check_denoiser_weights(d, grads)) return rc;
+  DIFFAB_REQUIRE(d->NL <= kMaxLayers, DIFFAB_ERR_UNSUPPORTED, "train_step_bwd: at most %d IPA layers", kMaxLayers);
+  DIFFAB_REQUIRE(seq_t && x_t && O_t && pair_ctx && out_eps && out_O0 && out_posterior && true_post && true_eps && true_O0 && gen_mask &&
+                     res_mask && upstream3 && tape && workspace,
+                 DIFFAB_ERR_ARG, "train_step_bwd: null pointer");
+  DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "train_step_bwd: tape too small");
+  DIFFAB_REQUIRE(workspace_bytes >= train_bwd_workspace_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "train_step_bwd: workspace %zu < %zu",
+                 workspace_bytes, train_bwd_workspace_floats(d) * sizeof(float));
+  const TrainTape tp = carve_tape(d, static_cast<float*>(const_cast<void*>(tape)));
+  return train_step_bwd(d, w, grads, tp, seq_t, x_t, O_t, pair_ctx, out_eps, out_O0, out_posterior, true_post, true_eps, true_O0, gen_mask,
+                        res_mask, upstream3, d_res_ctx, d_pair_ctx, static_cast<float*>(workspace), as_stream(stream));
 }
 
 int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_sched* s, const diffab_igso3* rev_tab,

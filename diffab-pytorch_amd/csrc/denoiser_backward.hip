@@ -1,0 +1,584 @@
+// denoiser_backward.hip - backward of the hot-path training step (reference: autograd through
+// Denoiser.forward diffab_pytorch.py:558-607 and the loss assembly :856-880; BASELINE config 4).
+//
+// Correctness-first kernels for ANY model dims: the softmax of each query row is recomputed from the saved projections
+// (nothing of size K x K is stored), per-row results are written directly and per-key / per-parameter sums are added
+// with float atomics (sized by bytes per Guideline 12: ~0.4 MB of adds per patch-layer).  Saved activations ("tape"):
+// per layer the layer input, the projection buffer and the feature rows - the same buffers the forward kernels write.
+#include "common.h"
+#include "denoiser_internal.h"
+#include "so3_math.h"
+
+namespace diffab {
+
+// ------------------------------------------------------------------ GEMMs (generic, LDS-tiled VALU)
+constexpr int TB = 64, TK = 16;
+
+// C[M,N] (+)= A[M,K] B[K,N]           (dX = dY W)
+template <bool ACC>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                      float* __restrict__ C, int ldc, int M, int N, int K) {
+  __shared__ float As[TK][TB + 4];
+  __shared__ float Bs[TK][TB + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + r * 256;
+      {  // A tile: 64 rows x 16 k
+        const int row = idx >> 4, kk = idx & 15;
+        const int gm = m0 + row, gk = k0 + kk;
+        As[kk][row] = (gm < M && gk < K) ? A[static_cast<int64_t>(gm) * lda + gk] : 0.0f;
+      }
+      {  // B tile: 16 k x 64 cols
+        const int kk = idx >> 6, col = idx & 63;
+        const int gk = k0 + kk, gn = n0 + col;
+        Bs[kk][col] = (gk < K && gn < N) ? Bm[static_cast<int64_t>(gk) * ldb + gn] : 0.0f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + ty * 4 + i;
+    if (gm >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + tx * 4 + j;
+      if (gn >= N) continue;
+      float* c = C + static_cast<int64_t>(gm) * ldc + gn;
+      *c = ACC ? (*c + acc[i][j]) : acc[i][j];
+    }
+  }
+}
+
+// C[N1,N2] += A[M,N1]^T B[M,N2]       (dW += dY^T X), the long M reduction is split over blockIdx.z and added atomically
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                      float* __restrict__ C, int ldc, int M, int N1, int N2, int m_chunk) {
+  __shared__ float As[TK][TB + 4];
+  __shared__ float Bs[TK][TB + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int a0 = blockIdx.y * TB, b0 = blockIdx.x * TB;
+  const int m_lo = blockIdx.z * m_chunk, m_hi = min(M, m_lo + m_chunk);
+  float acc[4][4] = {};
+  for (int k0 = m_lo; k0 < m_hi; k0 += TK) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + r * 256, kk = idx >> 6, col = idx & 63;
+      const int gm = k0 + kk;
+      As[kk][col] = (gm < m_hi && a0 + col < N1) ? A[static_cast<int64_t>(gm) * lda + a0 + col] : 0.0f;
+      Bs[kk][col] = (gm < m_hi && b0 + col < N2) ? Bm[static_cast<int64_t>(gm) * ldb + b0 + col] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = a0 + ty * 4 + i;
+    if (r >= N1) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = b0 + tx * 4 + j;
+      if (c < N2) atomicAdd(C + static_cast<int64_t>(r) * ldc + c, acc[i][j]);
+    }
+  }
+}
+
+// db[n] += sum_m dY[m][n]; optionally dY *= (act > 0) first (ReLU backward, in place)
+__global__ void relu_mask_kernel(float* __restrict__ dY, const float* __restrict__ act, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n && !(act[i] > 0.0f)) dY[i] = 0.0f;
+}
+__global__ void colsum_kernel(const float* __restrict__ dY, int ld, int M, int N, int m_chunk, float* __restrict__ db) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int lo = blockIdx.y * m_chunk, hi = min(M, lo + m_chunk);
+  float s = 0.f;
+  for (int m = lo; m < hi; ++m) s += dY[static_cast<int64_t>(m) * ld + n];
+  atomicAdd(db + n, s);
+}
+
+static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st) {
+  dim3 grid((N + TB - 1) / TB, (M + TB - 1) / TB);
+  if (acc) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+  else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st) {
+  const int m_chunk = 2048;
+  dim3 grid((N2 + TB - 1) / TB, (N1 + TB - 1) / TB, (M + m_chunk - 1) / m_chunk);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N1, N2, m_chunk);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+static int colsum(const float* dY, int ld, int M, int N, float* db, hipStream_t st) {
+  const int m_chunk = 4096;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + m_chunk - 1) / m_chunk), dim3(64), 0, st, dY, ld, M, N, m_chunk, db);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+static int relu_mask(float* dY, const float* act, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, dY, act, n);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// Y = act(X W^T + b) backward: dW += dY^T X, db += colsum dY, dX (+)= dY W.   dY must already carry the activation mask.
+static int linear_bwd(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M,
+                      int N, int Kd, bool acc_dx, hipStream_t st) {
+  if (int rc = gemm_tn(dY, ldy, X, ldx, dW, Kd, M, N, Kd, st)) return rc;
+  if (db)
+    if (int rc = colsum(dY, ldy, M, N, db, st)) return rc;
+  if (dX) return gemm_nn(dY, ldy, W, Kd, dX, lddx, M, Kd, N, acc_dx, st);
+  return DIFFAB_OK;
+}
+
+// ------------------------------------------------------------------ loss backward (per residue)
+// upstream scalars g = (g_seq, g_x, g_o); N = #masked residues (device scalar computed here by one block)
+__global__ void count_mask_kernel(const uint8_t* __restrict__ gm, const uint8_t* __restrict__ rm, int64_t n, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float c = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) c += (gm[i] && rm[i]) ? 1.0f : 0.0f;
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void losses_bwd_kernel(const float* __restrict__ post, const float* __restrict__ tpost, const float* __restrict__ eps,
+                                  const float* __restrict__ teps, const float* __restrict__ O0, const float* __restrict__ tO,
+                                  const float* __restrict__ O_t, const float* __restrict__ v, const uint8_t* __restrict__ gm,
+                                  const uint8_t* __restrict__ rm, const float* __restrict__ count, const float* __restrict__ up, int V,
+                                  int64_t rows, float* __restrict__ d_logits, float* __restrict__ d_eps, float* __restrict__ d_v) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= rows) return;
+  const float g_seq = up[0], g_x = up[1], g_o = up[2];  // upstream gradients of the three losses
+  const bool m = gm[i] && rm[i];
+  const float invN = 1.0f / count[0];
+  // KL(q || p) with p = softmax(logits): dL/dlogit_v = (p_v sum_u q_u - q_v) / N      (kl_div(log p, q), :857-859)
+  float qs = 0.f;
+  for (int c = 0; c < V; ++c) qs += tpost[i * V + c] > 0.0f ? tpost[i * V + c] : 0.0f;
+  for (int c = 0; c < V; ++c) {
+    const float q = tpost[i * V + c] > 0.0f ? tpost[i * V + c] : 0.0f;
+    d_logits[i * V + c] = m ? g_seq * invN * (post[i * V + c] * qs - q) : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d_eps[i * 3 + c] = m ? g_x * invN * 2.0f * (eps[i * 3 + c] - teps[i * 3 + c]) : 0.0f;  // MSE (:860-862)
+  if (!m) {
+    d_v[i * 3] = d_v[i * 3 + 1] = d_v[i * 3 + 2] = 0.0f;
+    return;
+  }
+  // orientation loss sum_jk (sum_r O0[r][j] tO[r][k] - delta_jk)^2   (:620-625)  -> G0 = dL/dO0
+  float D[9], G0[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float d = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) d += O0[i * 9 + r * 3 + j] * tO[i * 9 + r * 3 + k];
+      D[j * 3 + k] = d - (j == k ? 1.0f : 0.0f);
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += 2.0f * D[j * 3 + k] * tO[i * 9 + r * 3 + k];
+      G0[r * 3 + j] = g_o * invN * s;
+    }
+  // O0 = O_t E  ->  G = dL/dE = O_t^T G0        (:596)
+  float G[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) s += O_t[i * 9 + r * 3 + a] * G0[r * 3 + b];
+      G[a * 3 + b] = s;
+    }
+  // E = I + a S + b S^2, S = hat(v), n = |v|, a = sin n / n, b = (1 - cos n) / n^2      (so3.py:219-237)
+  const float vx = v[i * 3], vy = v[i * 3 + 1], vz = v[i * 3 + 2];
+  const float n = sqrtf(vx * vx + vy * vy + vz * vz);
+  float sn, cn;
+  sincosf(n, &sn, &cn);
+  const float a = sn / n, b = (1.0f - cn) / (n * n);
+  const float da = (cn - a) / n, db = (a - 2.0f * b) / n;  // derivatives with respect to n
+  float S[9], S2[9];
+  so3_hat(vx, vy, vz, S);
+  mat3_mul(S, S, S2);
+  float gS = 0.f, gS2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { gS += G[k] * S[k]; gS2 += G[k] * S2[k]; }
+  // <G, dS S + S dS> = <G S^T + S^T G, dS>;   dS = hat(dv)
+  float H[9], ST[9], T1[9], T2[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ST[r * 3 + c] = S[c * 3 + r];
+  mat3_mul(G, ST, T1);
+  mat3_mul(ST, G, T2);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) H[k] = a * G[k] + b * (T1[k] + T2[k]);
+  const float vv[3] = {vx, vy, vz};
+  // <H, hat(e_x)> = H21 - H12, <H, hat(e_y)> = H02 - H20, <H, hat(e_z)> = H10 - H01
+  const float hk[3] = {H[7] - H[5], H[2] - H[6], H[3] - H[1]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d_v[i * 3 + k] = hk[k] + (da * gS + db * gS2) * vv[k] / n;
+}
+
+// ------------------------------------------------------------------ attention backward, one work-group per (patch, query residue)
+// proj / dproj rows: [q_s | k_s | v_s | gq | gk | gv] (points in the global frame; dproj holds gradients w.r.t. the GLOBAL points,
+// points_bwd_kernel turns them into local-point gradients afterwards).  dproj must be zeroed before the launch.
+__global__ __launch_bounds__(256) void ipa_attn_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ e,
+                                                           const float* __restrict__ R, const float* __restrict__ t,
+                                                           const float* __restrict__ Wb, const float* __restrict__ gamma,
+                                                           const float* __restrict__ feat, const float* __restrict__ dfeat,
+                                                           float* __restrict__ dproj, float* __restrict__ de, float* __restrict__ dWb,
+                                                           float* __restrict__ dgamma, int K, int C, int H, int DS, int PQ, int PV) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x / K, i = blockIdx.x % K;
+  const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
+  const int F = H * DS + H * C + H * PV * 3 + H * PV;
+  const int off_ks = H * DS, off_vs = 2 * H * DS, off_gq = 3 * H * DS, off_gk = off_gq + H * PQ * 3, off_gv = off_gk + H * PQ * 3;
+  const int n_os = H * DS, n_oe = H * C, n_og = H * PV * 3;
+  float* attn = smem;                        // H*K   probabilities
+  float* gl = attn + H * K;                  // H*K   dA, then scale_t * dlogit
+  float* d2 = gl + H * K;                    // H*K   squared point distances
+  float* qrow = d2 + H * K;                  // H*DS + H*PQ*3
+  float* dog = qrow + H * DS + H * PQ * 3;   // H*PV*3  gradient w.r.t. the global value-point sums
+  float* red = dog + H * PV * 3;             // H  row sums
+  const int64_t row_i = static_cast<int64_t>(b) * K + i;
+  const float* prow = proj + row_i * NP;
+  const float* frow = feat + row_i * F;
+  const float* dfrow = dfeat + row_i * F;
+  const float* erow = e + row_i * K * C;
+  float* derow = de ? de + row_i * K * C : nullptr;
+  const float* Rr = R + row_i * 9;
+  for (int d = threadIdx.x; d < H * DS; d += blockDim.x) qrow[d] = prow[d];
+  for (int d = threadIdx.x; d < H * PQ * 3; d += blockDim.x) qrow[H * DS + d] = prow[off_gq + d];
+  // value-point sums: o_l = (o_g - t) R^T, o_n = |o_l|  ->  d o_g[k] = sum_c (do_l[c] + do_n o_l[c]/o_n) R[c][k]
+  for (int hp = threadIdx.x; hp < H * PV; hp += blockDim.x) {
+    const float on = frow[n_os + n_oe + n_og + hp], don = dfrow[n_os + n_oe + n_og + hp];
+    float dl[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float ol = frow[n_os + n_oe + hp * 3 + c];
+      dl[c] = dfrow[n_os + n_oe + hp * 3 + c] + (on > 0.0f ? don * ol / on : 0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dog[hp * 3 + k] = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
+  }
+  __syncthreads();
+  const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
+  const float scale_p = -0.5f / sqrtf(4.5f * PQ);
+  const float scale_t = 1.0f / sqrtf(3.0f);
+  // ---- recompute logits (same expression order as the forward kernel)
+  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+    const int h = idx / K, j = idx % K;
+    const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+    float ls = 0.f, lb = 0.f, lp = 0.f;
+    for (int d = 0; d < DS; ++d) ls += qrow[h * DS + d] * krow[off_ks + h * DS + d];
+    for (int c = 0; c < C; ++c) lb += erow[static_cast<int64_t>(j) * C + c] * Wb[h * C + c];
+    for (int p = 0; p < PQ * 3; ++p) {
+      const float dd = qrow[H * DS + h * PQ * 3 + p] - krow[off_gk + h * PQ * 3 + p];
+      lp += dd * dd;
+    }
+    d2[idx] = lp;
+    attn[idx] = scale_t * ((ls * scale_s + lb) + (scale_p * gamma[h]) * lp);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  for (int h = wave; h < H; h += nwave) {
+    float m = -INFINITY;
+    for (int j = lane; j < K; j += 64) m = fmaxf(m, attn[h * K + j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int j = lane; j < K; j += 64) {
+      const float ex = expf(attn[h * K + j] - m);
+      attn[h * K + j] = ex;
+      s += ex;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / s;
+    for (int j = lane; j < K; j += 64) attn[h * K + j] *= inv;
+  }
+  __syncthreads();
+  // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]; and the value-side gradients A * do_*
+  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+    const int h = idx / K, j = idx % K;
+    const float A = attn[idx];
+    const float* vrow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+    float* dvrow = dproj + (static_cast<int64_t>(b) * K + j) * NP;
+    float s = 0.f;
+    for (int d = 0; d < DS; ++d) {
+      const float g = dfrow[h * DS + d];
+      s += g * vrow[off_vs + h * DS + d];
+      atomicAdd(dvrow + off_vs + h * DS + d, A * g);
+    }
+    for (int c = 0; c < C; ++c) s += dfrow[n_os + h * C + c] * erow[static_cast<int64_t>(j) * C + c];
+    for (int p = 0; p < PV * 3; ++p) {
+      const float g = dog[h * PV * 3 + p];
+      s += g * vrow[off_gv + h * PV * 3 + p];
+      atomicAdd(dvrow + off_gv + h * PV * 3 + p, A * g);
+    }
+    gl[idx] = s;
+  }
+  __syncthreads();
+  // ---- softmax backward: dlogit = A (dA - sum_j A dA); keep g = scale_t * dlogit
+  for (int h = wave; h < H; h += nwave) {
+    float s = 0.f;
+    for (int j = lane; j < K; j += 64) s += attn[h * K + j] * gl[h * K + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[h] = s;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+    const int h = idx / K;
+    gl[idx] = scale_t * attn[idx] * (gl[idx] - red[h]);
+  }
+  __syncthreads();
+  // ---- key-side gradients (atomics over query rows) and gamma
+  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+    const int h = idx / K, j = idx % K;
+    const float g = gl[idx];
+    const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+    float* dkrow = dproj + (static_cast<int64_t>(b) * K + j) * NP;
+    for (int d = 0; d < DS; ++d) atomicAdd(dkrow + off_ks + h * DS + d, g * scale_s * qrow[h * DS + d]);
+    const float cp = 2.0f * scale_p * gamma[h] * g;
+    for (int p = 0; p < PQ * 3; ++p) {
+      const float dd = qrow[H * DS + h * PQ * 3 + p] - krow[off_gk + h * PQ * 3 + p];
+      atomicAdd(dkrow + off_gk + h * PQ * 3 + p, -cp * dd);
+    }
+  }
+  for (int h = wave; h < H; h += nwave) {
+    float s = 0.f;
+    for (int j = lane; j < K; j += 64) s += gl[h * K + j] * scale_p * d2[h * K + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) atomicAdd(dgamma + h, s);
+  }
+  // ---- query-side gradients (this row only: plain stores)
+  float* dqrow = dproj + row_i * NP;
+  for (int o = threadIdx.x; o < H * DS + H * PQ * 3; o += blockDim.x) {
+    float acc = 0.f;
+    if (o < H * DS) {
+      const int h = o / DS;
+      for (int j = 0; j < K; ++j) acc += gl[h * K + j] * proj[(static_cast<int64_t>(b) * K + j) * NP + off_ks + o];
+      atomicAdd(dqrow + o, acc * scale_s);  // this row's k/v/g_k/g_v slots receive atomics from other rows; q slots only from here
+    } else {
+      const int oo = o - H * DS, h = oo / (PQ * 3);
+      const float cp = 2.0f * scale_p * gamma[h];
+      for (int j = 0; j < K; ++j)
+        acc += gl[h * K + j] * (qrow[H * DS + oo] - proj[(static_cast<int64_t>(b) * K + j) * NP + off_gk + oo]);
+      atomicAdd(dqrow + off_gq + oo, cp * acc);
+    }
+  }
+  // ---- pair embedding: de[i][j][c] += sum_h (A do_e[h][c] + g Wb[h][c]);   dWb[h][c] += sum_j g e[i][j][c]
+  if (derow) {
+    for (int idx = threadIdx.x; idx < K * C; idx += blockDim.x) {
+      const int j = idx / C, c = idx % C;
+      float s = 0.f;
+      for (int h = 0; h < H; ++h) s += attn[h * K + j] * dfrow[n_os + h * C + c] + gl[h * K + j] * Wb[h * C + c];
+      derow[idx] += s;
+    }
+  }
+  for (int o = threadIdx.x; o < H * C; o += blockDim.x) {
+    const int h = o / C, c = o % C;
+    float s = 0.f;
+    for (int j = 0; j < K; ++j) s += gl[h * K + j] * erow[static_cast<int64_t>(j) * C + c];
+    atomicAdd(dWb + o, s);
+  }
+}
+
+// gradient w.r.t. global points -> local points, in place: g = p R + t  =>  dp[k] = sum_c dg[c] R[k][c]
+__global__ void points_bwd_kernel(float* __restrict__ dproj, int ld, int col0, int n_pts, const float* __restrict__ R, int64_t rows) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (gid >= rows * n_pts) return;
+  const int64_t r = gid / n_pts;
+  float* q = dproj + r * ld + col0 + (gid % n_pts) * 3;
+  const float* Rr = R + r * 9;
+  const float x = q[0], y = q[1], z = q[2];
+  q[0] = x * Rr[0] + y * Rr[1] + z * Rr[2];
+  q[1] = x * Rr[3] + y * Rr[4] + z * Rr[5];
+  q[2] = x * Rr[6] + y * Rr[7] + z * Rr[8];
+}
+
+// d seq_emb[s] += dcat2[:, D:2D];  d res_ctx = dcat2[:, 0:D]
+__global__ void embed_bwd_kernel(const float* __restrict__ dcat2, const int64_t* __restrict__ seq, int D, int64_t rows,
+                                 float* __restrict__ d_res_ctx, float* __restrict__ d_emb) {
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  const int64_t s = seq[r];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    if (d_res_ctx) d_res_ctx[r * D + d] = dcat2[r * 2 * D + d];
+    atomicAdd(d_emb + s * D + d, dcat2[r * 2 * D + D + d]);
+  }
+}
+
+// ------------------------------------------------------------------ orchestration
+size_t train_tape_floats(const diffab_dims* d) {
+  const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
+  const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
+  const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
+  return rows * (2 * D + D + D) + static_cast<size_t>(d->NL) * rows * (NP + F + D) + rows * (D + 3) + 6 * rows * D + rows * 3 +
+         rows * d->V + 1024;
+}
+
+TrainTape carve_tape(const diffab_dims* d, float* base) {
+  const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
+  const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
+  const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
+  TrainTape t;
+  float* p = base;
+  auto take = [&](size_t n) { float* r = p; p += n; return r; };
+  t.cat2 = take(rows * 2 * D);
+  t.h1 = take(rows * D);
+  t.x[0] = take(rows * D);
+  for (int l = 0; l < d->NL; ++l) {
+    t.ipa_ws[l] = take(rows * (NP + F));
+    t.x[l + 1] = take(rows * D);
+  }
+  t.cat3 = take(rows * (D + 3));
+  for (int hd = 0; hd < 3; ++hd) { t.t1[hd] = take(rows * D); t.t2[hd] = take(rows * D); }
+  t.vbuf = take(rows * 3);
+  t.logits = take(rows * d->V);
+  return t;
+}
+
+size_t train_bwd_workspace_floats(const diffab_dims* d) {
+  const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
+  const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
+  const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
+  return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64;
+}
+
+int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
+                   const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* eps_hat,
+                   const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
+                   const uint8_t* gm, const uint8_t* rm, const float* upstream3, float* d_res_ctx, float* d_pair_ctx, float* ws,
+                   hipStream_t st) {
+  const int rows = d->B * d->K, D = d->D, H = d->H, DS = d->DS, PQ = d->PQ, PV = d->PV, C = d->C, V = d->V;
+  const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
+  const int F = H * DS + H * C + H * PV * 3 + H * PV;
+  float* p = ws;
+  auto take = [&](size_t n) { float* r = p; p += n; return r; };
+  float* cnt = take(64);
+  float* d_logits = take(static_cast<size_t>(rows) * V);
+  float* d_eps = take(static_cast<size_t>(rows) * 3);
+  float* d_v = take(static_cast<size_t>(rows) * 3);
+  float* dcat3 = take(static_cast<size_t>(rows) * (D + 3));
+  float* dt2 = take(static_cast<size_t>(rows) * D);
+  float* dt1 = take(static_cast<size_t>(rows) * D);
+  float* dxa = take(static_cast<size_t>(rows) * D);
+  float* dxb = take(static_cast<size_t>(rows) * D);
+  float* dfeat = take(static_cast<size_t>(rows) * F);
+  float* dproj = take(static_cast<size_t>(rows) * NP);
+  float* dcat2 = take(static_cast<size_t>(rows) * 2 * D);
+
+  hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
+  DIFFAB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(losses_bwd_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, true_post, eps_hat, true_eps, O0_hat, true_O0,
+                     O_t, tp.vbuf, gm, rm, cnt, upstream3, V, static_cast<int64_t>(rows), d_logits, d_eps, d_v);
+  DIFFAB_LAUNCH_CHECK();
+  // ---- heads (Linear-ReLU-Linear-ReLU-Linear), gradients into cat3 accumulate over the three heads
+  const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
+  const diffab_mlp3_weights* hg[3] = {&g->coord, &g->orient, &g->seq};
+  const float* dy[3] = {d_eps, d_v, d_logits};
+  const int nout[3] = {3, 3, V};
+  for (int hd = 0; hd < 3; ++hd) {
+    if (int rc = linear_bwd(dy[hd], nout[hd], tp.t2[hd], D, hw[hd]->w4, const_cast<float*>(hg[hd]->w4), const_cast<float*>(hg[hd]->b4), dt2,
+                            D, rows, nout[hd], D, false, st)) return rc;
+    if (int rc = relu_mask(dt2, tp.t2[hd], static_cast<int64_t>(rows) * D, st)) return rc;
+    if (int rc = linear_bwd(dt2, D, tp.t1[hd], D, hw[hd]->w2, const_cast<float*>(hg[hd]->w2), const_cast<float*>(hg[hd]->b2), dt1, D, rows,
+                            D, D, false, st)) return rc;
+    if (int rc = relu_mask(dt1, tp.t1[hd], static_cast<int64_t>(rows) * D, st)) return rc;
+    if (int rc = linear_bwd(dt1, D, tp.cat3, D + 3, hw[hd]->w0, const_cast<float*>(hg[hd]->w0), const_cast<float*>(hg[hd]->b0), dcat3,
+                            D + 3, rows, D, D + 3, hd > 0, st)) return rc;
+  }
+  // dh = dcat3[:, :D] (leading dimension D+3)
+  float* dcur = dxa;
+  float* dnxt = dxb;
+  DIFFAB_HIP_CHECK(hipMemcpy2DAsync(dcur, sizeof(float) * D, dcat3, sizeof(float) * (D + 3), sizeof(float) * D, rows,
+                                    hipMemcpyDeviceToDevice, st));
+  // ---- IPA layers, last to first
+  for (int l = d->NL - 1; l >= 0; --l) {
+    const diffab_ipa_layer_weights* lw = &w->layers[l];
+    const diffab_ipa_layer_weights* lg = &g->layers[l];
+    const float* proj = tp.ipa_ws[l];
+    const float* feat = tp.ipa_ws[l] + static_cast<size_t>(rows) * NP;
+    const float* xin = tp.x[l];
+    // to_out
+    if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows, D, F,
+                            false, st)) return rc;
+    DIFFAB_HIP_CHECK(hipMemsetAsync(dproj, 0, sizeof(float) * static_cast<size_t>(rows) * NP, st));
+    const size_t lds = (3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H) * sizeof(float);
+    DIFFAB_REQUIRE(lds <= 160 * 1024, DIFFAB_ERR_UNSUPPORTED, "attention backward: H*K too large for LDS (%zu bytes)", lds);
+    if (lds > 64 * 1024)
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds)));
+    hipLaunchKernelGGL(ipa_attn_bwd_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, x_t, lw->w_bias, lw->gamma, feat, dfeat,
+                       dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), d->K, C, H, DS, PQ, PV);
+    DIFFAB_LAUNCH_CHECK();
+    // global-point gradients -> local-point gradients (three point blocks)
+    const int cols[3] = {3 * H * DS, 3 * H * DS + H * PQ * 3, 3 * H * DS + 2 * H * PQ * 3};
+    const int npts[3] = {H * PQ, H * PQ, H * PV};
+    for (int q = 0; q < 3; ++q) {
+      const int64_t n = static_cast<int64_t>(rows) * npts[q];
+      hipLaunchKernelGGL(points_bwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, dproj, NP, cols[q], npts[q], O_t,
+                         static_cast<int64_t>(rows));
+      DIFFAB_LAUNCH_CHECK();
+    }
+    // projections: dx = sum_seg dproj_seg W_seg, dW_seg += dproj_seg^T x_in
+    const float* Ws[6] = {lw->wq_s, lw->wk_s, lw->wv_s, lw->wq_p, lw->wk_p, lw->wv_p};
+    float* dWs[6] = {const_cast<float*>(lg->wq_s), const_cast<float*>(lg->wk_s), const_cast<float*>(lg->wv_s),
+                     const_cast<float*>(lg->wq_p), const_cast<float*>(lg->wk_p), const_cast<float*>(lg->wv_p)};
+    const int Ns[6] = {H * DS, H * DS, H * DS, H * PQ * 3, H * PQ * 3, H * PV * 3};
+    int col = 0;
+    for (int q = 0; q < 6; ++q) {
+      if (int rc = linear_bwd(dproj + col, NP, xin, D, Ws[q], dWs[q], nullptr, dnxt, D, rows, Ns[q], D, q > 0, st)) return rc;
+      col += Ns[q];
+    }
+    float* tmp = dcur; dcur = dnxt; dnxt = tmp;
+  }
+  // ---- to_res_emb (Linear-ReLU-Linear) and the sequence embedding
+  if (int rc = linear_bwd(dcur, D, tp.h1, D, w->res_w2, const_cast<float*>(g->res_w2), const_cast<float*>(g->res_b2), dnxt, D, rows, D, D,
+                          false, st)) return rc;
+  if (int rc = relu_mask(dnxt, tp.h1, static_cast<int64_t>(rows) * D, st)) return rc;
+  if (int rc = linear_bwd(dnxt, D, tp.cat2, 2 * D, w->res_w0, const_cast<float*>(g->res_w0), const_cast<float*>(g->res_b0), dcat2, 2 * D,
+                          rows, D, 2 * D, false, st)) return rc;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, st, dcat2, seq_t, D, static_cast<int64_t>(rows), d_res_ctx,
+                     const_cast<float*>(g->seq_emb));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // namespace diffab

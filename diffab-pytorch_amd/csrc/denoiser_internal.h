@@ -29,6 +29,22 @@ void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime s
 void timer_begin(hipStream_t st);
 void timer_end(hipStream_t st);
 
+// denoiser_backward.hip: saved activations of one training forward (every buffer written by the forward kernels themselves)
+constexpr int kMaxLayers = 16;
+struct TrainTape {
+  float *cat2, *h1, *x[kMaxLayers + 1], *ipa_ws[kMaxLayers], *cat3, *t1[3], *t2[3], *vbuf, *logits;
+};
+size_t train_tape_floats(const diffab_dims* d);
+TrainTape carve_tape(const diffab_dims* d, float* base);
+size_t train_bwd_workspace_floats(const diffab_dims* d);
+int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
+                   const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* eps_hat,
+                   const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
+                   const uint8_t* gm, const uint8_t* rm, const float* upstream3, float* d_res_ctx, float* d_pair_ctx, float* ws,
+                   hipStream_t st);
+int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const float* te, const float* pO, const float* tO, const uint8_t* gm,
+                      const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st);
+
 // diffusion_kernels.hip
 int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
                                  const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,

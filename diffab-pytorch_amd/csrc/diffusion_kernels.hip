@@ -3,6 +3,7 @@
 // coalesced loads, no LDS except the loss and CDF reductions.  Compiled with -ffp-contract=off so that
 // a*x + b*y rounds like the reference's separate ATen ops.
 #include "common.h"
+#include "denoiser_internal.h"
 #include "philox.h"
 #include "so3_math.h"
 
@@ -440,6 +441,13 @@ int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab,
   hipLaunchKernelGGL(reverse_update_philox_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, st, s->beta, s->alpha,
                      s->one_minus_alpha_bar_sqrt, t, tab->sigmas, tab->cdf, tab->n_bins, tab->sigma_threshold, seq, x, O, eps_hat, O0_hat,
                      post, gm, seed, first_patch, B, K, V);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const float* te, const float* pO, const float* tO, const uint8_t* gm,
+                      const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st) {
+  hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(1024), 0, st, pp, tp, pe, te, pO, tO, gm, rm, static_cast<int64_t>(B) * K, V, out3);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

@@ -90,6 +90,10 @@ SYMBOLS = {
     "diffab_denoise_step_fwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                           _fp, _sz, _u32, _fp]),
     "diffab_losses_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, _fp]),
+    "diffab_train_tape_bytes": (_sz, [_PD]),
+    "diffab_train_workspace_bytes": (_sz, [_PD]),
+    "diffab_train_step_fwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights)] + [_fp] * 16 + [_sz, _u32, _fp]),
+    "diffab_train_step_bwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), C.POINTER(DenoiserWeights)] + [_fp] * 16 + [_sz, _fp, _sz, _fp]),
     "diffab_orientation_loss": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp]),
     "diffab_reverse_update": (C.c_int, [_PS, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "diffab_sample_loop": (C.c_int, [_PD, C.POINTER(DenoiserWeights), _PS, _PI, _fp, _fp, _fp, _fp, _fp, _fp, _u64, _i64, _i32,

@@ -160,6 +160,61 @@ class Denoiser(nn.Module):
         return out
 
 
+class _HotpathTrainStep(torch.autograd.Function):
+    """(seq KL, translation MSE, orientation loss) of one noised batch, differentiable w.r.t. every denoiser parameter and
+    the two context embeddings.  Forward = diffab_train_step_fwd (Denoiser forward with a saved-activation tape + the masked
+    losses of reference diffab_pytorch.py:856-880), backward = diffab_train_step_bwd.  Both are single C-ABI calls."""
+
+    @staticmethod
+    def forward(ctx, denoiser, seq_t, x_t, O_t, beta, true_post, true_eps, true_O0, gen_mask, res_mask, res_ctx, pair_ctx, *params):
+        lib = _hip.lib()
+        names = [n for n, _ in denoiser.named_parameters()]
+        seq = _hip.dev_i64(seq_t)
+        x, O, bt, tp, te, tO, rc, pc = (_hip.dev_f32(a) for a in (x_t, O_t, beta, true_post, true_eps, true_O0, res_ctx, pair_ctx))
+        gm, rm = _hip.dev_mask(gen_mask), _hip.dev_mask(res_mask)
+        B, K = seq.shape
+        dims = denoiser.hip_dims(B, K)
+        w = _hip.DenoiserWeightsOnDevice(dict(zip(names, params)), denoiser.dims["NL"])
+        dev = seq.device
+        eps = torch.empty(B, K, 3, dtype=torch.float32, device=dev)
+        O0 = torch.empty(B, K, 3, 3, dtype=torch.float32, device=dev)
+        post = torch.empty(B, K, dims.V, dtype=torch.float32, device=dev)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        tape = _hip.workspace(lib.diffab_train_tape_bytes(C.byref(dims)))
+        _hip.check(lib.diffab_train_step_fwd(C.byref(dims), C.byref(w.struct), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(rc),
+                                             _hip.ptr(pc), _hip.ptr(bt), _hip.ptr(tp), _hip.ptr(te), _hip.ptr(tO), _hip.ptr(gm), _hip.ptr(rm),
+                                             _hip.ptr(eps), _hip.ptr(O0), _hip.ptr(post), _hip.ptr(losses), _hip.ptr(tape), tape.numel(), 0,
+                                             _hip.stream_ptr()), "diffab_train_step_fwd")
+        ctx.denoiser, ctx.names, ctx.dims = denoiser, names, dims
+        ctx.need = (ctx.needs_input_grad[10], ctx.needs_input_grad[11])
+        ctx.out_devs = (res_ctx.device, pair_ctx.device, [p.device for p in params])
+        ctx.save_for_backward(seq, x, O, pc, eps, O0, post, tp, te, tO, gm, rm, tape, *params)
+        ctx.mark_non_differentiable(eps, O0, post)
+        return losses, eps, O0, post
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_eps, _g_O0, _g_post):
+        lib = _hip.lib()
+        seq, x, O, pc, eps, O0, post, tp, te, tO, gm, rm, tape = ctx.saved_tensors[:13]
+        params = ctx.saved_tensors[13:]
+        dims = ctx.dims
+        B, K = seq.shape
+        w = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, params)), ctx.denoiser.dims["NL"])
+        grads = [torch.zeros(p.shape, dtype=torch.float32, device=seq.device) for p in params]
+        g = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, grads)), ctx.denoiser.dims["NL"])
+        up = _hip.dev_f32(g_losses)
+        d_rc = torch.empty(B, K, dims.D, dtype=torch.float32, device=seq.device)
+        d_pc = torch.zeros_like(pc) if ctx.need[1] else None
+        ws = _hip.workspace(lib.diffab_train_workspace_bytes(C.byref(dims)))
+        _hip.check(lib.diffab_train_step_bwd(C.byref(dims), C.byref(w.struct), C.byref(g.struct), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O),
+                                             _hip.ptr(pc), _hip.ptr(eps), _hip.ptr(O0), _hip.ptr(post), _hip.ptr(tp), _hip.ptr(te), _hip.ptr(tO),
+                                             _hip.ptr(gm), _hip.ptr(rm), _hip.ptr(up), _hip.ptr(d_rc), _hip.ptr(d_pc), _hip.ptr(tape),
+                                             tape.numel(), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()), "diffab_train_step_bwd")
+        rc_dev, pc_dev, p_devs = ctx.out_devs
+        out_params = tuple(gr.to(dv) for gr, dv in zip(grads, p_devs))
+        return (None,) * 10 + (d_rc.to(rc_dev) if ctx.need[0] else None, d_pc.to(pc_dev) if ctx.need[1] else None) + out_params
+
+
 class OrientationLoss(nn.Module):
     """(pred^T target - I)^2; reduction 'none' | 'mean' | 'sum' (diffab_pytorch.py:610-625)."""
 
@@ -294,6 +349,16 @@ class DiffAb(_ModuleBase):
                                          _hip.ptr(rm), B, K, V, _hip.ptr(out), _hip.stream_ptr()), "diffab_losses_fwd")
         return out[0], out[1], out[2]
 
+    def hotpath_train_losses(self, noised, res_context_emb, pair_context_emb, beta, orientations_t0, generation_mask, residue_mask):
+        """Differentiable (seq, translation, orientation) losses of a noised batch: denoise + losses in one taped HIP forward,
+        gradients for the denoiser parameters and both contexts in one HIP backward (reference :843-880 under autograd)."""
+        params = [p for _, p in self.denoiser.named_parameters()]
+        losses, *_ = _HotpathTrainStep.apply(self.denoiser, noised["seq_idx_t"], noised["translations_t"], noised["orientations_t"], beta,
+                                             noised["seq_posterior"], noised["translations_eps"], orientations_t0, generation_mask,
+                                             residue_mask, res_context_emb, pair_context_emb, *params)
+        out_dev = noised["translations_t"].device
+        return losses[0].to(out_dev), losses[1].to(out_dev), losses[2].to(out_dev)
+
     def _shared_step(self, batch, batch_idx):
         """t ~ U[1,T]; noise; denoise; three losses (diffab_pytorch.py:808-880).  Context embeddings are taken from
         batch['res_context_emb'] / batch['pair_context_emb'] until encode_context lands on this path."""
@@ -310,14 +375,22 @@ class DiffAb(_ModuleBase):
             res_ctx, pair_ctx = self.encode_context(batch["seq_idx"], xyz_t0, batch["orientations"], batch["backbone_dihedrals"],
                                                     batch["distmat"], batch["pairwise_dihedrals"], batch["atom_mask"], batch["chain_idx"],
                                                     batch["residue_idx"], batch["generation_mask"], batch["residue_mask"])
+        if torch.is_grad_enabled():
+            return self.hotpath_train_losses(noised, res_ctx, pair_ctx, beta, batch["orientations"], batch["generation_mask"],
+                                             batch["residue_mask"])
         denoised = self.denoise(noised["seq_idx_t"], noised["translations_t"], noised["orientations_t"], res_ctx, pair_ctx, beta,
                                 batch["generation_mask"], batch["residue_mask"])
         return self.hotpath_losses(denoised, noised, batch["orientations"], batch["generation_mask"], batch["residue_mask"])
 
     def training_step(self, batch, batch_idx):
-        raise NotImplementedError("the backward kernels of the denoise step are not built yet (DESIGN.md, 'what comes next'); "
-                                  "validation_step / sample run on HIP today")
+        seq_loss, translations_loss, orientations_loss = self._shared_step(batch, batch_idx)
+        loss = seq_loss + translations_loss + orientations_loss
+        self.log_dict({"train/seq_loss": seq_loss, "train/translations_loss": translations_loss,
+                       "train/orientations_loss": orientations_loss, "train/loss": loss}, on_step=True, on_epoch=True, prog_bar=True,
+                      logger=True)
+        return loss
 
+    @torch.no_grad()
     def validation_step(self, batch, batch_idx):
         seq_loss, translations_loss, orientations_loss = self._shared_step(batch, batch_idx)
         loss = seq_loss + translations_loss + orientations_loss

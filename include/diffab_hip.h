@@ -189,6 +189,27 @@ int diffab_losses_fwd(const float* pred_post, const float* true_post, const floa
                       const float* pred_O0, const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask,
                       int32_t B, int32_t K, int32_t V, float* losses3, void* stream);
 
+/* ---- training step of the hot path (diffab_pytorch.py:808-880 minus encode_context; BASELINE config 4) -------------------
+ * fwd: Denoiser.forward with every intermediate saved in `tape` (size: diffab_train_tape_bytes) + the three masked losses.
+ * bwd: gradients of  upstream3 . (seq KL, translation MSE, orientation loss)  w.r.t. every denoiser parameter, the residue
+ *      context and (optionally) the pair context.  `grads` is the weights struct again, pointing at ZERO-INITIALISED buffers
+ *      of the parameters' shapes; they, and d_pair_ctx (NULL to skip, else zero-initialised (B,K,K,C)), are accumulated into
+ *      (float atomics: sums over residues are order-dependent in the last bits).  d_res_ctx (B,K,D) may be NULL.
+ *      upstream3 is a DEVICE pointer to 3 floats (autograd's incoming gradient; no host sync). */
+size_t diffab_train_tape_bytes(const diffab_dims* d);
+size_t diffab_train_workspace_bytes(const diffab_dims* d);
+int diffab_train_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
+                          const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, const float* true_post,
+                          const float* true_eps, const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask,
+                          float* out_eps, float* out_O0, float* out_posterior, float* losses3, void* tape, size_t tape_bytes,
+                          uint32_t flags, void* stream);
+int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
+                          const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_eps,
+                          const float* out_O0, const float* out_posterior, const float* true_post, const float* true_eps,
+                          const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, const float* upstream3,
+                          float* d_res_ctx, float* d_pair_ctx, const void* tape, size_t tape_bytes, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* diffab_pytorch.py:610-625  OrientationLoss: elems (n,3,3) = (pred^T target - I)^2 and/or their total (either may be NULL) */
 int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream);
 

@@ -71,3 +71,46 @@ def test_gather_world2_gloo(n):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(shape[0] == n for _, _, shape in res)
+
+
+def _grad_worker(rank, world, port, q):
+    from diffab_pytorch.distributed import allreduce_gradients
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+        ps[2].grad = None  # parameters without a gradient are skipped
+        g = torch.Generator().manual_seed(100 + rank)
+        for p in ps[:2]:
+            p.grad = torch.randn(p.shape, generator=g)
+        allreduce_gradients(ps, dist)
+        want = []
+        for i, p in enumerate(ps[:2]):
+            acc = torch.zeros_like(p)
+            for r in range(world):
+                gr = torch.Generator().manual_seed(100 + r)
+                vals = [torch.randn(q_.shape, generator=gr) for q_ in ps[:2]]
+                acc += vals[i]
+            want.append(acc / world)
+        ok = all(torch.allclose(p.grad, w_, atol=1e-6) for p, w_ in zip(ps[:2], want)) and ps[2].grad is None
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -490,7 +490,7 @@ def test_shared_step_and_add_noise(hip):
     l2 = [float(x) for x in model._shared_step(batch, 0)]
     assert l1 == l2 and all(np.isfinite(l1)) and all(v >= 0 for v in l1)
     loss = model.validation_step(batch, 0)
-    assert torch.isfinite(loss)
+    assert torch.isfinite(loss) and not loss.requires_grad
     with pytest.raises(NotImplementedError):
         model.encode_context(*[None] * 11)
 
@@ -541,3 +541,92 @@ def test_full_size_properties_b256(hip):
     # IPA is invariant to a global rigid motion of the patch frame (translation): eps-hat changes only by fp32 noise
     shifted = den(seq[sl], x[sl] + torch.tensor([30.0, -20.0, 10.0], device="cuda"), O[sl], rc[sl], pc[sl], beta[sl], None, None)
     assert maxrel(shifted["translations_eps"], sub["translations_eps"]) < 1e-3
+
+
+# ------------------------------------------------------------------ training step: gradients vs the reference's autograd
+def test_hotpath_gradients_vs_reference_goldens(hip, golden):
+    """Loss values and gradients of the hot-path training step (noised state -> denoise -> 3 losses, contexts as leaf inputs)
+    against autograd of the REAL reference (tests/golden/losses_grads.npz, generated by oracle/gen_golden.py)."""
+    from diffab_pytorch import DiffAb
+
+    g = golden("losses_grads")
+    B, K, seed = [int(v) for v in g["meta"][:3]]
+    dims = dict(zip(("D", "C", "NL", "DS", "H", "PQ", "PV"), [int(v) for v in g["meta"][3:]]), V=21)
+    model = DiffAb(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"]).cuda()
+    model.denoiser.load_state_dict(syn.denoiser_state_dict(dims, seed=seed, prefix=""))
+    inp = syn.patches(B, K, dims, seed=seed, coord_sigma=4.0)
+    res_ctx = inp["res_context_emb"].cuda().requires_grad_(True)
+    pair_ctx = inp["pair_context_emb"].cuda().requires_grad_(True)
+    noised = {"seq_idx_t": T(g["seq_t"]).cuda(), "translations_t": T(g["x_t"]).cuda(), "orientations_t": T(g["O_t"]).cuda(),
+              "seq_posterior": T(g["post"]).cuda(), "translations_eps": T(g["eps"]).cuda()}
+    ls = model.hotpath_train_losses(noised, res_ctx, pair_ctx, T(g["beta"]).cuda(), inp["orientations"].cuda(), T(g["gen"]).cuda(),
+                                    T(g["resm"]).cuda())
+    np.testing.assert_allclose([float(x) for x in ls], g["losses"], rtol=5e-5)
+    (ls[0] + ls[1] + ls[2]).backward()
+    assert maxrel(res_ctx.grad, g["grad_res_ctx"]) < 2e-4, maxrel(res_ctx.grad, g["grad_res_ctx"])
+    assert maxrel(pair_ctx.grad, g["grad_pair_ctx"]) < 2e-4, maxrel(pair_ctx.grad, g["grad_pair_ctx"])
+    worst = ("", 0.0)
+    for n, p in model.denoiser.named_parameters():
+        want = g["grad/" + n]
+        assert p.grad is not None and p.grad.shape == want.shape, n
+        r = maxrel(p.grad, want)
+        worst = max(worst, (n, r), key=lambda t_: t_[1])
+        assert r < 2e-4, (n, r)
+    print("worst parameter-gradient max-rel:", worst)
+    # a second backward of the same batch accumulates like autograd does
+    ls2 = model.hotpath_train_losses(noised, res_ctx, pair_ctx, T(g["beta"]).cuda(), inp["orientations"].cuda(), T(g["gen"]).cuda(),
+                                     T(g["resm"]).cuda())
+    (2.0 * ls2[1]).backward()
+    assert torch.isfinite(model.denoiser.to_res_emb[0].weight.grad).all()
+
+
+def test_training_step_runs_and_learns(hip):
+    """DiffAb.training_step + Adam (configure_optimizers, reference :925-931) on a fixed synthetic batch: loss decreases."""
+    dims, model, _ = _unit_model()
+    B, K = 4, 16
+    inp = syn.patches(B, K, dims, seed=3, coord_sigma=5.0)
+    batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
+             "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),
+             "res_context_emb": inp["res_context_emb"].cuda(), "pair_context_emb": inp["pair_context_emb"].cuda()}
+    model.lr = 1e-3
+    opt = model.configure_optimizers()
+    first = last = None
+    for it in range(12):
+        torch.manual_seed(42)  # same t and noise every iteration: a fixed objective
+        opt.zero_grad()
+        loss = model.training_step(batch, it)
+        assert loss.requires_grad and torch.isfinite(loss)
+        loss.backward()
+        opt.step()
+        first = float(loss) if first is None else first
+        last = float(loss)
+    assert last < first, (first, last)
+    # the fast (MFMA) forward feeds the same backward at the benchmark geometry
+    from diffab_pytorch import DiffAb
+
+    bd = dict(syn.BENCH_DIMS, NL=2)
+    big = DiffAb(bd["D"], bd["C"], bd["NL"], bd["DS"], bd["PQ"], bd["PV"], bd["H"]).cuda()
+    sd = syn.denoiser_state_dict(bd, seed=4, prefix="")
+    big.denoiser.load_state_dict(sd)
+    bi = syn.patches(1, 128, bd, seed=4, coord_sigma=6.0)
+    rc = bi["res_context_emb"].cuda().requires_grad_(True)
+    t = torch.tensor([40])
+    torch.manual_seed(0)
+    nz = big._add_noise(bi["seq_idx"].cuda(), bi["translations"].cuda(), bi["orientations"].cuda(), bi["generation_mask"].cuda(), t.cuda())
+    ls = big.hotpath_train_losses(nz, rc, bi["pair_context_emb"].cuda(), big.sched["beta"][t].cuda(), bi["orientations"].cuda(),
+                                  bi["generation_mask"].cuda(), bi["residue_mask"].cuda())
+    sum(ls).backward()
+    # oracle autograd on the same noised state
+    rco = bi["res_context_emb"].clone().requires_grad_(True)
+    sdo = {"denoiser." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    den = orc.denoiser(sdo, nz["seq_idx_t"].cpu(), nz["translations_t"].cpu(), nz["orientations_t"].cpu(), rco, bi["pair_context_emb"],
+                       big.sched["beta"][t], bd["NL"], bd["H"])
+    lo = orc.hotpath_losses(den, nz["seq_posterior"].cpu(), nz["translations_eps"].cpu(), bi["orientations"], bi["generation_mask"],
+                            bi["residue_mask"])
+    sum(lo).backward()
+    np.testing.assert_allclose([float(x) for x in ls], [float(x) for x in lo], rtol=1e-4)
+    assert maxrel(rc.grad, rco.grad) < 5e-4, maxrel(rc.grad, rco.grad)
+    for n in ("ipa.layers.0.to_q_scalar.weight", "ipa.layers.1.gamma", "ipa.layers.0.to_pair_bias.weight", "to_res_emb.0.weight",
+              "sequence_denoising.4.weight", "ipa.layers.1.to_out.weight", "ipa.layers.0.to_k_point.weight"):
+        got = dict(big.denoiser.named_parameters())[n].grad
+        assert maxrel(got, sdo["denoiser." + n].grad) < 5e-4, (n, maxrel(got, sdo["denoiser." + n].grad))
