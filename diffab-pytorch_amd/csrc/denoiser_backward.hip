@@ -256,15 +256,21 @@ __global__ void losses_bwd_kernel(const float* __restrict__ post, const float* _
   for (int k = 0; k < 3; ++k) d_v[i * 3 + k] = hk[k] + (da * gS + db * gS2) * vv[k] / n;
 }
 
-// ------------------------------------------------------------------ attention backward, one work-group per (patch, query residue)
+// ------------------------------------------------------------------ attention backward in two atomic-free passes
+// Pass 1, one work-group per (patch, query residue i): recompute the row's softmax from the saved projections, form dA and
+// the logit gradient, write this row's own gradients (q_s, q points, de[i], and dog = d o_g) directly, and store the
+// probabilities A and g = scale_t * dlogit TRANSPOSED ([b][h][j][i]) for pass 2.  dWb / dgamma are per-row partial sums added
+// with one atomic each (H*C + H per row).
+// Pass 2, one work-group per (patch, key residue j): reduce over the query rows for k_s, k points, v_s, v points.
 // proj / dproj rows: [q_s | k_s | v_s | gq | gk | gv] (points in the global frame; dproj holds gradients w.r.t. the GLOBAL points,
-// points_bwd_kernel turns them into local-point gradients afterwards).  dproj must be zeroed before the launch.
-__global__ __launch_bounds__(256) void ipa_attn_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ e,
-                                                           const float* __restrict__ R, const float* __restrict__ t,
-                                                           const float* __restrict__ Wb, const float* __restrict__ gamma,
-                                                           const float* __restrict__ feat, const float* __restrict__ dfeat,
-                                                           float* __restrict__ dproj, float* __restrict__ de, float* __restrict__ dWb,
-                                                           float* __restrict__ dgamma, int K, int C, int H, int DS, int PQ, int PV) {
+// points_bwd_kernel turns them into local-point gradients afterwards).
+__global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __restrict__ proj, const float* __restrict__ e,
+                                                                const float* __restrict__ R, const float* __restrict__ Wb,
+                                                                const float* __restrict__ gamma, const float* __restrict__ feat,
+                                                                const float* __restrict__ dfeat, float* __restrict__ dproj,
+                                                                float* __restrict__ de, float* __restrict__ dWb, float* __restrict__ dgamma,
+                                                                float* __restrict__ At, float* __restrict__ Gt, float* __restrict__ dogbuf,
+                                                                int K, int C, int H, int DS, int PQ, int PV) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x / K, i = blockIdx.x % K;
   const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
@@ -296,7 +302,11 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_kernel(const float* __restri
       dl[c] = dfrow[n_os + n_oe + hp * 3 + c] + (on > 0.0f ? don * ol / on : 0.0f);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dog[hp * 3 + k] = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
+    for (int k = 0; k < 3; ++k) {
+      const float v = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
+      dog[hp * 3 + k] = v;
+      dogbuf[row_i * n_og + hp * 3 + k] = v;
+    }
   }
   __syncthreads();
   const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
@@ -333,24 +343,14 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_kernel(const float* __restri
     for (int j = lane; j < K; j += 64) attn[h * K + j] *= inv;
   }
   __syncthreads();
-  // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]; and the value-side gradients A * do_*
+  // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]
   for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
     const int h = idx / K, j = idx % K;
-    const float A = attn[idx];
     const float* vrow = proj + (static_cast<int64_t>(b) * K + j) * NP;
-    float* dvrow = dproj + (static_cast<int64_t>(b) * K + j) * NP;
     float s = 0.f;
-    for (int d = 0; d < DS; ++d) {
-      const float g = dfrow[h * DS + d];
-      s += g * vrow[off_vs + h * DS + d];
-      atomicAdd(dvrow + off_vs + h * DS + d, A * g);
-    }
+    for (int d = 0; d < DS; ++d) s += dfrow[h * DS + d] * vrow[off_vs + h * DS + d];
     for (int c = 0; c < C; ++c) s += dfrow[n_os + h * C + c] * erow[static_cast<int64_t>(j) * C + c];
-    for (int p = 0; p < PV * 3; ++p) {
-      const float g = dog[h * PV * 3 + p];
-      s += g * vrow[off_gv + h * PV * 3 + p];
-      atomicAdd(dvrow + off_gv + h * PV * 3 + p, A * g);
-    }
+    for (int p = 0; p < PV * 3; ++p) s += dog[h * PV * 3 + p] * vrow[off_gv + h * PV * 3 + p];
     gl[idx] = s;
   }
   __syncthreads();
@@ -363,43 +363,34 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_kernel(const float* __restri
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
-    const int h = idx / K;
-    gl[idx] = scale_t * attn[idx] * (gl[idx] - red[h]);
+    const int h = idx / K, j = idx % K;
+    const float g = scale_t * attn[idx] * (gl[idx] - red[h]);
+    gl[idx] = g;
+    const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + j) * K + i;  // transposed: [b][h][j][i]
+    At[o] = attn[idx];
+    Gt[o] = g;
   }
   __syncthreads();
-  // ---- key-side gradients (atomics over query rows) and gamma
-  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
-    const int h = idx / K, j = idx % K;
-    const float g = gl[idx];
-    const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
-    float* dkrow = dproj + (static_cast<int64_t>(b) * K + j) * NP;
-    for (int d = 0; d < DS; ++d) atomicAdd(dkrow + off_ks + h * DS + d, g * scale_s * qrow[h * DS + d]);
-    const float cp = 2.0f * scale_p * gamma[h] * g;
-    for (int p = 0; p < PQ * 3; ++p) {
-      const float dd = qrow[H * DS + h * PQ * 3 + p] - krow[off_gk + h * PQ * 3 + p];
-      atomicAdd(dkrow + off_gk + h * PQ * 3 + p, -cp * dd);
-    }
-  }
-  for (int h = wave; h < H; h += nwave) {
+  for (int h = wave; h < H; h += nwave) {  // dgamma_h += sum_j g scale_p d2
     float s = 0.f;
     for (int j = lane; j < K; j += 64) s += gl[h * K + j] * scale_p * d2[h * K + j];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) atomicAdd(dgamma + h, s);
   }
-  // ---- query-side gradients (this row only: plain stores)
+  // ---- query-side gradients (this row only)
   float* dqrow = dproj + row_i * NP;
   for (int o = threadIdx.x; o < H * DS + H * PQ * 3; o += blockDim.x) {
     float acc = 0.f;
     if (o < H * DS) {
       const int h = o / DS;
       for (int j = 0; j < K; ++j) acc += gl[h * K + j] * proj[(static_cast<int64_t>(b) * K + j) * NP + off_ks + o];
-      atomicAdd(dqrow + o, acc * scale_s);  // this row's k/v/g_k/g_v slots receive atomics from other rows; q slots only from here
+      dqrow[o] = acc * scale_s;
     } else {
       const int oo = o - H * DS, h = oo / (PQ * 3);
       const float cp = 2.0f * scale_p * gamma[h];
       for (int j = 0; j < K; ++j)
         acc += gl[h * K + j] * (qrow[H * DS + oo] - proj[(static_cast<int64_t>(b) * K + j) * NP + off_gk + oo]);
-      atomicAdd(dqrow + off_gq + oo, cp * acc);
+      dqrow[off_gq + oo] = cp * acc;
     }
   }
   // ---- pair embedding: de[i][j][c] += sum_h (A do_e[h][c] + g Wb[h][c]);   dWb[h][c] += sum_j g e[i][j][c]
@@ -416,6 +407,55 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_kernel(const float* __restri
     float s = 0.f;
     for (int j = 0; j < K; ++j) s += gl[h * K + j] * erow[static_cast<int64_t>(j) * C + c];
     atomicAdd(dWb + o, s);
+  }
+}
+
+// Pass 2: key-side gradients of residue j = sums over the query rows i, read contiguously from the transposed A / g images.
+__global__ __launch_bounds__(256) void ipa_attn_bwd_keys_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
+                                                                const float* __restrict__ dfeat, const float* __restrict__ At,
+                                                                const float* __restrict__ Gt, const float* __restrict__ dogbuf,
+                                                                float* __restrict__ dproj, int K, int C, int H, int DS, int PQ, int PV) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x / K, j = blockIdx.x % K;
+  const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
+  const int F = H * DS + H * C + H * PV * 3 + H * PV;
+  const int off_ks = H * DS, off_vs = 2 * H * DS, off_gq = 3 * H * DS, off_gk = off_gq + H * PQ * 3, off_gv = off_gk + H * PQ * 3;
+  const int n_og = H * PV * 3;
+  float* a = smem;        // H*K  A[h][i] for this key
+  float* g = a + H * K;   // H*K  g[h][i]
+  const int64_t base = static_cast<int64_t>(b) * H * K * K + static_cast<int64_t>(j) * K;
+  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+    const int h = idx / K, i = idx % K;
+    a[idx] = At[base + static_cast<int64_t>(h) * K * K + i];
+    g[idx] = Gt[base + static_cast<int64_t>(h) * K * K + i];
+  }
+  __syncthreads();
+  const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
+  const float scale_p = -0.5f / sqrtf(4.5f * PQ);
+  const int64_t row_j = static_cast<int64_t>(b) * K + j;
+  const float* prow_j = proj + row_j * NP;
+  float* drow = dproj + row_j * NP;
+  const int n_ks = H * DS, n_gk = H * PQ * 3, n_vs = H * DS, n_gv = H * PV * 3;
+  for (int o = threadIdx.x; o < n_ks + n_gk + n_vs + n_gv; o += blockDim.x) {
+    float acc = 0.f;
+    if (o < n_ks) {  // dk_s[j][h][d] = scale_s sum_i g q_s[i][h][d]
+      const int h = o / DS;
+      for (int i = 0; i < K; ++i) acc += g[h * K + i] * proj[(static_cast<int64_t>(b) * K + i) * NP + o];
+      drow[off_ks + o] = acc * scale_s;
+    } else if (o < n_ks + n_gk) {  // dgk = -2 scale_p gamma sum_i g (gq[i] - gk[j])
+      const int oo = o - n_ks, h = oo / (PQ * 3);
+      const float kj = prow_j[off_gk + oo];
+      for (int i = 0; i < K; ++i) acc += g[h * K + i] * (proj[(static_cast<int64_t>(b) * K + i) * NP + off_gq + oo] - kj);
+      drow[off_gk + oo] = -2.0f * scale_p * gamma[h] * acc;
+    } else if (o < n_ks + n_gk + n_vs) {  // dv_s[j][h][d] = sum_i A do_s[i][h][d]
+      const int oo = o - n_ks - n_gk, h = oo / DS;
+      for (int i = 0; i < K; ++i) acc += a[h * K + i] * dfeat[(static_cast<int64_t>(b) * K + i) * F + oo];
+      drow[off_vs + oo] = acc;
+    } else {  // dgv[j][h][p][k] = sum_i A dog[i][h][p][k]
+      const int oo = o - n_ks - n_gk - n_vs, h = oo / (PV * 3);
+      for (int i = 0; i < K; ++i) acc += a[h * K + i] * dogbuf[(static_cast<int64_t>(b) * K + i) * n_og + oo];
+      drow[off_gv + oo] = acc;
+    }
   }
 }
 
@@ -478,7 +518,9 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
   const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
-  return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64;
+  const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
+  return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64 + 2 * HKK +
+         rows * d->H * d->PV * 3;
 }
 
 int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
@@ -503,6 +545,10 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
   float* dfeat = take(static_cast<size_t>(rows) * F);
   float* dproj = take(static_cast<size_t>(rows) * NP);
   float* dcat2 = take(static_cast<size_t>(rows) * 2 * D);
+  const size_t HKK = static_cast<size_t>(d->B) * H * d->K * d->K;
+  float* At = take(HKK);
+  float* Gt = take(HKK);
+  float* dogbuf = take(static_cast<size_t>(rows) * H * PV * 3);
 
   hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
   DIFFAB_LAUNCH_CHECK();
@@ -539,14 +585,18 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     // to_out
     if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows, D, F,
                             false, st)) return rc;
-    DIFFAB_HIP_CHECK(hipMemsetAsync(dproj, 0, sizeof(float) * static_cast<size_t>(rows) * NP, st));
     const size_t lds = (3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H) * sizeof(float);
     DIFFAB_REQUIRE(lds <= 160 * 1024, DIFFAB_ERR_UNSUPPORTED, "attention backward: H*K too large for LDS (%zu bytes)", lds);
     if (lds > 64 * 1024)
-      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds)));
-    hipLaunchKernelGGL(ipa_attn_bwd_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, x_t, lw->w_bias, lw->gamma, feat, dfeat,
-                       dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), d->K, C, H, DS, PQ, PV);
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(ipa_attn_bwd_rows_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, lw->w_bias, lw->gamma, feat, dfeat,
+                       dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), At, Gt, dogbuf, d->K, C, H, DS, PQ,
+                       PV);
+    DIFFAB_LAUNCH_CHECK();
+    const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
+    hipLaunchKernelGGL(ipa_attn_bwd_keys_kernel, dim3(rows), dim3(256), lds2, st, proj, lw->gamma, dfeat, At, Gt, dogbuf, dproj, d->K, C, H,
+                       DS, PQ, PV);
     DIFFAB_LAUNCH_CHECK();
     // global-point gradients -> local-point gradients (three point blocks)
     const int cols[3] = {3 * H * DS, 3 * H * DS + H * PQ * 3, 3 * H * DS + 2 * H * PQ * 3};
