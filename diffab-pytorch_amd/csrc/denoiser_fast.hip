@@ -184,15 +184,25 @@ constexpr int TI = 16;  // query residues per work-group
 // sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
 #define MEM_FENCE() asm volatile("" ::: "memory")
 
-template <int NT>  // NT = K / 16 key tiles; compile-time so every per-lane array is register-allocated (static indices only)
+// NT: key tiles (16 keys each) per chunk: 8 when K % 128 == 0, else 4; compile-time so per-lane arrays stay in VGPRs.
+// MULTI: more than one chunk.  The single-chunk instantiation (K = 64, 128) has NC == 1 at compile time: the chunk loop and every
+// rescale branch fold away and it is the same straight-line kernel as before the chunk loop existed (the loop costs 13 % at K=128).
+template <int NT, bool MULTI>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
-                                                            float* __restrict__ feat, int B,
+                                                            float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps) {
-  extern __shared__ __attribute__((aligned(16))) float S[];  // [TI][AH][K+8] (+8 per i): logits, then probabilities
-  constexpr int K = NT * 16;
+  const int NC = MULTI ? NC_arg : 1;
+  // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
+  // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
+  // are rescaled by exp(M_old - M_new) through the feature rows in global memory.  K = 64 and 128 are the single-chunk case;
+  // K = 192, 256, ... reuse the same 16-row structure instead of needing a K-proportional LDS image.
+  extern __shared__ __attribute__((aligned(16))) float S[];  // [TI][AH][KC+8] (+8 per i)
+  constexpr int KC = NT * 16;
   constexpr int NS = NT * 4;  // (jt, r) key steps of 4 keys each
+  const int K = NC * KC;
+  const int ntile = K / TI;
   // diagnostic s_memtime stamps (stamps == nullptr in every production launch: nothing below executes)
   auto stamp = [&](int k) {
     if (stamps != nullptr) {
@@ -202,29 +212,20 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // Waves 4-7 share SIMDs with waves 0-3 and run the same program: delayed by part of an iteration, one partner's LDS /
-  // addresser stage overlaps the other's VALU / MFMA stage instead of both queueing on the same unit (measured).
-  auto stagger = [&]() {
-#ifdef DIFFAB_STAGGER
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_sleep(DIFFAB_STAGGER);
-#endif
-  };
   stamp(0);
-  stagger();
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
   if ((B & 7) == 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    b = (slot / NT) * 8 + xcd;
-    tile = slot % NT;
+    b = (slot / ntile) * 8 + xcd;
+    tile = slot % ntile;
   } else {
-    b = blockIdx.x / NT;
-    tile = blockIdx.x % NT;
+    b = blockIdx.x / ntile;
+    tile = blockIdx.x % ntile;
   }
   const int i0 = tile * TI;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int l15 = lane & 15, q = lane >> 4;
-  constexpr int HS = K + 8, IS = AH * (K + 8) + 8;
+  const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
+  constexpr int HS = KC + 8, IS = AH * (KC + 8) + 8;  // == 8 (mod 64): both ds_read_b128 patterns on the image are conflict-free
   const int64_t prow0 = static_cast<int64_t>(b) * K;  // first projection row of this patch
   const float scale_t = 0.57735026918962576f;         // 3^-1/2   (diffab_pytorch.py:387, :439)
 
@@ -233,307 +234,340 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   // loads (adjacent lanes on different rows) cost four lines per quad and made this kernel addresser-bound (4x the issue
   // time, measured).  Data is re-oriented into fragments through this scratch; a wave reads only what it wrote, and LDS
   // operations of one wave complete in order, so no barrier is involved.
-  constexpr int KLD = 40, GLD = 28;                       // key-tile strides (floats): ds_read_b128 conflict-free
-  constexpr int P1_TILE = 16 * KLD + 16 * GLD;            // 1088 floats per staged key tile
-  constexpr int ELD = 72;                                 // pair-tile stride (floats)
-  constexpr int SCR_FLOATS = 2 * 16 * ELD;                // 2304 floats per wave (>= 2 * P1_TILE = 2176)
+  constexpr int KLD = 40, GLD = 28;             // key-tile strides (floats): ds_read_b128 conflict-free
+  constexpr int P1_TILE = 16 * KLD + 16 * GLD;  // 1088 floats per staged key tile
+  constexpr int ELD = 72;                       // pair-tile stride (floats)
+  constexpr int SCR_FLOATS = 2 * 16 * ELD;      // 2304 floats per wave (>= 2 * P1_TILE = 2176)
+#ifndef DIFFAB_E_EARLY
+#define DIFFAB_E_EARLY 1
+#endif
+#ifndef DIFFAB_E_LAG
+#define DIFFAB_E_LAG 2
+#endif
+  constexpr int E_LAG = MULTI ? DIFFAB_E_LAG : 0;    // the next row's tile loads trail the retiring tiles by this many (VGPRs)
+  constexpr int E_EARLY = MULTI ? DIFFAB_E_EARLY : 2;       // pair tiles of phase 2's first row started under the tail of phase 1
   float* scr = S + TI * IS + wv * SCR_FLOATS;
+  float* st_fac = S + TI * IS + 8 * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
+  float* st_inv = st_fac + TI * AH;              // [TI][AH] 1 / L after the last chunk (1 before)
+  float* wb_lds = st_inv + TI * AH;              // [4 sg][64 lanes][4]: B fragments of the bias product (same for every wave)
+  if (wv == 0) {  // Wb[h][16 sg + 4 q + s] for lane (h = l15 < 8, q), zero in the padding columns; first read is behind a barrier
+    const int l15_ = lane0 & 15, q_ = lane0 >> 4;
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(Wb + (l15_ & 7) * AC + 16 * sg + 4 * q_);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) v[s_] = l15_ < 8 ? v[s_] : 0.0f;
+      *reinterpret_cast<f32x4*>(wb_lds + (sg * 64 + lane0) * 4) = v;
+    }
+  }
 
   // e[b, i0 + 2 wv + ii, :, :]: the two pair-embedding rows this wave owns in phase 2.  Streamed once (non-temporal: it
   // must not evict the K/V-side operands, re-read by the other row tiles of the patch, from L2), in the orientation of
   // the o_e product: lane (l15, q) holds e[i][j = 16 jt + 4 q + r][c = 4 l15 .. 4 l15 + 3] - 1 KiB contiguous per load.
+  // A chunk of a row (16 NT VGPRs) stays in registers from the bias product to the o_e product.
   const float* erow[2];
   erow[0] = e + ((prow0 + i0 + 2 * wv) * K) * AC;
-  erow[1] = erow[0] + K * AC;
-  constexpr bool RESIDENT = NT <= 8;   // a whole e row (16 NT VGPRs) stays in registers from the bias to the o_e product
-  constexpr int PFE = RESIDENT ? NT : 3;  // non-resident: rolling window, PFE key tiles of lookahead, second pass via L2
-  f32x4 ev[2][NT][4];
-  auto load_e_tile = [&](int ii, int jt) {
-    const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii] + (jt * 16 + 4 * q) * AC + 4 * l15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
-  };
+  erow[1] = erow[0] + static_cast<int64_t>(K) * AC;
+  float Mrun[2] = {-INFINITY, -INFINITY}, Lrun[2] = {0.f, 0.f};  // online-softmax state of (row 2 wv + ii, head l15 & 7)
 
-  // ---------------------------------------------------------------- phase 1: wave = head
-  {
-    const int h = wv;
-    const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
-    const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
-    // line-shaped loads of one key tile (16 keys): k_s 16 x 128 B (8 lanes per key), gk 16 x 96 B (6 lanes per key)
-    const float* ks_src = proj + (prow0 + (lane >> 3)) * ANP + OFF_KS + h * ADS + 4 * (lane & 7);  // + 8 t keys, + 16 jt keys
-    const int g0 = lane, g1 = lane + 64;  // gk chunk ids (0..95): key = id / 6, chunk = id % 6
-    const float* gk_src0 = proj + (prow0 + g0 / 6) * ANP + OFF_GK + h * 24 + 4 * (g0 % 6);
-    const float* gk_src1 = proj + (prow0 + g1 / 6) * ANP + OFF_GK + h * 24 + 4 * (g1 % 6);
-    const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
-    const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
-    constexpr int SD = 4;  // register staging depth: SD - 1 key tiles of lookahead (loaded L2 latency is ~2.5k cycles here)
-    f32x4 st[SD][4];
-    auto load_keys = [&](int sb, int jt) {
-#ifdef DIFFAB_ABLATE_P1_LOADS
-      return;
-#endif
-      const int64_t o = static_cast<int64_t>(jt) * 16 * ANP;
-      st[sb][0] = *reinterpret_cast<const f32x4*>(ks_src + o);
-      st[sb][1] = *reinterpret_cast<const f32x4*>(ks_src + o + 8 * ANP);
-      st[sb][2] = *reinterpret_cast<const f32x4*>(gk_src0 + o);
-      if (g1 < 96) st[sb][3] = *reinterpret_cast<const f32x4*>(gk_src1 + o);
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    const bool last = c == NC - 1;
+    const int64_t krow0 = prow0 + c * KC;  // first key row of this chunk
+    // Re-derive the lane coordinates from an opaque copy each iteration: otherwise every lane-constant address of the three
+    // phases is hoisted out of this loop and stays live through phase 2, which spills (hipcc, ROCm 7.2).
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int l15 = lane & 15, q = lane >> 4;
+    f32x4 ev[2][NT][4];
+    auto load_e_tile = [&](int ii, int cc_, int jt) {
+      const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii] + (cc_ * KC + jt * 16 + 4 * q) * AC + 4 * l15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
     };
-    auto stage_keys = [&](int sb, int lb) {
-#ifdef DIFFAB_ABLATE_P1_LOADS
-      return;
-#endif
-      float* t_ = scr + lb * P1_TILE;
-      *reinterpret_cast<f32x4*>(t_ + ks_dst) = st[sb][0];
-      *reinterpret_cast<f32x4*>(t_ + ks_dst + 8 * KLD) = st[sb][1];
-      *reinterpret_cast<f32x4*>(t_ + gk_dst0) = st[sb][2];
-      if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
-    };
+    // ---------------------------------------------------------------- phase 1: wave = head
+    {
+      const int h = wv;
+      const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
+      const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
+      // line-shaped loads of one key tile (16 keys): k_s 16 x 128 B (8 lanes per key), gk 16 x 96 B (6 lanes per key)
+      const float* ks_src = proj + (krow0 + (lane >> 3)) * ANP + OFF_KS + h * ADS + 4 * (lane & 7);  // + 8 t keys, + 16 jt keys
+      const int g0 = lane, g1 = lane + 64;  // gk chunk ids (0..95): key = id / 6, chunk = id % 6
+      const float* gk_src0 = proj + (krow0 + g0 / 6) * ANP + OFF_GK + h * 24 + 4 * (g0 % 6);
+      const float* gk_src1 = proj + (krow0 + g1 / 6) * ANP + OFF_GK + h * 24 + 4 * (g1 % 6);
+      const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
+      const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
+      constexpr int SD = MULTI ? 3 : 4;  // register staging depth: SD - 1 key tiles of lookahead
+      f32x4 st[SD][4];
+      auto load_keys = [&](int sb, int jt) {
+        const int64_t o = static_cast<int64_t>(jt) * 16 * ANP;
+        st[sb][0] = *reinterpret_cast<const f32x4*>(ks_src + o);
+        st[sb][1] = *reinterpret_cast<const f32x4*>(ks_src + o + 8 * ANP);
+        st[sb][2] = *reinterpret_cast<const f32x4*>(gk_src0 + o);
+        if (g1 < 96) st[sb][3] = *reinterpret_cast<const f32x4*>(gk_src1 + o);
+      };
+      auto stage_keys = [&](int sb, int lb) {
+        float* t_ = scr + lb * P1_TILE;
+        *reinterpret_cast<f32x4*>(t_ + ks_dst) = st[sb][0];
+        *reinterpret_cast<f32x4*>(t_ + ks_dst + 8 * KLD) = st[sb][1];
+        *reinterpret_cast<f32x4*>(t_ + gk_dst0) = st[sb][2];
+        if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
+      };
 #pragma unroll
-    for (int jt = 0; jt < SD - 1 && jt < NT; ++jt) load_keys(jt, jt);
-    // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
-    f32x4 qa[2];
-    const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
-    qa[0] = *reinterpret_cast<const f32x4*>(qrow);
-    qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
-    // query points of the 4 rows this lane accumulates (rows i0 + 4q + r); the 16 lanes of a quarter share each address
-    f32x4 gq[4][6];
+      for (int jt = 0; jt < SD - 1 && jt < NT; ++jt) load_keys(jt, jt);
+      // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
+      f32x4 qa[2];
+      const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
+      qa[0] = *reinterpret_cast<const f32x4*>(qrow);
+      qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
+      // query points of the 4 rows this lane accumulates (rows i0 + 4q + r); the 16 lanes of a quarter share each address
+      f32x4 gq[4][6];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* p = proj + (prow0 + i0 + 4 * q + r) * ANP + OFF_GQ + h * 24;
+      for (int r = 0; r < 4; ++r) {
+        const float* p = proj + (prow0 + i0 + 4 * q + r) * ANP + OFF_GQ + h * 24;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) gq[r][c] = *reinterpret_cast<const f32x4*>(p + 4 * c);
-    }
-    MEM_FENCE();
-    stage_keys(0, 0);
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-      if (jt + 1 < NT) stage_keys((jt + 1) % SD, (jt + 1) & 1);  // tile jt+1: registers -> LDS (loads issued SD-2 tiles ago)
-      if (jt + SD - 1 < NT) {
-        load_keys((jt + SD - 1) % SD, jt + SD - 1);
-      } else if constexpr (RESIDENT) {
-        if (jt + 2 >= NT) load_e_tile(0, jt + 2 - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
+        for (int cc = 0; cc < 6; ++cc) gq[r][cc] = *reinterpret_cast<const f32x4*>(p + 4 * cc);
       }
       MEM_FENCE();
-#ifdef DIFFAB_ABLATE_P1_COMPUTE
-      asm volatile("" ::"v"(st[jt % SD][0][0]), "v"(st[jt % SD][1][0]), "v"(st[jt % SD][2][0]));
-      continue;
-#endif
-      const float* t_ = scr + (jt & 1) * P1_TILE;
-      const f32x4 kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
-      const f32x4 kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
-      f32x4 gk[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) gk[c] = *reinterpret_cast<const f32x4*>(t_ + 16 * KLD + l15 * GLD + 4 * c);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
-      // acc[r] = q_s[i0+4q+r] . k_s[16jt+l15]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float d2 = 0.f;
-#ifndef DIFFAB_ABLATE_P1_VALU
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const float dd = gq[r][c][s] - gk[c][s];
-            d2 += dd * dd;
-          }
-#else
-        d2 = gq[r][0][0] - gk[r][1];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) asm volatile("" ::"v"(gk[c][0]), "v"(gk[c][1]), "v"(gk[c][2]), "v"(gk[c][3]));
-#endif
-        S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
-      }
-    }
-  }
-  stamp(1);
-
-  // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
-  {
-    const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
-    if constexpr (RESIDENT) {
-#pragma unroll
-      for (int jt = 2; jt < NT; ++jt) load_e_tile(0, jt);  // tiles 0, 1 were started under the last two key tiles of phase 1
-    } else {
-#pragma unroll
-      for (int jt = 0; jt < PFE; ++jt) load_e_tile(0, jt);
-    }
-    f32x4 wb[4];  // B operand of the bias product: Wb[h][16 sg + 4 q + s], zero in the padding columns
-#pragma unroll
-    for (int sg = 0; sg < 4; ++sg) {
-      wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
-    }
-    MEM_FENCE();
-    __syncthreads();  // phase-1 logits of all heads are in LDS (and every wave is done with its key-tile scratch)
-    stamp(2);
-    stagger();
-    // tile re-orientation for the bias product: write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
-    auto stage_e = [&](int ii, int jt) {
-      float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[ii][jt][r];
-    };
-
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int il = 2 * wv + ii;  // local row
-      float* Srow = S + il * IS + h * HS;
-      float lg[NT][4];  // logits, then probabilities, of keys j = 16 jt + 4 q + r for head h
-      float mx = -INFINITY;
-      stage_e(ii, 0);
+      stage_keys(0, 0);
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-        if (jt + 1 < NT) stage_e(ii, jt + 1);
-        if constexpr (!RESIDENT) {
-          if (jt + PFE < NT) {
-            load_e_tile(ii, jt + PFE);
-            MEM_FENCE();
-          }
+        if (jt + 1 < NT) stage_keys((jt + 1) % SD, (jt + 1) & 1);  // tile jt+1: registers -> LDS (loads issued SD-2 tiles ago)
+        if (jt + SD - 1 < NT) {
+          load_keys((jt + SD - 1) % SD, jt + SD - 1);
+        } else if (jt + E_EARLY >= NT) {
+          load_e_tile(0, c, jt + E_EARLY - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
         }
-        const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
+        MEM_FENCE();
+        const float* t_ = scr + (jt & 1) * P1_TILE;
+        const f32x4 kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
+        const f32x4 kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
+        f32x4 gk[6];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) gk[cc] = *reinterpret_cast<const f32x4*>(t_ + 16 * KLD + l15 * GLD + 4 * cc);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-          const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wb[sg][s], acc, 0, 0, 0);
-        }
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
+        // acc[r] = q_s[i0+4q+r] . k_s[key 16jt+l15]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = sv[r] + scale_t * acc[r];
-          lg[jt][r] = v;
-          mx = fmaxf(mx, v);
+          float d2 = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const float dd = gq[r][cc][s] - gk[cc][s];
+              d2 += dd * dd;
+            }
+          S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
         }
-      }
-      if constexpr (!RESIDENT) {  // second pass over the row (L2 / Infinity Cache), same rolling window
-#pragma unroll
-        for (int jt = 0; jt < PFE; ++jt) load_e_tile(ii, jt);
-        MEM_FENCE();
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      float sum = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = expf(lg[jt][r] - mx);
-          lg[jt][r] = p;
-          sum += p;
-        }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
-      const float inv = 1.0f / sum;
-      // ---- probabilities: to LDS for phase 3, and straight into the o_e product as its B operand
-      f32x4 oe[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        f32x4 pv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = lg[jt][r] * inv;
-        if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + jt * 16 + 4 * q) = pv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct)  // A: e[i][j = 16 jt + 4 q + r][c = 4 l15 + ct]
-            oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[ii][jt][r][ct], pv[r], oe[ct], 0, 0, 0);
-        if constexpr (RESIDENT) {
-          if (ii == 0) {  // this tile's registers are free: start the next row's copy of it
-            load_e_tile(1, jt);
-            MEM_FENCE();
-          }
-        } else {
-          if (jt + PFE < NT) {
-            load_e_tile(ii, jt + PFE);
-            MEM_FENCE();
-          } else if (ii == 0) {
-            load_e_tile(1, jt + PFE - NT);  // next row's first tiles
-            MEM_FENCE();
-          }
-        }
-      }
-      // D: column h = l15, row m = 4 q + r' <-> c = 4 m + ct = 16 q + 4 r' + ct
-      if (l15 < 8) {
-        float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 16 * q;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(fo + 4 * r) = f32x4{oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
       }
     }
-  }
+    if (c == 0) stamp(1);
 
-  stamp(3);
-  // ---------------------------------------------------------------- phase 3: wave = head
-  {
-    constexpr int PFV = 16;  // value prefetch distance, key steps (16 x 160 MFMA cycles ~ the loaded L2 latency)
-    const int h = wv;
-    const int pp = l15 & 7;
-    const float* vbase = proj + (prow0 + 4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;  // + (16 jt + r) rows; d = 2 l15 + dt
-    const float* gbase = proj + (prow0 + 4 * q) * ANP + OFF_GV + h * 24 + 3 * pp;    // point pp, coords 0..2
-    float2 vs[NS];
-    float gx[NS], gy[NS], gz[NS];
-    auto load_vals = [&](int st) {
-      const int64_t o = static_cast<int64_t>((st >> 2) * 16 + (st & 3)) * ANP;
-      vs[st] = *reinterpret_cast<const float2*>(vbase + o);
-      gx[st] = gbase[o];
-      gy[st] = gbase[o + 1];
-      gz[st] = gbase[o + 2];
-    };
+    // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
+    {
+      const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
 #pragma unroll
-    for (int st = 0; st < PFV; ++st) load_vals(st);
-    MEM_FENCE();
-    __syncthreads();  // probabilities of all rows are in LDS
-    stamp(4);
-    stagger();
-    f32x4 os[2], og[3];
+      for (int jt = E_EARLY; jt < NT; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
+      f32x4 wb[4];  // single-chunk kernel: bias B fragments in registers; multi-chunk: read from LDS per tile (VGPR pressure)
+      if constexpr (!MULTI) {
 #pragma unroll
-    for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sg = 0; sg < 4; ++sg) {
+          wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) og[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 16 jt + 4 q + r]
+          for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
+        }
+      }
+      MEM_FENCE();
+      __syncthreads();  // phase-1 logits of all heads are in LDS (and every wave is done with its key-tile scratch)
+      if (c == 0) stamp(2);
+      // tile re-orientation for the bias product: write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
+      auto stage_e = [&](int ii, int jt) {
+        float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-      const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[ii][jt][r];
+      };
+
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int st = jt * 4 + r;
-        if (st + PFV < NS) {
-          load_vals(st + PFV);
+      for (int ii = 0; ii < 2; ++ii) {
+        const int il = 2 * wv + ii;  // local row
+        float* Srow = S + il * IS + h * HS;
+        float lg[NT][4];  // logits, then exp(logit - M), of keys j = 16 jt + 4 q + r of this chunk for head h
+        float mx = -INFINITY;
+        stage_e(ii, 0);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          if (jt + 1 < NT) stage_e(ii, jt + 1);
+          const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int sg = 0; sg < 4; ++sg) {
+            const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
+            const f32x4 wbf = MULTI ? *reinterpret_cast<const f32x4*>(wb_lds + (sg * 64 + lane) * 4) : wb[sg];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
+          }
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = sv[r] + scale_t * acc[r];
+            lg[jt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float Mnew = fmaxf(Mrun[ii], mx);
+        const float fac = c == 0 ? 0.0f : expf(Mrun[ii] - Mnew);  // rescale of everything accumulated before this chunk
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = expf(lg[jt][r] - Mnew);
+            lg[jt][r] = p;
+            sum += p;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        Mrun[ii] = Mnew;
+        Lrun[ii] = Lrun[ii] * fac + sum;
+        const float inv = last ? 1.0f / Lrun[ii] : 1.0f;
+        // ---- exp(logit - M): to LDS for phase 3, and straight into the o_e product as its B operand
+        f32x4 oe[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          const f32x4 pv = {lg[jt][0], lg[jt][1], lg[jt][2], lg[jt][3]};
+          if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + jt * 16 + 4 * q) = pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)  // A: e[i][j = 16 jt + 4 q + r][c = 4 l15 + ct]
+              oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[ii][jt][r][ct], pv[r], oe[ct], 0, 0, 0);
+          if (ii == 0 && jt >= E_LAG) {  // retired tiles free their registers: start the next row, E_LAG tiles behind
+            load_e_tile(1, c, jt - E_LAG);
+            MEM_FENCE();
+          }
+        }
+        if (ii == 0) {  // the last E_LAG tiles of the next row are needed last by its bias loop
+#pragma unroll
+          for (int jt = NT - E_LAG; jt < NT; ++jt) load_e_tile(1, c, jt);
           MEM_FENCE();
         }
-        os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[st].x, os[0], 0, 0, 0);
-        os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[st].y, os[1], 0, 0, 0);
-        og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gx[st], og[0], 0, 0, 0);
-        og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gy[st], og[1], 0, 0, 0);
-        og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz[st], og[2], 0, 0, 0);
-      }
-    }
-    // D rows i = 4 q + r, column n = l15
+        // D: column h = l15, row m = 4 q + r' <-> channel 4 m + ct = 16 q + 4 r' + ct
+        if (l15 < 8) {
+          float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 16 * q;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = prow0 + i0 + 4 * q + r;
-      float* fr = feat + row * AF;
-      *reinterpret_cast<float2*>(fr + FOFF_OS + h * ADS + 2 * l15) = make_float2(os[0][r], os[1][r]);
-      if (l15 < 8) {
-        const float* Rr = R + row * 9;
-        const float* tr = t + row * 3;
-        const float dx = og[0][r] - tr[0], dy = og[1][r] - tr[1], dz = og[2][r] - tr[2];
-        const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
-        const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
-        const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
-        float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
-        fo[0] = lx; fo[1] = ly; fo[2] = lz;
-        fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
+          for (int r = 0; r < 4; ++r) {
+            f32x4 v = {oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
+            if (c > 0) {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(fo + 4 * r);
+#pragma unroll
+              for (int s = 0; s < 4; ++s) v[s] += old[s] * fac;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] *= inv;
+            *reinterpret_cast<f32x4*>(fo + 4 * r) = v;
+          }
+          if (q == 0) {
+            st_fac[il * AH + h] = fac;
+            st_inv[il * AH + h] = inv;
+          }
+        }
       }
     }
+    if (c == 0) stamp(3);
+
+    // ---------------------------------------------------------------- phase 3: wave = head
+    {
+      constexpr int PFV = 16;  // value prefetch distance, key steps (16 x 160 MFMA cycles ~ the loaded L2 latency)
+      const int h = wv;
+      const int pp = l15 & 7;
+      const float* vbase = proj + (krow0 + 4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;  // + (16 jt + r) rows; d = 2 l15 + dt
+      const float* gbase = proj + (krow0 + 4 * q) * ANP + OFF_GV + h * 24 + 3 * pp;    // point pp, coords 0..2
+      float2 vs[NS];
+      float gx[NS], gy[NS], gz[NS];
+      auto load_vals = [&](int stp) {
+        const int64_t o = static_cast<int64_t>((stp >> 2) * 16 + (stp & 3)) * ANP;
+        vs[stp] = *reinterpret_cast<const float2*>(vbase + o);
+        gx[stp] = gbase[o];
+        gy[stp] = gbase[o + 1];
+        gz[stp] = gbase[o + 2];
+      };
+#pragma unroll
+      for (int stp = 0; stp < PFV && stp < NS; ++stp) load_vals(stp);
+      MEM_FENCE();
+      __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS
+      if (c == 0) stamp(4);
+      f32x4 os[2], og[3];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) og[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 16 jt + 4 q + r]
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int stp = jt * 4 + r;
+          if (stp + PFV < NS) {
+            load_vals(stp + PFV);
+            MEM_FENCE();
+          }
+          os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[stp].x, os[0], 0, 0, 0);
+          os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[stp].y, os[1], 0, 0, 0);
+          og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gx[stp], og[0], 0, 0, 0);
+          og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gy[stp], og[1], 0, 0, 0);
+          og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz[stp], og[2], 0, 0, 0);
+        }
+      }
+      // D rows i = 4 q + r, column n = l15; earlier chunks' sums are rescaled through the feature row
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = 4 * q + r;
+        const int64_t row = prow0 + i0 + il;
+        const float fac = st_fac[il * AH + h], inv = st_inv[il * AH + h];
+        float* fr = feat + row * AF;
+        float2 o2 = make_float2(os[0][r], os[1][r]);
+        float2* po = reinterpret_cast<float2*>(fr + FOFF_OS + h * ADS + 2 * l15);
+        if (c > 0) {
+          const float2 old = *po;
+          o2.x += old.x * fac;
+          o2.y += old.y * fac;
+        }
+        o2.x *= inv;
+        o2.y *= inv;
+        *po = o2;
+        if (l15 < 8) {
+          float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
+          float g0_ = og[0][r], g1_ = og[1][r], g2_ = og[2][r];
+          if (c > 0) {  // running (unnormalised, global-frame) sums are parked in the o_l slot between chunks
+            g0_ += fo[0] * fac;
+            g1_ += fo[1] * fac;
+            g2_ += fo[2] * fac;
+          }
+          if (last) {
+            const float* Rr = R + row * 9;
+            const float* tr = t + row * 3;
+            const float dx = g0_ * inv - tr[0], dy = g1_ * inv - tr[1], dz = g2_ * inv - tr[2];
+            const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
+            const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
+            const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
+            fo[0] = lx; fo[1] = ly; fo[2] = lz;
+            fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
+          } else {
+            fo[0] = g0_; fo[1] = g1_; fo[2] = g2_;
+          }
+        }
+      }
+    }
+    if (!last) __syncthreads();  // the next chunk's phase 1 overwrites the image
   }
   stamp(5);
 }
@@ -556,7 +590,7 @@ __global__ void points_to_global_fast_kernel(float* __restrict__ proj, const flo
 
 bool fast_path_supported(const diffab_dims* d) {
   return d->D == 128 && d->C == AC && d->H == AH && d->DS == ADS && d->PQ == AP && d->PV == AP && d->K % 64 == 0 && d->K >= 64 &&
-         d->K <= 128;  // K = 192/256: logits image + per-wave scratch exceed the 160 KiB LDS (generic path until re-tiled)
+         d->K <= 1024;  // any multiple of 64: keys are processed in chunks of 128 (or 64) with an online softmax
 }
 
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
@@ -579,24 +613,23 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   if (int rc = launch_linear_bn<64>(x, D, segs, nullptr, proj, ANP, rows, ANP, D, false, vec, st)) return rc;
   hipLaunchKernelGGL(points_to_global_fast_kernel, dim3((rows * 192 + 255) / 256), dim3(256), 0, st, proj, R, t, rows);
   DIFFAB_LAUNCH_CHECK();
-  const size_t lds = (static_cast<size_t>(TI) * (AH * (d->K + 8) + 8) + 8 * 2 * 16 * 72) * sizeof(float);  // logits + per-wave scratch
+  const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
+  const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
+  const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
   const dim3 grid(d->B * (d->K / TI));
-#define ATTN_LAUNCH(NT_)                                                                                                              \
+#define ATTN_LAUNCH(NT_, MULTI_)                                                                                                      \
   do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_>),                                    \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_>),                            \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL(ipa_attn_fast_kernel<NT_>, grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, d->B,           \
-                       g_attn_stamps);                                                                                                \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_>), grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, d->B, \
+                       nc, g_attn_stamps);                                                                                            \
     timer_end(st);                                                                                                                    \
   } while (0)
-  switch (d->K / 16) {
-    case 4: ATTN_LAUNCH(4); break;
-    case 8: ATTN_LAUNCH(8); break;
-    case 12: ATTN_LAUNCH(12); break;
-    case 16: ATTN_LAUNCH(16); break;
-    default: set_error("fast attention: unsupported K=%d", d->K); return DIFFAB_ERR_UNSUPPORTED;
-  }
+  if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
+  else if (nt == 8) ATTN_LAUNCH(8, true);
+  else if (nc == 1) ATTN_LAUNCH(4, false);
+  else ATTN_LAUNCH(4, true);
 #undef ATTN_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);

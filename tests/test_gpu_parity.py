@@ -299,6 +299,28 @@ def test_denoiser_vs_oracle_batch_and_permutation(hip):
         assert torch.equal(outp[k].cpu(), out[k].cpu()[perm]), k
 
 
+@pytest.mark.parametrize("K", [64, 192, 256])
+def test_fast_path_key_chunks_vs_generic_and_oracle(hip, K):
+    """K = 64 (one 64-key chunk), 192 (three 64-key chunks) and 256 (two 128-key chunks): the online-softmax chunk loop of the
+    MFMA attention kernel against the generic kernels (same device) and the oracle."""
+    from diffab_pytorch.diffab_pytorch import Denoiser
+
+    dims = dict(syn.BENCH_DIMS, NL=2)
+    den = Denoiser(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"], 21)
+    sd = syn.denoiser_state_dict(dims, seed=6, prefix="")
+    den.load_state_dict(sd)
+    den = den.cuda()
+    inp = syn.patches(2, K, dims, seed=60 + K, coord_sigma=5.0)
+    beta = torch.tensor([0.02, 0.6])
+    args = [inp[k] for k in ("seq_idx", "translations", "orientations", "res_context_emb", "pair_context_emb")]
+    fast = den(*[a.cuda() for a in args], beta.cuda(), None, None, return_logits=True)
+    gen = den(*[a.cuda() for a in args], beta.cuda(), None, None, return_logits=True, flags=_hip.FLAG_FORCE_GENERIC)
+    want = orc.denoiser({"denoiser." + k: v for k, v in sd.items()}, *args, beta, dims["NL"], dims["H"])
+    for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
+        assert maxrel(fast[k], want[k]) < TOL, (K, k, maxrel(fast[k], want[k]))
+        assert maxrel(fast[k], gen[k]) < TOL, (K, k, maxrel(fast[k], gen[k]))
+
+
 def test_denoiser_translation_offset_robustness(hip):
     """The reference feeds raw PDB coordinates (diffab_pytorch.py:820); a 150 A offset must not break parity
     (reference fp32 noise floor rises to 6e-6 there)."""
