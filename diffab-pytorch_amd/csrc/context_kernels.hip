@@ -1,0 +1,220 @@
+// context_kernels.hip - encode_context: ResidueEmbedding (reference diffab_pytorch.py:57-183) and PairEmbedding
+// (:186-312) forward.  Runs once per sample (not per denoise step); produces the (B,K,D) / (B,K,K,C) context embeddings the hot
+// path consumes.  Feature rows are assembled by small gather kernels and pushed through the MFMA linear kernel; the pair part
+// is processed a few patches at a time so its row buffers (K^2 rows x 225 floats per patch) stay bounded.
+// Reference quirks reproduced on purpose: same_chain_mask is the PRODUCT of chain ids (:279); the structure-context mask is
+// applied to `distmat` only after its use, so neither the distance nor the dihedral pair feature is masked (:292-301);
+// non-context residues take amino-acid type UNK = 20 (:115, :273); nn.Embedding padding_idx only affects gradients.
+#include "common.h"
+#include "denoiser_internal.h"
+
+namespace diffab {
+
+constexpr int kAA = 21, kUNK = 20, kCA = 1;
+
+__device__ inline float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // F.softplus defaults (beta 1, threshold 20)
+
+// AngularEncoding (:20-54): [x, sin(f x) for f in bands, cos(f x) for f in bands], bands = [1..n, 1/1..1/n]
+__device__ inline void angular_encode(float x, int nf, float* out) {
+  out[0] = x;
+  for (int k = 0; k < 2 * nf; ++k) {
+    const float f = k < nf ? static_cast<float>(k + 1) : 1.0f / static_cast<float>(k - nf + 1);
+    out[1 + k] = sinf(f * x);
+    out[1 + 2 * nf + k] = cosf(f * x);
+  }
+}
+
+// one block per residue: [aa_emb (D) | coord one-hot-by-type (21*A*3) | dihedral enc (3*13) | chain_emb (D)]
+__global__ void residue_feat_kernel(const int64_t* __restrict__ seq, const float* __restrict__ xyz, const float* __restrict__ O,
+                                    const float* __restrict__ dih, const int64_t* __restrict__ chain, const float* __restrict__ amask,
+                                    const uint8_t* __restrict__ struct_m, const uint8_t* __restrict__ seq_m, const float* __restrict__ aa_emb,
+                                    const float* __restrict__ chain_emb, int K, int A, int D, float* __restrict__ out) {
+  const int64_t r = blockIdx.x;
+  const int l = static_cast<int>(r % K);
+  const int64_t b0 = r - l;
+  const int Din = D + kAA * A * 3 + 39 + D;
+  float* o = out + r * Din;
+  int64_t s = seq[r];
+  if (seq_m && !seq_m[r]) s = kUNK;
+  const bool sm = struct_m ? struct_m[r] != 0 : true;
+  const bool dm = struct_m ? (struct_m[r] != 0 && struct_m[b0 + (l + 1) % K] != 0) : true;  // roll(mask,-1) & mask (:160-166)
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    o[d] = aa_emb[s * D + d];
+    o[D + kAA * A * 3 + 39 + d] = chain_emb[chain[r] * D + d];
+  }
+  for (int idx = threadIdx.x; idx < kAA * A * 3; idx += blockDim.x) {
+    const int t = idx / (A * 3), a = (idx / 3) % A, i = idx % 3;
+    float v = 0.0f;
+    if (t == s && sm) {  // local = O^T (x - x_CA), times the atom mask (:119-127)
+      const float* x = xyz + (r * A + a) * 3;
+      const float* ca = xyz + (r * A + kCA) * 3;
+      const float* Or = O + r * 9;
+      v = (Or[0 * 3 + i] * (x[0] - ca[0]) + Or[1 * 3 + i] * (x[1] - ca[1]) + Or[2 * 3 + i] * (x[2] - ca[2])) * amask[r * A + a];
+    }
+    o[D + idx] = v;
+  }
+  if (threadIdx.x < 3) {
+    float enc[13];
+    angular_encode(dih[r * 3 + threadIdx.x], 3, enc);
+    for (int k = 0; k < 13; ++k) o[D + kAA * A * 3 + threadIdx.x * 13 + k] = dm ? enc[k] : 0.0f;
+  }
+}
+
+// one thread per (pair row, atom pair): exp(-softplus(coef[s_i*21+s_j]) d^2) * atom_mask_i * atom_mask_j   (:288-295)
+__global__ void pair_dist_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const float* __restrict__ distmat,
+                                 const float* __restrict__ amask, const float* __restrict__ coefw, int K, int A, int64_t row0, int64_t nrows,
+                                 float* __restrict__ out) {
+  const int AA2 = A * A;
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (gid >= nrows * AA2) return;
+  const int64_t lr = gid / AA2, row = row0 + lr;  // global pair row (b, i, j)
+  const int p = static_cast<int>(gid % AA2), a1 = p / A, a2 = p % A;
+  const int64_t b = row / (static_cast<int64_t>(K) * K);
+  const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+  const int64_t ri = b * K + i, rj = b * K + j;
+  const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+  const float coef = softplus_f(coefw[(si * kAA + sj) * AA2 + p]);
+  const float d = distmat[row * AA2 + p];
+  out[lr * AA2 + p] = expf(-1.0f * coef * (d * d)) * (amask[ri * A + a1] * amask[rj * A + a2]);
+}
+
+// one block per pair row: [aa_pair_emb (C) | relpos_emb * chain_i*chain_j (C) | dist_feat (C) | dihedral enc (2*9)]
+__global__ void pair_cat_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
+                                int resid_bstride, const int64_t* __restrict__ chain, const float* __restrict__ pdih,
+                                const float* __restrict__ dist_feat, const float* __restrict__ pair_emb, const float* __restrict__ rel_emb,
+                                int K, int C, int max_dist, int64_t row0, float* __restrict__ out) {
+  const int64_t lr = blockIdx.x, row = row0 + lr;
+  const int64_t b = row / (static_cast<int64_t>(K) * K);
+  const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+  const int64_t ri = b * K + i, rj = b * K + j;
+  const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+  int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
+  rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
+  const float same = static_cast<float>(chain[ri] * chain[rj]);  // a product, not an equality test (:279)
+  const int W = 3 * C + 18;
+  float* o = out + lr * W;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    o[c] = pair_emb[(si * kAA + sj) * C + c];
+    o[C + c] = rel_emb[(rel + max_dist) * C + c] * same;
+    o[2 * C + c] = dist_feat[lr * C + c];
+  }
+  if (threadIdx.x < 2) {
+    float enc[9];
+    angular_encode(pdih[row * 2 + threadIdx.x], 2, enc);
+    for (int k = 0; k < 9; ++k) o[3 * C + threadIdx.x * 9 + k] = enc[k];
+  }
+}
+
+// out[row][:] *= atom_mask_i[CA] * atom_mask_j[CA]   (:269-271, :312)
+__global__ void pair_mask_kernel(float* __restrict__ out, const float* __restrict__ amask, int K, int A, int C, int64_t rows) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (gid >= rows * C) return;
+  const int64_t row = gid / C;
+  const int64_t b = row / (static_cast<int64_t>(K) * K);
+  const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+  out[gid] *= amask[(b * K + i) * A + kCA] * amask[(b * K + j) * A + kCA];
+}
+
+}  // namespace diffab
+
+using namespace diffab;
+
+extern "C" {
+
+static int check_ctx(const diffab_ctx_dims* d, const char* who) {
+  DIFFAB_REQUIRE(d && d->B > 0 && d->K > 0 && d->A > kCA && d->D > 0 && d->C > 0 && d->max_dist > 0, DIFFAB_ERR_ARG, "%s: bad dims", who);
+  return DIFFAB_OK;
+}
+
+size_t diffab_residue_embedding_workspace_bytes(const diffab_ctx_dims* d) {
+  if (check_ctx(d, "residue_embedding_workspace_bytes")) return 0;
+  const size_t rows = static_cast<size_t>(d->B) * d->K, Din = 2 * d->D + kAA * d->A * 3 + 39;
+  return (rows * (Din + 2 * d->D + d->D + d->D) + 64) * sizeof(float);
+}
+
+int diffab_residue_embedding_fwd(const diffab_ctx_dims* d, const diffab_residue_emb_weights* w, const int64_t* seq_idx, const float* xyz,
+                                 const float* orientations, const float* dihedrals, const int64_t* chain_idx, const float* atom_mask,
+                                 const uint8_t* structure_context_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (int rc = check_ctx(d, "residue_embedding_fwd")) return rc;
+  DIFFAB_REQUIRE(w && w->aa_emb && w->chain_emb && w->w0 && w->b0 && w->w2 && w->b2 && w->w4 && w->b4 && w->w6 && w->b6, DIFFAB_ERR_ARG,
+                 "residue_embedding_fwd: null weight");
+  DIFFAB_REQUIRE(seq_idx && xyz && orientations && dihedrals && chain_idx && atom_mask && out && workspace, DIFFAB_ERR_ARG,
+                 "residue_embedding_fwd: null pointer");
+  DIFFAB_REQUIRE(workspace_bytes >= diffab_residue_embedding_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "residue_embedding_fwd: workspace");
+  hipStream_t st = as_stream(stream);
+  const int rows = d->B * d->K, D = d->D, Din = 2 * D + kAA * d->A * 3 + 39;
+  float* feat = static_cast<float*>(workspace);
+  float* h1 = feat + static_cast<size_t>(rows) * Din;
+  float* h2 = h1 + static_cast<size_t>(rows) * 2 * D;
+  float* h3 = h2 + static_cast<size_t>(rows) * D;
+  hipLaunchKernelGGL(residue_feat_kernel, dim3(rows), dim3(128), 0, st, seq_idx, xyz, orientations, dihedrals, chain_idx, atom_mask,
+                     structure_context_mask, sequence_context_mask, w->aa_emb, w->chain_emb, d->K, d->A, D, feat);
+  DIFFAB_LAUNCH_CHECK();
+  if (int rc = launch_linear(feat, Din, w->w0, w->b0, h1, 2 * D, rows, 2 * D, Din, true, st)) return rc;
+  if (int rc = launch_linear(h1, 2 * D, w->w2, w->b2, h2, D, rows, D, 2 * D, true, st)) return rc;
+  if (int rc = launch_linear(h2, D, w->w4, w->b4, h3, D, rows, D, D, true, st)) return rc;
+  return launch_linear(h3, D, w->w6, w->b6, out, D, rows, D, D, false, st);
+}
+
+static int pair_chunk_patches(const diffab_ctx_dims* d) {
+  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (d->A * d->A + 7 * d->C + 18) * sizeof(float);
+  const size_t budget = static_cast<size_t>(512) << 20;  // ~0.5 GiB of row buffers at a time
+  const size_t n = budget / per_patch;
+  return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
+}
+
+size_t diffab_pair_embedding_workspace_bytes(const diffab_ctx_dims* d) {
+  if (check_ctx(d, "pair_embedding_workspace_bytes")) return 0;
+  const size_t rows = static_cast<size_t>(pair_chunk_patches(d)) * d->K * d->K;
+  return (rows * (d->A * d->A + 7 * d->C + 18) + 64) * sizeof(float);
+}
+
+int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
+                              const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
+                              const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_ctx(d, "pair_embedding_fwd")) return rc;
+  DIFFAB_REQUIRE(w && w->aa_pair_emb && w->relpos_emb && w->pair2distcoef && w->dw0 && w->db0 && w->dw2 && w->db2 && w->mw0 && w->mb0 &&
+                     w->mw2 && w->mb2 && w->mw4 && w->mb4,
+                 DIFFAB_ERR_ARG, "pair_embedding_fwd: null weight");
+  DIFFAB_REQUIRE(seq_idx && distmat && pairwise_dihedrals && residue_idx && chain_idx && atom_mask && out && workspace, DIFFAB_ERR_ARG,
+                 "pair_embedding_fwd: null pointer");
+  DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_fwd: workspace");
+  hipStream_t st = as_stream(stream);
+  const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18;
+  const int bc = pair_chunk_patches(d);
+  const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
+  float* din = static_cast<float*>(workspace);
+  float* h1 = din + static_cast<size_t>(bc) * per_patch * AA2;
+  float* df = h1 + static_cast<size_t>(bc) * per_patch * C;
+  float* cat = df + static_cast<size_t>(bc) * per_patch * C;
+  float* m1 = cat + static_cast<size_t>(bc) * per_patch * W;
+  float* m2 = m1 + static_cast<size_t>(bc) * per_patch * C;
+  for (int b0 = 0; b0 < d->B; b0 += bc) {
+    const int nb = (d->B - b0) < bc ? (d->B - b0) : bc;
+    const int64_t row0 = b0 * per_patch, nrows = nb * per_patch;
+    const int rows = static_cast<int>(nrows);
+    const int64_t n1 = nrows * AA2;
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, seq_idx, sequence_context_mask,
+                       distmat, atom_mask, w->pair2distcoef, d->K, d->A, row0, nrows, din);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_linear(din, AA2, w->dw0, w->db0, h1, C, rows, C, AA2, true, st)) return rc;
+    if (int rc = launch_linear(h1, C, w->dw2, w->db2, df, C, rows, C, C, true, st)) return rc;
+    hipLaunchKernelGGL(pair_cat_kernel, dim3(static_cast<unsigned>(nrows)), dim3(64), 0, st, seq_idx, sequence_context_mask, residue_idx,
+                       residue_idx_batch_stride, chain_idx, pairwise_dihedrals, df, w->aa_pair_emb, w->relpos_emb, d->K, C, d->max_dist,
+                       row0, cat);
+    DIFFAB_LAUNCH_CHECK();
+    float* o = out + row0 * C;
+    if (int rc = launch_linear(cat, W, w->mw0, w->mb0, m1, C, rows, C, W, true, st)) return rc;
+    if (int rc = launch_linear(m1, C, w->mw2, w->mb2, m2, C, rows, C, C, true, st)) return rc;
+    if (int rc = launch_linear(m2, C, w->mw4, w->mb4, o, C, rows, C, C, false, st)) return rc;
+  }
+  const int64_t total = static_cast<int64_t>(d->B) * per_patch;
+  hipLaunchKernelGGL(pair_mask_kernel, dim3(static_cast<unsigned>((total * C + 255) / 256)), dim3(256), 0, st, out, atom_mask, d->K, d->A, C,
+                     total);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // extern "C"

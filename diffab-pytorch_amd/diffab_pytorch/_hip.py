@@ -51,6 +51,19 @@ class DenoiserWeights(C.Structure):
     ]
 
 
+class CtxDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "K", "A", "D", "C", "max_dist")]
+
+
+class ResidueEmbWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("aa_emb", "chain_emb", "w0", "b0", "w2", "b2", "w4", "b4", "w6", "b6")]
+
+
+class PairEmbWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("aa_pair_emb", "relpos_emb", "pair2distcoef", "dw0", "db0", "dw2", "db2", "mw0", "mb0", "mw2", "mb2",
+                                   "mw4", "mb4")]
+
+
 class Sched(C.Structure):
     _fields_ = [("T", C.c_int32), ("alpha", _fp), ("alpha_bar", _fp), ("alpha_bar_sqrt", _fp),
                 ("one_minus_alpha_bar_sqrt", _fp), ("beta", _fp)]
@@ -94,6 +107,11 @@ SYMBOLS = {
     "diffab_train_workspace_bytes": (_sz, [_PD]),
     "diffab_train_step_fwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights)] + [_fp] * 16 + [_sz, _u32, _fp]),
     "diffab_train_step_bwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), C.POINTER(DenoiserWeights)] + [_fp] * 16 + [_sz, _fp, _sz, _fp]),
+    "diffab_residue_embedding_workspace_bytes": (_sz, [C.POINTER(CtxDims)]),
+    "diffab_residue_embedding_fwd": (C.c_int, [C.POINTER(CtxDims), C.POINTER(ResidueEmbWeights)] + [_fp] * 10 + [_sz, _fp]),
+    "diffab_pair_embedding_workspace_bytes": (_sz, [C.POINTER(CtxDims)]),
+    "diffab_pair_embedding_fwd": (C.c_int, [C.POINTER(CtxDims), C.POINTER(PairEmbWeights), _fp, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp,
+                                            _fp, _sz, _fp]),
     "diffab_orientation_loss": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp]),
     "diffab_reverse_update": (C.c_int, [_PS, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "diffab_sample_loop": (C.c_int, [_PD, C.POINTER(DenoiserWeights), _PS, _PI, _fp, _fp, _fp, _fp, _fp, _fp, _u64, _i64, _i32,

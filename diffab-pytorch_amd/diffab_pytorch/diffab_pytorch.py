@@ -7,9 +7,8 @@ output dict keys and ``state_dict`` keys/shapes, so a c
 reference loads unchanged and callers need no edits.  The ``nn.Module`` objects only own the
 parameters; every forward is one C-ABI call into the HIP library - there is no ATen fallback.
 
-Not on this path ("next"): the context encoders ResidueEmbedding /
-PairEmbedding keep their parameters (so state_dicts round-trip) but ``encode_context`` is not yet
-implemented here; callers pass precomputed context embeddings.
+The context encoders ResidueEmbedding / PairEmbedding (the step just before the hot path) also run
+on HIP (forward only: the reference itself cannot back-propagate through PairEmbedding, diffab_pytorch.py:295-301).
 """
 from __future__ import annotations
 
@@ -239,35 +238,55 @@ class OrientationLoss(nn.Module):
         return out.to(device=pred_rotmat.device, dtype=pred_rotmat.dtype)
 
 
-class _ParamsOnly(nn.Module):
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            f"{type(self).__name__} is a context encoder (reference diffab_pytorch.py:57-312): outside the hot path, "
-            "next on the list (SURVEY.md 8f-1).  Its parameters are kept so state_dicts round-trip; pass precomputed "
-            "res_context_emb / pair_context_emb instead.")
+def _opt_mask(m):
+    return None if m is None else _hip.dev_mask(m)
 
 
-class ResidueEmbedding(_ParamsOnly):
-    """Parameter container with the reference's keys/shapes/creation order (diffab_pytorch.py:57-79)."""
+class ResidueEmbedding(nn.Module):
+    """Per-residue context embedding (reference diffab_pytorch.py:57-183): same parameters, creation order and forward
+    signature; the forward is one C-ABI call (feature gather kernel + four MFMA linears)."""
 
     def __init__(self, max_n_atoms_per_residue, d_feat):
         super().__init__()
         self.max_n_aa_types = 21
         self.max_n_atoms_per_residue = max_n_atoms_per_residue
+        self.d_feat = d_feat
         self.amino_acid_type_embedding = nn.Embedding(self.max_n_aa_types, d_feat)
         self.chain_embedding = nn.Embedding(10, d_feat, padding_idx=0)
         d_in = d_feat + self.max_n_aa_types * max_n_atoms_per_residue * 3 + 3 * (3 * 2 * 2 + 1) + d_feat
         self.mlp = nn.Sequential(nn.Linear(d_in, d_feat * 2), nn.ReLU(), nn.Linear(d_feat * 2, d_feat), nn.ReLU(),
                                  nn.Linear(d_feat, d_feat), nn.ReLU(), nn.Linear(d_feat, d_feat))
 
+    def forward(self, seq_idx, xyz, orientation, dihedrals, chain_idx, atom_mask, structure_context_mask=None,
+                sequence_context_mask=None):
+        lib = _hip.lib()
+        out_dev = xyz.device
+        seq, ch = _hip.dev_i64(seq_idx), _hip.dev_i64(chain_idx)
+        x, O, dh, am = (_hip.dev_f32(a) for a in (xyz, orientation, dihedrals, atom_mask))
+        sm, qm = _opt_mask(structure_context_mask), _opt_mask(sequence_context_mask)
+        B, K = seq.shape
+        dims = _hip.CtxDims(B, K, self.max_n_atoms_per_residue, self.d_feat, 1, 32)
+        p = _named(self)
+        ts = [_hip.dev_f32(p[k]) for k in ("amino_acid_type_embedding.weight", "chain_embedding.weight", "mlp.0.weight", "mlp.0.bias",
+                                           "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias", "mlp.6.weight", "mlp.6.bias")]
+        w = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in ts])
+        ws = _hip.workspace(lib.diffab_residue_embedding_workspace_bytes(C.byref(dims)))
+        out = torch.empty(B, K, self.d_feat, dtype=torch.float32, device=seq.device)
+        _hip.check(lib.diffab_residue_embedding_fwd(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(dh),
+                                                    _hip.ptr(ch), _hip.ptr(am), _hip.ptr(sm), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws),
+                                                    ws.numel(), _hip.stream_ptr()), "diffab_residue_embedding_fwd")
+        return out.to(out_dev)
 
-class PairEmbedding(_ParamsOnly):
-    """Parameter container with the reference's keys/shapes/creation order (diffab_pytorch.py:186-218)."""
+
+class PairEmbedding(nn.Module):
+    """Residue-pair context embedding (reference diffab_pytorch.py:186-312), forward on HIP.  Reference quirks kept: the
+    same-chain mask is a product of chain ids (:279) and the structure-context mask never reaches the output (:292-301)."""
 
     def __init__(self, max_n_atoms_per_residue, d_feat, max_dist_to_consider=32):
         super().__init__()
         self.d_feat = d_feat
         self.max_dist_to_consider = max_dist_to_consider
+        self.max_n_atoms_per_residue = max_n_atoms_per_residue
         self.max_n_aa_types = 21
         self.aa_pair_type_embedding = nn.Embedding(self.max_n_aa_types**2, d_feat)
         self.relpos_embedding = nn.Embedding(2 * max_dist_to_consider + 1, d_feat)
@@ -277,6 +296,31 @@ class PairEmbedding(_ParamsOnly):
                                                 nn.ReLU())
         self.mlp = nn.Sequential(nn.Linear(3 * d_feat + 2 * (2 * 2 * 2 + 1), d_feat), nn.ReLU(), nn.Linear(d_feat, d_feat), nn.ReLU(),
                                  nn.Linear(d_feat, d_feat))
+
+    def forward(self, seq_idx, distmat, dihedrals, residue_idx, chain_idx, atom_mask, structure_context_mask, sequence_context_mask):
+        lib = _hip.lib()
+        out_dev = distmat.device
+        seq, ch, ri = _hip.dev_i64(seq_idx), _hip.dev_i64(chain_idx), _hip.dev_i64(residue_idx)
+        dm, dh, am = (_hip.dev_f32(a) for a in (distmat, dihedrals, atom_mask))
+        qm = _opt_mask(sequence_context_mask)
+        B, K = seq.shape
+        A = self.max_n_atoms_per_residue
+        dims = _hip.CtxDims(B, K, A, 1, self.d_feat, self.max_dist_to_consider)
+        p = _named(self)
+        ts = [_hip.dev_f32(p[k]) for k in ("aa_pair_type_embedding.weight", "relpos_embedding.weight", "pair2distcoef.weight",
+                                           "distance_embedding.0.weight", "distance_embedding.0.bias", "distance_embedding.2.weight",
+                                           "distance_embedding.2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
+                                           "mlp.4.weight", "mlp.4.bias")]
+        w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
+        ws = _hip.workspace(lib.diffab_pair_embedding_workspace_bytes(C.byref(dims)))
+        out = torch.empty(B, K, K, self.d_feat, dtype=torch.float32, device=seq.device)
+        stride = K if ri.shape[0] == B and B > 1 or ri.shape[0] == B else 0
+        if ri.shape[0] not in (1, B):
+            raise ValueError("residue_idx must be (1, K) or (B, K)")
+        _hip.check(lib.diffab_pair_embedding_fwd(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri),
+                                                 stride if ri.shape[0] == B else 0, _hip.ptr(ch), _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out),
+                                                 _hip.ptr(ws), ws.numel(), _hip.stream_ptr()), "diffab_pair_embedding_fwd")
+        return out.to(out_dev)
 
 
 class DiffAb(_ModuleBase):
@@ -319,8 +363,15 @@ class DiffAb(_ModuleBase):
     # ------------------------------------------------------------------ reference API
     def encode_context(self, seq_idx_t0, xyz_t0, orientations_t0, backbone_dihedrals, distmat, pairwise_dihedrals, atom_mask, chain_idx,
                        residue_idx, generation_mask, residue_mask, generate_structure: bool = True, generate_sequence: bool = True):
-        raise NotImplementedError("encode_context (reference diffab_pytorch.py:680-724) is outside the hot path - SURVEY.md 8f-1, next; "
-                                  "pass res_context_emb / pair_context_emb")
+        """Residue and pair context embeddings of the non-generated residues (reference diffab_pytorch.py:680-724)."""
+        context_mask = residue_mask.bool() & (~generation_mask.bool())
+        structure_context_mask = context_mask if generate_structure else None
+        sequence_context_mask = context_mask if generate_sequence else None
+        res_context_emb = self.residue_context_embedding(seq_idx_t0, xyz_t0, orientations_t0, backbone_dihedrals, chain_idx, atom_mask,
+                                                         structure_context_mask, sequence_context_mask)
+        pair_context_emb = self.pair_context_embedding(seq_idx_t0, distmat, pairwise_dihedrals, residue_idx, chain_idx, atom_mask,
+                                                       structure_context_mask, sequence_context_mask)
+        return res_context_emb, pair_context_emb
 
     def denoise(self, seq_idx_t, translations_t, orientations_t, res_context_emb, pair_context_emb, beta, generation_mask, residue_mask
                 ) -> Dict[str, torch.Tensor]:

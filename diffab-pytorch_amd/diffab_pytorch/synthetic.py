@@ -99,3 +99,67 @@ def patches(B: int, K: int, dims: Dict[str, int], seed: int = 0, coord_sigma: fl
         out["generation_mask"].append(m)
         out["residue_mask"].append(np.ones(K, dtype=bool))
     return {k: torch.from_numpy(np.stack(v)) for k, v in out.items()}
+
+
+def context_state_dict(d_res: int, d_pair: int, n_atoms: int = 15, max_dist: int = 32, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic parameters of the two context encoders with the reference's keys/shapes.
+    pair2distcoef is zero-initialised upstream; random here so the distance feature depends on it."""
+    rng = _rng(seed, 3003)
+    sd: Dict[str, np.ndarray] = {}
+
+    def lin(name, out_f, in_f):
+        sd[name + ".weight"] = rng.standard_normal((out_f, in_f)) / np.sqrt(in_f)
+        sd[name + ".bias"] = 0.1 * rng.standard_normal(out_f)
+
+    r = "residue_context_embedding."
+    sd[r + "amino_acid_type_embedding.weight"] = rng.standard_normal((21, d_res))
+    sd[r + "chain_embedding.weight"] = rng.standard_normal((10, d_res))
+    lin(r + "mlp.0", 2 * d_res, 2 * d_res + 21 * n_atoms * 3 + 39)
+    lin(r + "mlp.2", d_res, 2 * d_res)
+    lin(r + "mlp.4", d_res, d_res)
+    lin(r + "mlp.6", d_res, d_res)
+    q = "pair_context_embedding."
+    sd[q + "aa_pair_type_embedding.weight"] = rng.standard_normal((441, d_pair))
+    sd[q + "relpos_embedding.weight"] = rng.standard_normal((2 * max_dist + 1, d_pair))
+    sd[q + "pair2distcoef.weight"] = 0.5 * rng.standard_normal((441, n_atoms * n_atoms)) - 3.0
+    lin(q + "distance_embedding.0", d_pair, n_atoms * n_atoms)
+    lin(q + "distance_embedding.2", d_pair, d_pair)
+    lin(q + "mlp.0", d_pair, 3 * d_pair + 18)
+    lin(q + "mlp.2", d_pair, d_pair)
+    lin(q + "mlp.4", d_pair, d_pair)
+    return {k: torch.from_numpy(v.astype(np.float32)) for k, v in sd.items()}
+
+
+def context_batch(B: int, K: int, n_atoms: int = 15, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic inputs of DiffAb.encode_context (reference batch dict): atoms scattered around each
+    residue's CA, real pairwise atom distances, random angles, chains 1..3, a contiguous generated segment per patch."""
+    out = {k: [] for k in ("seq_idx", "xyz", "orientations", "backbone_dihedrals", "distmat", "pairwise_dihedrals", "atom_mask",
+                           "chain_idx", "generation_mask", "residue_mask")}
+    for p in range(B):
+        rng = _rng(seed, 4004, p)
+        ca = 8.0 * rng.standard_normal((K, 1, 3))
+        xyz = ca + 1.5 * rng.standard_normal((K, n_atoms, 3))
+        xyz[:, 1] = ca[:, 0]
+        am = (rng.random((K, n_atoms)) < 0.8)
+        am[:, :4] = True
+        am[K - 1, 1] = False  # one residue without CA: exercises the residue-pair mask
+        d = np.linalg.norm(xyz[:, None, :, None, :] - xyz[None, :, None, :, :], axis=-1)
+        out["seq_idx"].append(rng.integers(0, 20, size=K, dtype=np.int64))
+        out["xyz"].append(xyz.astype(np.float32))
+        out["orientations"].append(random_rotations(rng, K).astype(np.float32))
+        out["backbone_dihedrals"].append(rng.uniform(-np.pi, np.pi, (K, 3)).astype(np.float32))
+        out["distmat"].append(d.astype(np.float32))
+        out["pairwise_dihedrals"].append(rng.uniform(-np.pi, np.pi, (K, K, 2)).astype(np.float32))
+        out["atom_mask"].append(am.astype(np.float32))
+        out["chain_idx"].append(np.sort(rng.integers(1, 4, size=K)).astype(np.int64))
+        seg = int(rng.integers(2, max(3, K // 3)))
+        start = int(rng.integers(0, K - seg + 1))
+        g = np.zeros(K, dtype=bool)
+        g[start:start + seg] = True
+        rm = np.ones(K, dtype=bool)
+        rm[0] = False
+        out["generation_mask"].append(g)
+        out["residue_mask"].append(rm)
+    res = {k: torch.from_numpy(np.stack(v)) for k, v in out.items()}
+    res["residue_idx"] = torch.arange(K).unsqueeze(0)
+    return res

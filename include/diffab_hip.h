@@ -213,6 +213,44 @@ int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w
 /* diffab_pytorch.py:610-625  OrientationLoss: elems (n,3,3) = (pred^T target - I)^2 and/or their total (either may be NULL) */
 int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream);
 
+/* ---- encode_context (reference diffab_pytorch.py:57-312, 680-724) -----------------------------------------
+ * Runs once per sample.  atom_mask is float32 (B,K,A) (1 = atom present); context masks are 1 byte per residue, NULL = "not
+ * given" (the reference passes None when generate_structure / generate_sequence is False). */
+typedef struct {
+  int32_t B, K;
+  int32_t A;        /* atoms per residue (n_atoms, 15) */
+  int32_t D;        /* d_residue_emb */
+  int32_t C;        /* d_pair_emb */
+  int32_t max_dist; /* max_dist_to_consider (32) */
+} diffab_ctx_dims;
+
+typedef struct { /* ResidueEmbedding parameters (:57-79), nn.Linear layout */
+  const float *aa_emb, *chain_emb;        /* (21, D), (10, D) */
+  const float *w0, *b0, *w2, *b2, *w4, *b4, *w6, *b6; /* mlp: (2D, 2D+21*A*3+39) (D,2D) (D,D) (D,D) */
+} diffab_residue_emb_weights;
+
+typedef struct { /* PairEmbedding parameters (:186-218) */
+  const float *aa_pair_emb, *relpos_emb, *pair2distcoef; /* (441, C), (2*max_dist+1, C), (441, A*A) */
+  const float *dw0, *db0, *dw2, *db2;                    /* distance_embedding: (C, A*A), (C, C) */
+  const float *mw0, *mb0, *mw2, *mb2, *mw4, *mb4;        /* mlp: (C, 3C+18), (C, C), (C, C) */
+} diffab_pair_emb_weights;
+
+size_t diffab_residue_embedding_workspace_bytes(const diffab_ctx_dims* d);
+/* ResidueEmbedding.forward (:81-183) -> out (B,K,D) */
+int diffab_residue_embedding_fwd(const diffab_ctx_dims* d, const diffab_residue_emb_weights* w, const int64_t* seq_idx,
+                                 const float* xyz /* (B,K,A,3) */, const float* orientations, const float* dihedrals /* (B,K,3) */,
+                                 const int64_t* chain_idx, const float* atom_mask, const uint8_t* structure_context_mask,
+                                 const uint8_t* sequence_context_mask, float* out, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+size_t diffab_pair_embedding_workspace_bytes(const diffab_ctx_dims* d);
+/* PairEmbedding.forward (:220-312) -> out (B,K,K,C).  residue_idx is (B,K) with batch stride K, or (1,K) with batch stride 0.
+ * The structure-context mask has no effect on this module's output in the reference (:292-301) and is not a parameter. */
+int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx,
+                              const float* distmat /* (B,K,K,A,A) */, const float* pairwise_dihedrals /* (B,K,K,2) */,
+                              const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                              const float* atom_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- reverse process (build-defined; reference stub diffab_pytorch.py:770-776) -- */
 /* One update t -> t-1 from denoiser outputs with explicit noise (z (B,K,3), rotvec (B,K,3), u_seq (B,K)),
  * in place on (seq, x, O), only where gen_mask is set. */

@@ -489,3 +489,84 @@ def uniform_rotation_from_normals(n4):
         ],
         -2,
     )
+
+
+# --------------------------------------------------------------------------
+# encode_context (SURVEY 8f-1)               reference: diffab_pytorch.py:20-312, 680-724
+# --------------------------------------------------------------------------
+
+AA_UNK = 20  # protstruc.general.AA.UNK (reference :115, :273)
+
+
+def angular_encoding(x, num_funcs):
+    """[x, sin(f x), cos(f x)] per input dim, f in [1..n, 1/1..1/n], flattened "(d1 d2)".  (diffab_pytorch.py:20-54)"""
+    freq = torch.tensor([i + 1.0 for i in range(num_funcs)] + [1.0 / (i + 1.0) for i in range(num_funcs)]).float().to(x.dtype)
+    xe = x.unsqueeze(-1)
+    enc = torch.cat([xe, torch.sin(freq * xe), torch.cos(freq * xe)], dim=-1)
+    return enc.flatten(-2)
+
+
+def _mlp(x, sd, prefix, idxs):
+    for n, i in enumerate(idxs):
+        x = x @ sd[f"{prefix}{i}.weight"].to(x.dtype).T + sd[f"{prefix}{i}.bias"].to(x.dtype)
+        if n + 1 < len(idxs):
+            x = torch.relu(x)
+    return x
+
+
+def residue_embedding(sd, seq_idx, xyz, orientation, dihedrals, chain_idx, atom_mask, structure_context_mask=None,
+                      sequence_context_mask=None, prefix="residue_context_embedding."):
+    """ResidueEmbedding.forward  (diffab_pytorch.py:81-183)"""
+    B, L, A, _ = xyz.shape
+    if sequence_context_mask is not None:
+        seq_idx = torch.where(sequence_context_mask.bool(), seq_idx, torch.full_like(seq_idx, AA_UNK))
+    aa = sd[prefix + "amino_acid_type_embedding.weight"][seq_idx]
+    rel = xyz - xyz[:, :, 1:2, :]
+    local = torch.einsum("blji,blaj->blai", orientation, rel) * atom_mask[:, :, :, None]  # O^T (x - x_CA)
+    onehot = torch.nn.functional.one_hot(seq_idx, 21).to(xyz.dtype)  # (B,L,21)
+    coord = (onehot[:, :, :, None, None] * local[:, :, None, :, :]).reshape(B, L, 21 * A * 3)
+    if structure_context_mask is not None:
+        coord = coord * structure_context_mask[:, :, None]
+    dih = angular_encoding(dihedrals, 3)
+    if structure_context_mask is not None:
+        dmask = torch.stack([torch.roll(structure_context_mask, shifts=s, dims=1) for s in range(-1, 1)]).all(dim=0)
+        dih = dih * dmask[:, :, None]
+    chain = sd[prefix + "chain_embedding.weight"][chain_idx]
+    x = torch.cat([aa, coord, dih, chain], dim=-1)
+    return _mlp(x, sd, prefix + "mlp.", (0, 2, 4, 6))
+
+
+def pair_embedding(sd, seq_idx, distmat, dihedrals, residue_idx, chain_idx, atom_mask, structure_context_mask=None,
+                   sequence_context_mask=None, max_dist=32, prefix="pair_context_embedding."):
+    """PairEmbedding.forward  (diffab_pytorch.py:220-312).  The structure-context mask is multiplied into `distmat` only
+    after its last use (:295-301), so it does not reach the output: accepted and ignored, like the reference's effect."""
+    B, L = seq_idx.shape
+    A = atom_mask.shape[-1]
+    am_pair = (atom_mask[:, :, None, :, None] * atom_mask[:, None, :, None, :]).reshape(B, L, L, A * A)
+    rmask = atom_mask[:, :, 1]
+    rmask_pair = rmask[:, :, None] * rmask[:, None, :]
+    if sequence_context_mask is not None:
+        seq_idx = torch.where(sequence_context_mask.bool(), seq_idx, torch.full_like(seq_idx, AA_UNK))
+    sp = seq_idx[:, :, None] * 21 + seq_idx[:, None, :]
+    sp_feat = sd[prefix + "aa_pair_type_embedding.weight"][sp]
+    same_chain = chain_idx[:, :, None] * chain_idx[:, None, :]  # a product (:279)
+    rel = (residue_idx[:, :, None] - residue_idx[:, None, :]).clamp(-max_dist, max_dist)
+    rel_feat = sd[prefix + "relpos_embedding.weight"][rel + max_dist] * same_chain[:, :, :, None]
+    coef = torch.nn.functional.softplus(sd[prefix + "pair2distcoef.weight"][sp])
+    dm = torch.exp(-1 * coef * distmat.reshape(B, L, L, A * A) ** 2)
+    dist_feat = torch.relu(_mlp(dm * am_pair, sd, prefix + "distance_embedding.", (0, 2)))
+    dih = angular_encoding(dihedrals, 2)
+    x = torch.cat([sp_feat, rel_feat.expand(B, L, L, -1), dist_feat, dih], dim=-1)
+    return _mlp(x, sd, prefix + "mlp.", (0, 2, 4)) * rmask_pair[:, :, :, None]
+
+
+def encode_context(sd, batch, generate_structure=True, generate_sequence=True, max_dist=32):
+    """DiffAb.encode_context  (diffab_pytorch.py:680-724)"""
+    ctx = batch["residue_mask"].bool() & (~batch["generation_mask"].bool())
+    sm = ctx if generate_structure else None
+    qm = ctx if generate_sequence else None
+    res = residue_embedding(sd, batch["seq_idx"], batch["xyz"], batch["orientations"], batch["backbone_dihedrals"], batch["chain_idx"],
+                            batch["atom_mask"], sm, qm)
+    pair = pair_embedding(sd, batch["seq_idx"], batch["distmat"], batch["pairwise_dihedrals"], batch["residue_idx"], batch["chain_idx"],
+                          batch["atom_mask"], sm, qm, max_dist)
+    return res, pair

@@ -327,6 +327,29 @@ def main():
         g["grad/" + n_] = npf(p_.grad)
     np.savez_compressed(os.path.join(GOLD, "losses_grads.npz"), **g)
 
+    # ---------------------------------------------------------------- encode_context through the real DiffAb
+    print("encode_context (ResidueEmbedding + PairEmbedding), 4 flag combinations")
+    D_, C_, A_, Kc, Bc = 32, 16, 15, 12, 2
+    ref_model = rmod.DiffAb(D_, C_, 1, 12, 4, 4, 8).eval()
+    csd = syn.context_state_dict(D_, C_, A_, 32, seed=41)
+    missing = ref_model.load_state_dict(csd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("denoiser.") for k in missing.missing_keys)
+    cb = syn.context_batch(Bc, Kc, A_, seed=41)
+    g = {"meta": np.array([Bc, Kc, A_, D_, C_, 41])}
+    for gs in (True, False):
+        for gq in (True, False):
+            with torch.no_grad():
+                res_ref, pair_ref = ref_model.encode_context(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"],
+                                                             cb["distmat"].clone(), cb["pairwise_dihedrals"], cb["atom_mask"], cb["chain_idx"],
+                                                             cb["residue_idx"], cb["generation_mask"], cb["residue_mask"],
+                                                             generate_structure=gs, generate_sequence=gq)
+            res_o, pair_o = orc.encode_context(csd, cb, gs, gq)
+            check(f"encode_context res  gs={gs} gq={gq}", res_o, res_ref, 2e-6)
+            check(f"encode_context pair gs={gs} gq={gq}", pair_o, pair_ref, 2e-6)
+            g[f"res_{int(gs)}{int(gq)}"] = npf(res_ref)
+            g[f"pair_{int(gs)}{int(gq)}"] = npf(pair_ref)
+    np.savez_compressed(os.path.join(GOLD, "encode_context.npz"), **g)
+
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print(f"wrote {len(os.listdir(GOLD))} fixtures, {tot/1024:.0f} KiB, under {GOLD}")
 

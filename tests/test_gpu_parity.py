@@ -513,8 +513,6 @@ def test_shared_step_and_add_noise(hip):
     assert l1 == l2 and all(np.isfinite(l1)) and all(v >= 0 for v in l1)
     loss = model.validation_step(batch, 0)
     assert torch.isfinite(loss) and not loss.requires_grad
-    with pytest.raises(NotImplementedError):
-        model.encode_context(*[None] * 11)
 
 
 def test_argument_errors_are_reported_not_crashed(hip):
@@ -652,3 +650,58 @@ def test_training_step_runs_and_learns(hip):
               "sequence_denoising.4.weight", "ipa.layers.1.to_out.weight", "ipa.layers.0.to_k_point.weight"):
         got = dict(big.denoiser.named_parameters())[n].grad
         assert maxrel(got, sdo["denoiser." + n].grad) < 5e-4, (n, maxrel(got, sdo["denoiser." + n].grad))
+
+
+# ------------------------------------------------------------------ encode_context
+def test_encode_context_vs_reference_goldens(hip, golden):
+    from diffab_pytorch import DiffAb
+
+    g = golden("encode_context")
+    Bc, Kc, A_, D_, C_, seed = [int(v) for v in g["meta"]]
+    model = DiffAb(D_, C_, 1, 12, 4, 4, 8).cuda()
+    missing = model.load_state_dict(syn.context_state_dict(D_, C_, A_, 32, seed=seed), strict=False)
+    assert not missing.unexpected_keys
+    cb = syn.context_batch(Bc, Kc, A_, seed=seed)
+    for gs in (True, False):
+        for gq in (True, False):
+            res, pair = model.encode_context(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], cb["distmat"],
+                                             cb["pairwise_dihedrals"], cb["atom_mask"], cb["chain_idx"], cb["residue_idx"],
+                                             cb["generation_mask"], cb["residue_mask"], generate_structure=gs, generate_sequence=gq)
+            assert res.shape == (Bc, Kc, D_) and pair.shape == (Bc, Kc, Kc, C_)
+            assert maxrel(res, g[f"res_{int(gs)}{int(gq)}"]) < 1e-5, (gs, gq, maxrel(res, g[f"res_{int(gs)}{int(gq)}"]))
+            assert maxrel(pair, g[f"pair_{int(gs)}{int(gq)}"]) < 1e-5, (gs, gq, maxrel(pair, g[f"pair_{int(gs)}{int(gq)}"]))
+
+
+def test_encode_context_benchmark_dims_and_end_to_end(hip):
+    """Benchmark model (D=128, C=64, A=15), K=64, vs the oracle; then the whole chain on the device: encode_context ->
+    _shared_step (no precomputed contexts) -> sample."""
+    from diffab_pytorch import DiffAb
+
+    d = syn.BENCH_DIMS
+    torch.manual_seed(0)
+    model = DiffAb(d["D"], d["C"], 2, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    csd = syn.context_state_dict(d["D"], d["C"], 15, 32, seed=7)
+    model.load_state_dict(csd, strict=False)
+    B, K = 3, 64
+    cb = syn.context_batch(B, K, 15, seed=7)
+    dev = {k: v.cuda() for k, v in cb.items()}
+    res, pair = model.encode_context(dev["seq_idx"], dev["xyz"], dev["orientations"], dev["backbone_dihedrals"], dev["distmat"],
+                                     dev["pairwise_dihedrals"], dev["atom_mask"], dev["chain_idx"], dev["residue_idx"],
+                                     dev["generation_mask"], dev["residue_mask"])
+    assert res.is_cuda and pair.is_cuda
+    res_o, pair_o = orc.encode_context(csd, cb, True, True)
+    assert maxrel(res, res_o) < 1e-5 and maxrel(pair, pair_o) < 1e-5, (maxrel(res, res_o), maxrel(pair, pair_o))
+    # (B, K) residue_idx gives the same result as the broadcast (1, K) form
+    dev2 = dict(dev, residue_idx=dev["residue_idx"].expand(B, K).contiguous())
+    _, pair2 = model.encode_context(dev2["seq_idx"], dev2["xyz"], dev2["orientations"], dev2["backbone_dihedrals"], dev2["distmat"],
+                                    dev2["pairwise_dihedrals"], dev2["atom_mask"], dev2["chain_idx"], dev2["residue_idx"],
+                                    dev2["generation_mask"], dev2["residue_mask"])
+    assert torch.equal(pair2, pair)
+    batch = dict(dev)  # reference batch dict (SURVEY B.2): no precomputed contexts
+    with torch.no_grad():
+        torch.manual_seed(3)
+        ls = model._shared_step(batch, 0)
+    assert all(torch.isfinite(x) for x in ls)
+    out = model.sample(dev["seq_idx"], dev["xyz"], dev["orientations"], res_context_emb=res, pair_context_emb=pair,
+                       generation_mask=dev["generation_mask"], seed=5, t_start=100, t_stop=90)
+    assert torch.isfinite(out["translations"]).all() and out["translations"].shape == (B, K, 3)

@@ -149,3 +149,19 @@ def test_categorical_and_reverse_update_properties():
     s1, x1, O1 = orc.reverse_update(1, seq, x, O, den, m, sched, torch.full_like(x, 1e9), torch.full_like(x, 1.0), torch.rand(2, 5))
     assert torch.equal(x1[~m], x[~m]) and torch.equal(O1[~m], O[~m]) and torch.equal(s1[~m], seq[~m])
     assert torch.equal(O1[m], den["orientations_t0"][m]) and x1.abs().max() < 1e6
+
+
+def test_encode_context_oracle_vs_golden(golden):
+    """ResidueEmbedding + PairEmbedding through DiffAb.encode_context, 4 flag combinations."""
+    g = golden("encode_context")
+    Bc, Kc, A_, D_, C_, seed = [int(v) for v in g["meta"]]
+    sd = syn.context_state_dict(D_, C_, A_, 32, seed=seed)
+    cb = syn.context_batch(Bc, Kc, A_, seed=seed)
+    for gs in (True, False):
+        for gq in (True, False):
+            res, pair = orc.encode_context(sd, cb, gs, gq)
+            assert maxrel(res, g[f"res_{int(gs)}{int(gq)}"]) < 2e-6
+            assert maxrel(pair, g[f"pair_{int(gs)}{int(gq)}"]) < 2e-6
+    # the flags matter (sequence masking changes both outputs, structure masking only the residue embedding)
+    assert not np.allclose(g["res_11"], g["res_01"]) and not np.allclose(g["res_11"], g["res_10"])
+    assert not np.allclose(g["pair_11"], g["pair_10"]) and np.array_equal(g["pair_11"], g["pair_01"])
