@@ -183,6 +183,13 @@ constexpr int TI = 16;  // query residues per work-group
 // Compile-time fence for memory operations: keeps the hand-placed prefetch loads where they are written (hipcc otherwise
 // sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
 #define MEM_FENCE() asm volatile("" ::: "memory")
+// softmax exponentials: v_exp_f32 path (2^(x log2 e)); arguments are <= 0 and the relative error (<~ |x| 1e-7) is far inside the
+// 1e-4 parity bar (measured ~2e-6 on the outputs).  -DDIFFAB_ACCURATE_EXP restores the libm expf expansion (~12 VALU ops each).
+#ifdef DIFFAB_ACCURATE_EXP
+#define FAST_EXP(x) expf(x)
+#else
+#define FAST_EXP(x) __expf(x)
+#endif
 
 // NT: key tiles (16 keys each) per chunk: 8 when K % 128 == 0, else 4; compile-time so per-lane arrays stay in VGPRs.
 // MULTI: more than one chunk.  The single-chunk instantiation (K = 64, 128) has NC == 1 at compile time: the chunk loop and every
@@ -402,18 +409,21 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int jt = 0; jt < NT; ++jt) {
           if (jt + 1 < NT) stage_e(ii, jt + 1);
           const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains of 8: half the dependent-MFMA latency
 #pragma unroll
           for (int sg = 0; sg < 4; ++sg) {
             const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
             const f32x4 wbf = MULTI ? *reinterpret_cast<const f32x4*>(wb_lds + (sg * 64 + lane) * 4) : wb[sg];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+              if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc2, 0, 0, 0);
+              else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
+            }
           }
           const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = sv[r] + scale_t * acc[r];
+            const float v = sv[r] + scale_t * (acc[r] + acc2[r]);
             lg[jt][r] = v;
             mx = fmaxf(mx, v);
           }
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = expf(lg[jt][r] - Mnew);
+            const float p = FAST_EXP(lg[jt][r] - Mnew);
             lg[jt][r] = p;
             sum += p;
           }
