@@ -16,6 +16,8 @@
 //    row tiles of a patch, which the blockIdx map places on one XCD so the re-reads are L2 hits.
 //
 // Reference: InvariantPointAttentionLayer.forward, diffab_pytorch.py:389-465.
+#include <type_traits>
+
 #include "common.h"
 #include "denoiser_internal.h"
 
@@ -23,6 +25,10 @@ namespace diffab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Compile-time fence for memory operations: keeps the hand-placed prefetch loads where they are written (hipcc otherwise
+// sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
+#define MEM_FENCE() asm volatile("" ::: "memory")
 
 // ================================================================== Y = act(X W^T + b) on MFMA 32x32x2
 constexpr int LBM = 128, LBK = 32, LLD = LBK + 4;  // LDS row stride 36 floats: ds_read_b128 conflict-free
@@ -158,6 +164,153 @@ static int launch_linear_bn(const float* X, int ldx, const LinearSegs& segs, con
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ================================================================== Y[M x 128] = act(X[M x K] W^T + b), K % 128 == 0
+// The to_out projection (K = 1024) and the 128-wide MLP layers.  With N = 128 the tiled kernel above has one 4-wave work-group
+// per CU (a 1 x M/128 grid) and nothing to hide latency with.  Here a work-group of 8 waves owns 128 rows and ALL 128 columns:
+// wave (rw, cw) accumulates a 32 x 64 tile in registers, takes its A fragments straight from global memory (a row slab is not
+// shared between waves, so staging it through LDS buys nothing), double-buffered one 64-wide K chunk ahead, and only the weight
+// chunk [128][64] goes through LDS (double-buffered, one barrier per chunk).  The MFMA n index is permuted (tile tt, lane column j
+// <-> output column 4 j + tt of the wave's 64) so a lane ends with 4 consecutive columns: float4 stores, 256 contiguous bytes per
+// 16 lanes.
+constexpr int RG_KC = 64, RG_LD = RG_KC + 4;
+#ifndef RG_MT
+#define RG_MT 2  // 16-row MFMA tiles per wave: 2 -> 128 rows per work-group (1 -> 64 rows, two work-groups per CU: measured slower)
+#endif
+constexpr int RG_ROWS = 64 * RG_MT;
+#ifndef RG_DEEP_A
+#define RG_DEEP_A 0  // 1: A register sets span two weight chunks (deeper prefetch) - measured SLOWER (101 vs 88 us at K = 1024)
+#endif
+
+// AW: weight chunks (64 k) per A register set.  The A fragments of set n+1 are requested while set n is consumed, so AW = 2
+// doubles the prefetch distance (2 x 3.5 us of MFMA work at K = 1024): with AW = 1 every CU asks for its next 64 KiB at the same
+// instant after each barrier and the burst (16 MiB chip-wide) does not drain within one chunk of compute.
+template <bool RELU, int AW>
+__global__ __launch_bounds__(512, RG_MT == 1 ? 2 : 1) void rowgemm128_kernel(const float* __restrict__ X, int ldx,
+                                                                            const float* __restrict__ W,
+                                                                            const float* __restrict__ bias, float* __restrict__ Y,
+                                                                            int ldy, int M, int Kd) {
+  constexpr int MT = RG_MT;
+  __shared__ __attribute__((aligned(16))) float Ws[2 * 128 * RG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4, rw = wv & 3, cw = wv >> 2;
+  const int m0 = blockIdx.x * RG_ROWS;
+  const int nchunk = Kd / RG_KC;  // a multiple of 2 AW (launcher)
+
+  // weight staging: thread -> (LDS row l = 32 r + tid / 16, float4 column tid % 16); LDS row l = 64 cw' + 16 tt + j <-> W row 64 cw' + 4 j + tt
+  f32x4 wreg[4];
+  const float* wsrc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int l = 32 * r + (tid >> 4), c4 = tid & 15;
+    const int n = (l & 64) + 4 * (l & 15) + ((l >> 4) & 3);
+    wsrc[r] = W + static_cast<int64_t>(n) * Kd + 4 * c4;
+  }
+  auto load_w = [&](int ch) {
+#ifdef RG_ABL_NOW
+    if (ch > 0) return;
+#endif
+    ch = ch < nchunk ? ch : nchunk - 1;  // unconditional prefetch: the last trips re-read the final chunk
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc[r] + ch * RG_KC);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int l = 32 * r + (tid >> 4), c4 = tid & 15;
+      *reinterpret_cast<f32x4*>(&Ws[(buf * 128 + l) * RG_LD + 4 * c4]) = wreg[r];
+    }
+  };
+  // A fragments: a[mt][kq][s] = X[m0 + 16 MT rw + 16 mt + l15][64 AW set + 16 kq + 4 g + s], kq < 4 AW; rows past M are clamped
+  // (their results are never stored)
+  const float* asrc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int row = m0 + 16 * MT * rw + 16 * mt + l15;
+    row = row < M ? row : M - 1;
+    asrc[mt] = X + static_cast<int64_t>(row) * ldx + 4 * g;
+  }
+  const int nset = nchunk / AW;
+  f32x4 aA[MT][4 * AW], aB[MT][4 * AW];
+  auto load_a = [&](f32x4 (&a)[MT][4 * AW], int set) {
+#ifdef RG_ABL_NOA
+    if (set > 0) return;
+#endif
+    set = set < nset ? set : nset - 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int kq = 0; kq < 4 * AW; ++kq) a[mt][kq] = *reinterpret_cast<const f32x4*>(asrc[mt] + set * (RG_KC * AW) + 16 * kq);
+  };
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[mt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one weight chunk: `part` selects which 64 k of the A set it pairs with
+  auto compute = [&](const f32x4 (&a)[MT][4 * AW], int part, int buf) {
+    const float* Wl = Ws + (buf * 128 + 64 * cw + l15) * RG_LD + 4 * g;
+    f32x4 b[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) b[0][tt] = *reinterpret_cast<const f32x4*>(Wl + 16 * tt * RG_LD);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      if (kq + 1 < 4) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) b[(kq + 1) & 1][tt] = *reinterpret_cast<const f32x4*>(Wl + 16 * tt * RG_LD + 16 * (kq + 1));
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+            acc[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][4 * part + kq][s], b[kq & 1][tt][s], acc[mt][tt], 0, 0, 0);
+    }
+  };
+
+  load_w(0);
+  load_a(aA, 0);
+  store_w(0);
+  __syncthreads();
+  // 2 AW weight chunks per trip so the A register sets and the LDS buffers alternate statically.  All prefetches are
+  // UNCONDITIONAL (indices are clamped): a branch around them makes the compiler's vmcnt bookkeeping fall back to the no-prefetch
+  // path's count, i.e. every chunk waits for the loads just issued.
+  for (int ch = 0; ch < nchunk; ch += 2 * AW) {
+    load_a(aB, ch / AW + 1);
+#pragma unroll
+    for (int p = 0; p < AW; ++p) {
+      load_w(ch + p + 1);
+      MEM_FENCE();
+      compute(aA, p, p & 1);
+      store_w((p + 1) & 1);
+      __syncthreads();
+    }
+    load_a(aA, ch / AW + 2);
+#pragma unroll
+    for (int p = 0; p < AW; ++p) {
+      load_w(ch + AW + p + 1);
+      MEM_FENCE();
+      compute(aB, p, (AW + p) & 1);
+      store_w((AW + p + 1) & 1);
+      __syncthreads();
+    }
+  }
+  // lane holds columns 64 cw + 4 l15 + (0..3) of rows 16 MT rw + 16 mt + 4 g + r
+  const int col = 64 * cw + 4 * l15;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * MT * rw + 16 * mt + 4 * g + r;
+      f32x4 o = {acc[mt][0][r] + bv[0], acc[mt][1][r] + bv[1], acc[mt][2][r] + bv[2], acc[mt][3][r] + bv[3]};
+      if (RELU) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+      if (row < M) *reinterpret_cast<f32x4*>(Y + static_cast<int64_t>(row) * ldy + col) = o;
+    }
+}
+
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st) {
   LinearSegs segs{};
@@ -165,6 +318,17 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
   segs.n_end[0] = N;
   segs.nseg = 1;
   const bool vec = (ldx % 4 == 0) && (Kd % 4 == 0) && aligned16(X) && aligned16(W);
+#ifndef DIFFAB_NO_ROWGEMM
+  if (N == 128 && vec && Kd % (2 * RG_KC) == 0 && ldy % 4 == 0 && aligned16(Y) && (!bias || aligned16(bias)) && M >= RG_ROWS) {
+    const dim3 grid((M + RG_ROWS - 1) / RG_ROWS);
+#define RG_LAUNCH(R, AW_) hipLaunchKernelGGL((rowgemm128_kernel<R, AW_>), grid, dim3(512), 0, st, X, ldx, W, bias, Y, ldy, M, Kd)
+    if (RG_DEEP_A && Kd % (4 * RG_KC) == 0) { if (relu) RG_LAUNCH(true, 2); else RG_LAUNCH(false, 2); }
+    else                       { if (relu) RG_LAUNCH(true, 1); else RG_LAUNCH(false, 1); }
+#undef RG_LAUNCH
+    DIFFAB_LAUNCH_CHECK();
+    return DIFFAB_OK;
+  }
+#endif
   if (N > 64) return launch_linear_bn<128>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
   return launch_linear_bn<64>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
 }
@@ -180,9 +344,6 @@ constexpr int TI = 16;  // query residues per work-group
 // LDS strides of the logits/probabilities image: head stride K + 8 (== 8 mod 64 for K % 64 == 0) and row stride
 // 8 (K + 8) + 8 keep both the (head, quarter)-lane and the (row, quarter)-lane ds_read_b128 patterns conflict-free.
 
-// Compile-time fence for memory operations: keeps the hand-placed prefetch loads where they are written (hipcc otherwise
-// sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
-#define MEM_FENCE() asm volatile("" ::: "memory")
 // softmax exponentials: v_exp_f32 path (2^(x log2 e)); arguments are <= 0 and the relative error (<~ |x| 1e-7) is far inside the
 // 1e-4 parity bar (measured ~2e-6 on the outputs).  -DDIFFAB_ACCURATE_EXP restores the libm expf expansion (~12 VALU ops each).
 #ifdef DIFFAB_ACCURATE_EXP
@@ -598,6 +759,189 @@ __global__ void points_to_global_fast_kernel(float* __restrict__ proj, const flo
   qv[2] = (x * Rr[2] + y * Rr[5] + z * Rr[8]) + t[r * 3 + 2];
 }
 
+// ================================================================== six projections + local->global frames in one kernel
+// proj[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T with the three point blocks mapped to the global frame
+// (x R + t, row-vector convention of diffab_pytorch.py:324) before they are stored.
+//
+// x-stationary: a work-group owns 128 rows of x for the whole kernel and every wave keeps its 32 x 128 slab as MFMA A fragments
+// in 64 VGPRs, so x is read from HBM exactly once and the LDS only double-buffers 96-column blocks of the weights (14 blocks).
+// Inside a block the MFMA n index is permuted: tile tt (0..2), lane column j holds output column 3 j + tt of the wave's 48, so a
+// lane ends up with three CONSECUTIVE output columns per row - a whole (x, y, z) point in the point blocks, and a 12-byte
+// store (16 lanes = 192 contiguous bytes) everywhere.  The previous block's epilogue is issued between the MFMAs of the
+// current one (two accumulator sets), which keeps the matrix pipe fed across the one barrier per block.
+constexpr int PJB = 96, PJLD = 132, PJROWS = 128, PJNB = ANP / PJB;  // 14 blocks
+static_assert(ANP % PJB == 0 && OFF_GQ % PJB == 0, "projection blocks must tile the scalar and point column ranges");
+struct __attribute__((packed, aligned(4))) pj_f3 { float x, y, z; };
+
+struct PjW {  // the six weight matrices, by value (kept in SGPRs)
+  const float *w0, *w1, *w2, *w3, *w4, *w5;
+};
+struct PjCtx {  // per-thread constants of proj_frames_kernel
+  float* PW;
+  float* Rt;
+  float* ybase;
+  int tid, l15, g, rw, cw, m0, M;
+};
+
+// weight staging: thread -> (LDS row l = 16 r + tid / 32, float4 column tid % 32); LDS row l = 48 cw' + 16 tt + j holds output
+// column 48 cw' + 3 j + tt of the block.  The six weight pointers stay in SGPRs (selects, no indexed kernarg loads).
+__device__ __forceinline__ void pj_load_w(const PjCtx& c, const PjW w, int blk, f32x4 (&wreg)[6]) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int l = 16 * r + (c.tid >> 5), c4 = c.tid & 31;
+    const int cwl = l / 48, rem = l % 48, tt = rem >> 4, j = rem & 15;
+    const int gc = PJB * blk + 48 * cwl + 3 * j + tt;
+    const float* Wp;
+    int row;
+    if (gc < OFF_GQ) {
+      Wp = gc < OFF_KS ? w.w0 : (gc < OFF_VS ? w.w1 : w.w2);
+      row = gc & 255;
+    } else {
+      Wp = gc < OFF_GK ? w.w3 : (gc < OFF_GV ? w.w4 : w.w5);
+      row = gc - (gc < OFF_GK ? OFF_GQ : (gc < OFF_GV ? OFF_GK : OFF_GV));
+    }
+    wreg[r] = *reinterpret_cast<const f32x4*>(Wp + row * 128 + 4 * c4);
+  }
+}
+__device__ __forceinline__ void pj_store_w(const PjCtx& c, int buf, const f32x4 (&wreg)[6]) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int l = 16 * r + (c.tid >> 5), c4 = c.tid & 31;
+    *reinterpret_cast<f32x4*>(&c.PW[(buf * PJB + l) * PJLD + 4 * c4]) = wreg[r];
+  }
+}
+// one (mt, r) slice of a finished block: 3 consecutive columns of one row per lane
+template <bool FULL, bool FRAMES>
+__device__ __forceinline__ void pj_epilogue_piece(const PjCtx& c, const f32x4 (&acc)[2][3], int blk, int piece) {
+  const int mt = piece >> 2, r = piece & 3;
+  const int lrow = 32 * c.rw + 16 * mt + 4 * c.g + r;
+  float vx = acc[mt][0][r], vy = acc[mt][1][r], vz = acc[mt][2][r];
+  if (FRAMES) {
+    const f32x4* F = reinterpret_cast<const f32x4*>(c.Rt + lrow * 12);
+    const f32x4 f0 = F[0], f1 = F[1], f2 = F[2];  // R row-major 0..8, t 9..11
+    const float ox = (vx * f0[0] + vy * f0[3] + vz * f1[2]) + f2[1];
+    const float oy = (vx * f0[1] + vy * f1[0] + vz * f1[3]) + f2[2];
+    const float oz = (vx * f0[2] + vy * f1[1] + vz * f2[0]) + f2[3];
+    vx = ox; vy = oy; vz = oz;
+  }
+#ifdef PJ_ABL_NOSTORE
+  if (c.M < 0) {
+#else
+  if (FULL || c.m0 + lrow < c.M) {
+#endif
+    pj_f3 o{vx, vy, vz};
+    *reinterpret_cast<pj_f3*>(c.ybase + (16 * mt + r) * ANP + PJB * blk) = o;
+  }
+}
+template <bool FULL, bool HAVE_PREV, bool PREV_FRAMES>
+__device__ __forceinline__ void pj_run_block(const PjCtx& c, const PjW w, const f32x4 (&a)[2][8], f32x4 (&wreg)[6], f32x4 (&cur)[2][3],
+                                             const f32x4 (&prev)[2][3], int blk) {
+#ifndef PJ_ABL_NOWLOAD
+  if (blk + 1 < PJNB) pj_load_w(c, w, blk + 1, wreg);
+#endif
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) cur[mt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* Wl = c.PW + ((blk & 1) * PJB + 48 * c.cw + c.l15) * PJLD + 4 * c.g;
+  f32x4 b[2][3];
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt) b[0][tt] = *reinterpret_cast<const f32x4*>(Wl + 16 * tt * PJLD);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (q + 1 < 8) {
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) b[(q + 1) & 1][tt] = *reinterpret_cast<const f32x4*>(Wl + 16 * tt * PJLD + 16 * (q + 1));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+          cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q][s], b[q & 1][tt][s], cur[mt][tt], 0, 0, 0);
+    // The next block's weights go to LDS (q = 1) BEFORE this block issues any global store (q = 2..7): on gfx9 a wait for loads
+    // with stores in flight degenerates to vmcnt(0), i.e. to waiting for the L2 acknowledgement of the newest store (measured:
+    // 8 % of the kernel when the wait sat right behind the last store of the block).
+#ifndef PJ_ABL_NOWLOAD
+    if (q == 1 && blk + 1 < PJNB) pj_store_w(c, (blk + 1) & 1, wreg);
+#endif
+    if (HAVE_PREV) {  // 8 epilogue slices of the previous block spread over q = 2..7
+      if (q == 2) { pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 0); pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 1); }
+      if (q == 3) { pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 2); pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 3); }
+      if (q >= 4) pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, q);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep each slice's stores where they are (the scheduler otherwise sinks all 8 to the barrier)
+  }
+#ifndef PJ_ABL_NOBARRIER
+  __syncthreads();
+#endif
+}
+
+template <bool FULL>  // FULL: M is a multiple of 128, no row guards
+__global__ __launch_bounds__(512) void proj_frames_kernel(const float* __restrict__ X, const float* __restrict__ W0,
+                                                          const float* __restrict__ W1, const float* __restrict__ W2,
+                                                          const float* __restrict__ W3, const float* __restrict__ W4,
+                                                          const float* __restrict__ W5, const float* __restrict__ R,
+                                                          const float* __restrict__ t, float* __restrict__ Y, int M) {
+  extern __shared__ __attribute__((aligned(16))) float PW[];  // [2][PJB][PJLD] weights, then [PJROWS][12] frames
+  PjCtx c;
+  PjW w;
+  {  // pin the six weight pointers in SGPRs: without this the selects in pj_load_w become per-lane indexed loads of the
+     // pointer itself (a dependent memory round trip in front of every weight load)
+    const float *w0 = W0, *w1 = W1, *w2 = W2, *w3 = W3, *w4 = W4, *w5 = W5;
+    asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5));
+    w = PjW{w0, w1, w2, w3, w4, w5};
+  }
+  c.PW = PW;
+  c.Rt = PW + 2 * PJB * PJLD;
+  c.tid = threadIdx.x;
+  const int lane = c.tid & 63, wv = c.tid >> 6;
+  c.l15 = lane & 15; c.g = lane >> 4; c.rw = wv & 3; c.cw = wv >> 2;
+  c.m0 = blockIdx.x * PJROWS;
+  c.M = M;
+  c.ybase = Y + static_cast<int64_t>(c.m0 + 32 * c.rw + 4 * c.g) * ANP + 48 * c.cw + 3 * c.l15;
+
+  f32x4 wreg[6];
+  pj_load_w(c, w, 0, wreg);
+  // A fragments: a[mt][q][s] = x[m0 + 32 rw + 16 mt + l15][16 q + 4 g + s]
+  f32x4 a[2][8];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = c.m0 + 32 * c.rw + 16 * mt + c.l15;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (FULL || row < M) v = *reinterpret_cast<const f32x4*>(X + static_cast<int64_t>(row) * 128 + 16 * q + 4 * c.g);
+      a[mt][q] = v;
+    }
+  }
+  for (int idx = c.tid; idx < PJROWS * 12; idx += 512) {
+    const int row = idx / 12, cc = idx % 12, gr = c.m0 + row;
+    float v = 0.0f;
+    if (FULL || gr < M) v = cc < 9 ? R[static_cast<int64_t>(gr) * 9 + cc] : t[static_cast<int64_t>(gr) * 3 + (cc - 9)];
+    c.Rt[idx] = v;
+  }
+  pj_store_w(c, 0, wreg);
+  __syncthreads();
+
+  f32x4 accA[2][3], accB[2][3];
+  constexpr int FIRST_PT = OFF_GQ / PJB;  // 8: blocks 0..7 are the scalar q/k/v columns, 8..13 the point columns
+  static_assert(FIRST_PT % 2 == 0 && PJNB % 2 == 0, "block schedule below assumes even counts");
+  pj_run_block<FULL, false, false>(c, w, a, wreg, accA, accB, 0);
+  for (int blk = 1; blk < FIRST_PT; blk += 2) {  // previous block is a scalar block
+    pj_run_block<FULL, true, false>(c, w, a, wreg, accB, accA, blk);
+    pj_run_block<FULL, true, false>(c, w, a, wreg, accA, accB, blk + 1);
+  }
+  for (int blk = FIRST_PT + 1; blk + 1 < PJNB; blk += 2) {  // previous block is a point block
+    pj_run_block<FULL, true, true>(c, w, a, wreg, accB, accA, blk);
+    pj_run_block<FULL, true, true>(c, w, a, wreg, accA, accB, blk + 1);
+  }
+  pj_run_block<FULL, true, true>(c, w, a, wreg, accB, accA, PJNB - 1);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) pj_epilogue_piece<FULL, true>(c, accB, PJNB - 1, q);
+}
+
 bool fast_path_supported(const diffab_dims* d) {
   return d->D == 128 && d->C == AC && d->H == AH && d->DS == ADS && d->PQ == AP && d->PV == AP && d->K % 64 == 0 && d->K >= 64 &&
          d->K <= 1024;  // any multiple of 64: keys are processed in chunks of 128 (or 64) with an online softmax
@@ -620,9 +964,27 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   segs.nseg = 6;
   bool vec = aligned16(x);
   for (int s = 0; s < 6; ++s) vec = vec && aligned16(segs.W[s]);
+#ifdef DIFFAB_PROJ_TWO_KERNELS  // previous formulation, kept for A/B timing: tiled GEMM, then an in-place frame pass
   if (int rc = launch_linear_bn<64>(x, D, segs, nullptr, proj, ANP, rows, ANP, D, false, vec, st)) return rc;
   hipLaunchKernelGGL(points_to_global_fast_kernel, dim3((rows * 192 + 255) / 256), dim3(256), 0, st, proj, R, t, rows);
   DIFFAB_LAUNCH_CHECK();
+#else
+  DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
+  {
+    const size_t pj_lds = (2 * PJB * PJLD + PJROWS * 12) * sizeof(float);
+#define PROJ_LAUNCH(FULL_)                                                                                                        \
+  do {                                                                                                                            \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_kernel<FULL_>),                                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pj_lds)));                  \
+    hipLaunchKernelGGL((proj_frames_kernel<FULL_>), dim3((rows + PJROWS - 1) / PJROWS), dim3(512), pj_lds, st, x, segs.W[0],      \
+                       segs.W[1], segs.W[2], segs.W[3], segs.W[4], segs.W[5], R, t, proj, rows);                                  \
+  } while (0)
+    if (rows % PJROWS == 0) PROJ_LAUNCH(true);
+    else PROJ_LAUNCH(false);
+#undef PROJ_LAUNCH
+    DIFFAB_LAUNCH_CHECK();
+  }
+#endif
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
   const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
