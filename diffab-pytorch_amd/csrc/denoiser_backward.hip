@@ -112,13 +112,17 @@ __global__ void relu_mask_kernel(float* __restrict__ dY, const float* __restrict
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i < n && !(act[i] > 0.0f)) dY[i] = 0.0f;
 }
-__global__ void colsum_kernel(const float* __restrict__ dY, int ld, int M, int N, int m_chunk, float* __restrict__ db) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dY, int ld, int M, int N, int m_chunk, float* __restrict__ db) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
   const int lo = blockIdx.y * m_chunk, hi = min(M, lo + m_chunk);
   float s = 0.f;
-  for (int m = lo; m < hi; ++m) s += dY[static_cast<int64_t>(m) * ld + n];
-  atomicAdd(db + n, s);
+  if (n < N)
+    for (int m = lo + ty; m < hi; m += 4) s += dY[static_cast<int64_t>(m) * ld + n];
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) atomicAdd(db + n, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
 }
 
 static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st) {
@@ -128,7 +132,71 @@ static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, i
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
+// MFMA version of the weight-gradient product for 16-byte-aligned operands and N1, N2 multiples of 64: one wave per 64 x 64 tile
+// of C and per chunk of M.  Both operands are read along their contiguous (n) direction: lane (l15, g) loads the float4
+// A[m + g][a0 + 4 l15 ..] and B[m + g][b0 + 4 l15 ..]; component c of the A vector is row 4 l15 + c of the tile and component c' of
+// the B vector column 4 l15 + c', so the 16 MFMAs (c, c') of a step fill 16 accumulators whose (row, col) = (l15, l15') element
+// is C[4 l15 + c][4 l15' + c'].  Two 1 KiB loads feed 16 MFMAs - no LDS staging needed.
+typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                           float* __restrict__ C, int ldc, int M, int m_chunk) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+  const int m_lo = (blockIdx.z * 4 + wv) * m_chunk, m_hi = min(M, m_lo + m_chunk);
+  if (m_lo >= M) return;
+  tn_f32x4 acc[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) acc[c][d] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = A + static_cast<int64_t>(m_lo + g) * lda + a0 + 4 * l15;
+  const float* bp = Bm + static_cast<int64_t>(m_lo + g) * ldb + b0 + 4 * l15;
+  constexpr int U = 4;  // steps (of 4 rows of M) in flight
+  tn_f32x4 va[U], vb[U];
+  auto load = [&](int u, int m) {
+    const bool ok = m + g < m_hi;
+    va[u] = ok ? *reinterpret_cast<const tn_f32x4*>(ap + static_cast<int64_t>(m - m_lo) * lda) : tn_f32x4{0.f, 0.f, 0.f, 0.f};
+    vb[u] = ok ? *reinterpret_cast<const tn_f32x4*>(bp + static_cast<int64_t>(m - m_lo) * ldb) : tn_f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) load(u, m_lo + 4 * u);
+  for (int m = m_lo; m < m_hi; m += 4 * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const tn_f32x4 xa = va[u], xb = vb[u];
+      load(u, m + 4 * (U + u));  // rows past m_hi load zeros
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], xb[d], acc[c][d], 0, 0, 0);
+    }
+  }
+  // D layout: acc[c][d][r] = tile row 4 (4 g + r) + c, tile column 4 l15 + d
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* crow = C + static_cast<int64_t>(a0 + 4 * (4 * g + r) + c) * ldc + b0 + 4 * l15;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) atomicAdd(crow + d, acc[c][d][r]);
+    }
+}
+
 static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st) {
+  const bool mfma = N1 % 64 == 0 && N2 % 64 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  if (mfma) {
+    // enough (tile, M-chunk) waves to fill the chip: ~2048 waves, chunks of at least 256 rows
+    const int tiles = (N1 / 64) * (N2 / 64);
+    int splits = (2048 + tiles - 1) / tiles;  // M chunks wanted
+    int m_chunk = (M + splits - 1) / splits;
+    m_chunk = ((max(m_chunk, 256) + 15) / 16) * 16;
+    const int nchunks = (M + m_chunk - 1) / m_chunk;
+    dim3 grid(N2 / 64, N1 / 64, (nchunks + 3) / 4);
+    hipLaunchKernelGGL(gemm_tn_mfma_kernel, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk);
+    DIFFAB_LAUNCH_CHECK();
+    return DIFFAB_OK;
+  }
   const int m_chunk = 2048;
   dim3 grid((N2 + TB - 1) / TB, (N1 + TB - 1) / TB, (M + m_chunk - 1) / m_chunk);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N1, N2, m_chunk);
@@ -136,8 +204,8 @@ static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
   return DIFFAB_OK;
 }
 static int colsum(const float* dY, int ld, int M, int N, float* db, hipStream_t st) {
-  const int m_chunk = 4096;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + m_chunk - 1) / m_chunk), dim3(64), 0, st, dY, ld, M, N, m_chunk, db);
+  const int m_chunk = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + m_chunk - 1) / m_chunk), dim3(256), 0, st, dY, ld, M, N, m_chunk, db);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -270,7 +338,11 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
                                                                 const float* __restrict__ dfeat, float* __restrict__ dproj,
                                                                 float* __restrict__ de, float* __restrict__ dWb, float* __restrict__ dgamma,
                                                                 float* __restrict__ At, float* __restrict__ Gt, float* __restrict__ dogbuf,
-                                                                int K, int C, int H, int DS, int PQ, int PV) {
+                                                                float* __restrict__ wb_part, int K, int C, int H, int DS, int PQ, int PV,
+                                                                int vec) {
+  // vec: DS, C, 3 PQ, 3 PV are multiples of 4 and e is 16-byte aligned: the (h, j) dot products run on 8 lanes x float4 (every
+  // load instruction covers 128-byte pieces of a key row) instead of one lane per (h, j) walking its own row (64 lines per load
+  // instruction: the texture-address unit, not the math, set the 10 ms this kernel used to take per layer).
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x / K, i = blockIdx.x % K;
   const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
@@ -283,6 +355,7 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
   float* qrow = d2 + H * K;                  // H*DS + H*PQ*3
   float* dog = qrow + H * DS + H * PQ * 3;   // H*PV*3  gradient w.r.t. the global value-point sums
   float* red = dog + H * PV * 3;             // H  row sums
+  float* dfl = red + H;                      // F  this row's feature gradient
   const int64_t row_i = static_cast<int64_t>(b) * K + i;
   const float* prow = proj + row_i * NP;
   const float* frow = feat + row_i * F;
@@ -292,6 +365,7 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
   const float* Rr = R + row_i * 9;
   for (int d = threadIdx.x; d < H * DS; d += blockDim.x) qrow[d] = prow[d];
   for (int d = threadIdx.x; d < H * PQ * 3; d += blockDim.x) qrow[H * DS + d] = prow[off_gq + d];
+  for (int d = threadIdx.x; d < F; d += blockDim.x) dfl[d] = dfrow[d];
   // value-point sums: o_l = (o_g - t) R^T, o_n = |o_l|  ->  d o_g[k] = sum_c (do_l[c] + do_n o_l[c]/o_n) R[c][k]
   for (int hp = threadIdx.x; hp < H * PV; hp += blockDim.x) {
     const float on = frow[n_os + n_oe + n_og + hp], don = dfrow[n_os + n_oe + n_og + hp];
@@ -312,19 +386,53 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
   const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
   const float scale_p = -0.5f / sqrtf(4.5f * PQ);
   const float scale_t = 1.0f / sqrtf(3.0f);
-  // ---- recompute logits (same expression order as the forward kernel)
-  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
-    const int h = idx / K, j = idx % K;
-    const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
-    float ls = 0.f, lb = 0.f, lp = 0.f;
-    for (int d = 0; d < DS; ++d) ls += qrow[h * DS + d] * krow[off_ks + h * DS + d];
-    for (int c = 0; c < C; ++c) lb += erow[static_cast<int64_t>(j) * C + c] * Wb[h * C + c];
-    for (int p = 0; p < PQ * 3; ++p) {
-      const float dd = qrow[H * DS + h * PQ * 3 + p] - krow[off_gk + h * PQ * 3 + p];
-      lp += dd * dd;
+  // ---- recompute logits
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const int lo = threadIdx.x & 7, oct = threadIdx.x >> 3, noct = blockDim.x >> 3;
+  if (vec) {
+    for (int idx = oct; idx < H * K; idx += noct) {
+      const int h = idx / K, j = idx % K;
+      const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+      float ls = 0.f, lb = 0.f, lp = 0.f;
+      for (int d = 4 * lo; d < DS; d += 32) {
+        const v4 kv = *reinterpret_cast<const v4*>(krow + off_ks + h * DS + d), qv = *reinterpret_cast<const v4*>(qrow + h * DS + d);
+        ls += (qv[0] * kv[0] + qv[1] * kv[1]) + (qv[2] * kv[2] + qv[3] * kv[3]);
+      }
+      for (int c = 4 * lo; c < C; c += 32) {
+        const v4 ev = *reinterpret_cast<const v4*>(erow + static_cast<int64_t>(j) * C + c), wv = *reinterpret_cast<const v4*>(Wb + h * C + c);
+        lb += (ev[0] * wv[0] + ev[1] * wv[1]) + (ev[2] * wv[2] + ev[3] * wv[3]);
+      }
+      for (int p = 4 * lo; p < PQ * 3; p += 32) {
+        const v4 kv = *reinterpret_cast<const v4*>(krow + off_gk + h * PQ * 3 + p);
+        const v4 qv = *reinterpret_cast<const v4*>(qrow + H * DS + h * PQ * 3 + p);
+        const v4 dd = qv - kv;
+        lp += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        ls += __shfl_xor(ls, o);
+        lb += __shfl_xor(lb, o);
+        lp += __shfl_xor(lp, o);
+      }
+      if (lo == 0) {
+        d2[idx] = lp;
+        attn[idx] = scale_t * ((ls * scale_s + lb) + (scale_p * gamma[h]) * lp);
+      }
     }
-    d2[idx] = lp;
-    attn[idx] = scale_t * ((ls * scale_s + lb) + (scale_p * gamma[h]) * lp);
+  } else {
+    for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+      const int h = idx / K, j = idx % K;
+      const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+      float ls = 0.f, lb = 0.f, lp = 0.f;
+      for (int d = 0; d < DS; ++d) ls += qrow[h * DS + d] * krow[off_ks + h * DS + d];
+      for (int c = 0; c < C; ++c) lb += erow[static_cast<int64_t>(j) * C + c] * Wb[h * C + c];
+      for (int p = 0; p < PQ * 3; ++p) {
+        const float dd = qrow[H * DS + h * PQ * 3 + p] - krow[off_gk + h * PQ * 3 + p];
+        lp += dd * dd;
+      }
+      d2[idx] = lp;
+      attn[idx] = scale_t * ((ls * scale_s + lb) + (scale_p * gamma[h]) * lp);
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -344,14 +452,37 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
   }
   __syncthreads();
   // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]
-  for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
-    const int h = idx / K, j = idx % K;
-    const float* vrow = proj + (static_cast<int64_t>(b) * K + j) * NP;
-    float s = 0.f;
-    for (int d = 0; d < DS; ++d) s += dfrow[h * DS + d] * vrow[off_vs + h * DS + d];
-    for (int c = 0; c < C; ++c) s += dfrow[n_os + h * C + c] * erow[static_cast<int64_t>(j) * C + c];
-    for (int p = 0; p < PV * 3; ++p) s += dog[h * PV * 3 + p] * vrow[off_gv + h * PV * 3 + p];
-    gl[idx] = s;
+  if (vec) {
+    for (int idx = oct; idx < H * K; idx += noct) {
+      const int h = idx / K, j = idx % K;
+      const float* vrow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+      float sacc = 0.f;
+      for (int d = 4 * lo; d < DS; d += 32) {
+        const v4 a = *reinterpret_cast<const v4*>(dfl + h * DS + d), v = *reinterpret_cast<const v4*>(vrow + off_vs + h * DS + d);
+        sacc += (a[0] * v[0] + a[1] * v[1]) + (a[2] * v[2] + a[3] * v[3]);
+      }
+      for (int c = 4 * lo; c < C; c += 32) {
+        const v4 a = *reinterpret_cast<const v4*>(dfl + n_os + h * C + c), v = *reinterpret_cast<const v4*>(erow + static_cast<int64_t>(j) * C + c);
+        sacc += (a[0] * v[0] + a[1] * v[1]) + (a[2] * v[2] + a[3] * v[3]);
+      }
+      for (int p = 4 * lo; p < PV * 3; p += 32) {
+        const v4 a = *reinterpret_cast<const v4*>(dog + h * PV * 3 + p), v = *reinterpret_cast<const v4*>(vrow + off_gv + h * PV * 3 + p);
+        sacc += (a[0] * v[0] + a[1] * v[1]) + (a[2] * v[2] + a[3] * v[3]);
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) sacc += __shfl_xor(sacc, o);
+      if (lo == 0) gl[idx] = sacc;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
+      const int h = idx / K, j = idx % K;
+      const float* vrow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+      float sacc = 0.f;
+      for (int d = 0; d < DS; ++d) sacc += dfl[h * DS + d] * vrow[off_vs + h * DS + d];
+      for (int c = 0; c < C; ++c) sacc += dfl[n_os + h * C + c] * erow[static_cast<int64_t>(j) * C + c];
+      for (int p = 0; p < PV * 3; ++p) sacc += dog[h * PV * 3 + p] * vrow[off_gv + h * PV * 3 + p];
+      gl[idx] = sacc;
+    }
   }
   __syncthreads();
   // ---- softmax backward: dlogit = A (dA - sum_j A dA); keep g = scale_t * dlogit
@@ -375,7 +506,7 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
     float s = 0.f;
     for (int j = lane; j < K; j += 64) s += gl[h * K + j] * scale_p * d2[h * K + j];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) atomicAdd(dgamma + h, s);
+    if (lane == 0) wb_part[row_i * (H * C + H) + H * C + h] = s;  // per-row partial; summed over rows afterwards (no contended atomics)
   }
   // ---- query-side gradients (this row only)
   float* dqrow = dproj + row_i * NP;
@@ -398,7 +529,7 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
     for (int idx = threadIdx.x; idx < K * C; idx += blockDim.x) {
       const int j = idx / C, c = idx % C;
       float s = 0.f;
-      for (int h = 0; h < H; ++h) s += attn[h * K + j] * dfrow[n_os + h * C + c] + gl[h * K + j] * Wb[h * C + c];
+      for (int h = 0; h < H; ++h) s += attn[h * K + j] * dfl[n_os + h * C + c] + gl[h * K + j] * Wb[h * C + c];
       derow[idx] += s;
     }
   }
@@ -406,7 +537,7 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
     const int h = o / C, c = o % C;
     float s = 0.f;
     for (int j = 0; j < K; ++j) s += gl[h * K + j] * erow[static_cast<int64_t>(j) * C + c];
-    atomicAdd(dWb + o, s);
+    wb_part[row_i * (H * C + H) + o] = s;
   }
 }
 
@@ -520,7 +651,7 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
   const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
   return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64 + 2 * HKK +
-         rows * d->H * d->PV * 3;
+         rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64;
 }
 
 int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
@@ -549,6 +680,7 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
   float* At = take(HKK);
   float* Gt = take(HKK);
   float* dogbuf = take(static_cast<size_t>(rows) * H * PV * 3);
+  float* wb_part = take(static_cast<size_t>(rows) * (H * C + H));  // per-row partials of d w_bias (H*C) and d gamma (H)
 
   hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
   DIFFAB_LAUNCH_CHECK();
@@ -585,15 +717,20 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     // to_out
     if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows, D, F,
                             false, st)) return rc;
-    const size_t lds = (3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H) * sizeof(float);
+    const size_t lds = (3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) * sizeof(float);
+    const int vec = (DS % 4 == 0 && C % 4 == 0 && (PQ * 3) % 4 == 0 && (PV * 3) % 4 == 0 && H % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(pair_ctx) & 15) == 0 && (reinterpret_cast<uintptr_t>(lw->w_bias) & 15) == 0) ? 1 : 0;
     DIFFAB_REQUIRE(lds <= 160 * 1024, DIFFAB_ERR_UNSUPPORTED, "attention backward: H*K too large for LDS (%zu bytes)", lds);
     if (lds > 64 * 1024)
       DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL(ipa_attn_bwd_rows_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, lw->w_bias, lw->gamma, feat, dfeat,
-                       dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), At, Gt, dogbuf, d->K, C, H, DS, PQ,
-                       PV);
+                       dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), At, Gt, dogbuf, wb_part, d->K, C, H,
+                       DS, PQ, PV, vec);
     DIFFAB_LAUNCH_CHECK();
+    // d w_bias[h][c] += sum_rows partial, d gamma[h] += sum_rows partial (one column sum over the [rows][H*C + H] partials)
+    if (int rc = colsum(wb_part, H * C + H, rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
+    if (int rc = colsum(wb_part + H * C, H * C + H, rows, H, const_cast<float*>(lg->gamma), st)) return rc;
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
     hipLaunchKernelGGL(ipa_attn_bwd_keys_kernel, dim3(rows), dim3(256), lds2, st, proj, lw->gamma, dfeat, At, Gt, dogbuf, dproj, d->K, C, H,
                        DS, PQ, PV);
