@@ -54,7 +54,7 @@ static int check_dims(const diffab_dims* d, const char* who) {
 }
 
 struct StepBuffers {
-  float *cat2, *h1, *hA, *hB, *cat3, *t1, *t2, *vbuf, *logits, *ipa;
+  float *cat2, *h1, *hA, *hB, *cat3, *t1, *t2, *vbuf, *logits, *ipa, *emb_tab, *beta_tab;
   size_t bytes;
 };
 
@@ -71,6 +71,8 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
   b.t2 = c.take<float>(rows * d->D);
   b.vbuf = c.take<float>(rows * 3);
   b.logits = c.take<float>(rows * d->V);
+  b.emb_tab = c.take<float>(static_cast<size_t>(25) * d->D);
+  b.beta_tab = c.take<float>(static_cast<size_t>(3) * d->B * d->D);
   size_t ipa_floats = ipa_generic_workspace_floats(d);
   if (fast_path_supported(d)) ipa_floats = ipa_floats > ipa_fast_workspace_floats(d) ? ipa_floats : ipa_fast_workspace_floats(d);
   b.ipa = c.take<float>(ipa_floats);
@@ -100,8 +102,18 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
                         float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st) {
   const StepBuffers b = carve_step(d, ws);
   const int rows = d->B * d->K, D = d->D;
-  if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, b.cat2, st)) return rc;
-  if (int rc = launch_linear(b.cat2, 2 * D, w->res_w0, w->res_b0, b.h1, D, rows, D, 2 * D, true, st)) return rc;
+  // Folded concatenations (MFMA path): the sequence-embedding half of to_res_emb[0] and the beta-embedding columns of the three
+  // head MLPs become bias tables, so neither cat[res_ctx, E[s]] nor cat[h, tau] is written or re-read.
+  const bool fold = !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d) && rowgemm128_ok(res_ctx, D, b.h1, D, rows, D);
+  if (fold) {
+    DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0, DIFFAB_ERR_ARG,
+                   "denoiser head: null weight pointer");
+    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st)) return rc;
+    if (int rc = launch_rowgemm128(res_ctx, D, w->res_w0, 2 * D, b.emb_tab, seq_t, 0, b.h1, D, rows, D, true, st)) return rc;
+  } else {
+    if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, b.cat2, st)) return rc;
+    if (int rc = launch_linear(b.cat2, 2 * D, w->res_w0, w->res_b0, b.h1, D, rows, D, 2 * D, true, st)) return rc;
+  }
   if (int rc = launch_linear(b.h1, D, w->res_w2, w->res_b2, b.hA, D, rows, D, D, false, st)) return rc;
   float *cur = b.hA, *nxt = b.hB;
   for (int l = 0; l < d->NL; ++l) {
@@ -109,11 +121,24 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   if (out_res_emb) DIFFAB_HIP_CHECK(hipMemcpyAsync(out_res_emb, cur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
-  if (int rc = launch_beta_concat(cur, beta, D, d->K, rows, b.cat3, st)) return rc;
   float* logits = out_logits ? out_logits : b.logits;
-  if (int rc = mlp3(d, &w->coord, b.cat3, b.t1, b.t2, out_eps, 3, st)) return rc;
-  if (int rc = mlp3(d, &w->orient, b.cat3, b.t1, b.t2, b.vbuf, 3, st)) return rc;
-  if (int rc = mlp3(d, &w->seq, b.cat3, b.t1, b.t2, logits, d->V, st)) return rc;
+  if (fold) {
+    const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
+    float* outs[3] = {out_eps, b.vbuf, logits};
+    const int nout[3] = {3, 3, d->V};
+    for (int hd = 0; hd < 3; ++hd) {
+      DIFFAB_REQUIRE(hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
+      if (int rc = launch_rowgemm128(cur, D, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, D, rows,
+                                     D, true, st)) return rc;
+      if (int rc = launch_linear(b.t1, D, hw[hd]->w2, hw[hd]->b2, b.t2, D, rows, D, D, true, st)) return rc;
+      if (int rc = launch_linear(b.t2, D, hw[hd]->w4, hw[hd]->b4, outs[hd], nout[hd], rows, nout[hd], D, false, st)) return rc;
+    }
+  } else {
+    if (int rc = launch_beta_concat(cur, beta, D, d->K, rows, b.cat3, st)) return rc;
+    if (int rc = mlp3(d, &w->coord, b.cat3, b.t1, b.t2, out_eps, 3, st)) return rc;
+    if (int rc = mlp3(d, &w->orient, b.cat3, b.t1, b.t2, b.vbuf, 3, st)) return rc;
+    if (int rc = mlp3(d, &w->seq, b.cat3, b.t1, b.t2, logits, d->V, st)) return rc;
+  }
   return launch_heads_finish(b.vbuf, O_t, logits, d->V, rows, out_O0, out_post, st);
 }
 

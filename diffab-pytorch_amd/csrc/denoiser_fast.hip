@@ -25,6 +25,7 @@ namespace diffab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Compile-time fence for memory operations: keeps the hand-placed prefetch loads where they are written (hipcc otherwise
 // sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
@@ -186,9 +187,13 @@ constexpr int RG_ROWS = 64 * RG_MT;
 // instant after each barrier and the burst (16 MiB chip-wide) does not drain within one chunk of compute.
 template <bool RELU, int AW>
 __global__ __launch_bounds__(512, RG_MT == 1 ? 2 : 1) void rowgemm128_kernel(const float* __restrict__ X, int ldx,
-                                                                            const float* __restrict__ W,
-                                                                            const float* __restrict__ bias, float* __restrict__ Y,
-                                                                            int ldy, int M, int Kd) {
+                                                                            const float* __restrict__ W, int ldw,
+                                                                            const float* __restrict__ bias,
+                                                                            const int64_t* __restrict__ bias_idx, int bias_div,
+                                                                            float* __restrict__ Y, int ldy, int M, int Kd) {
+  // bias: one vector (bias_idx == nullptr, bias_div == 0), or a table of 128-wide rows indexed by bias_idx[row] or row / bias_div
+  // (the folded concatenations of the denoiser: a per-residue-type or per-patch affine term, see fold_tables in api.hip).
+  // W rows are ldw floats apart and only 4-byte aligned (the 131-wide head weights are read in place).
   constexpr int MT = RG_MT;
   __shared__ __attribute__((aligned(16))) float Ws[2 * 128 * RG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -203,15 +208,16 @@ __global__ __launch_bounds__(512, RG_MT == 1 ? 2 : 1) void rowgemm128_kernel(con
   for (int r = 0; r < 4; ++r) {
     const int l = 32 * r + (tid >> 4), c4 = tid & 15;
     const int n = (l & 64) + 4 * (l & 15) + ((l >> 4) & 3);
-    wsrc[r] = W + static_cast<int64_t>(n) * Kd + 4 * c4;
+    wsrc[r] = W + static_cast<int64_t>(n) * ldw + 4 * c4;
   }
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   auto load_w = [&](int ch) {
 #ifdef RG_ABL_NOW
     if (ch > 0) return;
 #endif
     ch = ch < nchunk ? ch : nchunk - 1;  // unconditional prefetch: the last trips re-read the final chunk
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc[r] + ch * RG_KC);
+    for (int r = 0; r < 4; ++r) wreg[r] = *reinterpret_cast<const f32x4u*>(wsrc[r] + ch * RG_KC);
   };
   auto store_w = [&](int buf) {
 #pragma unroll
@@ -298,17 +304,40 @@ __global__ __launch_bounds__(512, RG_MT == 1 ? 2 : 1) void rowgemm128_kernel(con
   }
   // lane holds columns 64 cw + 4 l15 + (0..3) of rows 16 MT rw + 16 mt + 4 g + r
   const int col = 64 * cw + 4 * l15;
+  const bool table = bias_idx != nullptr || bias_div > 0;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+  if (bias && !table) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 16 * MT * rw + 16 * mt + 4 * g + r;
+      if (row >= M) continue;
+      if (table) {
+        const int64_t bi = bias_idx ? bias_idx[row] : row / bias_div;
+        bv = *reinterpret_cast<const f32x4*>(bias + bi * 128 + col);
+      }
       f32x4 o = {acc[mt][0][r] + bv[0], acc[mt][1][r] + bv[1], acc[mt][2][r] + bv[2], acc[mt][3][r] + bv[3]};
       if (RELU) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
-      if (row < M) *reinterpret_cast<f32x4*>(Y + static_cast<int64_t>(row) * ldy + col) = o;
+      *reinterpret_cast<f32x4*>(Y + static_cast<int64_t>(row) * ldy + col) = o;
     }
+}
+
+bool rowgemm128_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd) {
+  return Kd % (2 * RG_KC) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(X) && aligned16(Y) && M >= RG_ROWS;
+}
+// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + table row); W rows ldw apart; see rowgemm128_kernel
+int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                      int ldy, int M, int Kd, bool relu, hipStream_t st) {
+  DIFFAB_REQUIRE(rowgemm128_ok(X, ldx, Y, ldy, M, Kd) && (!bias || aligned16(bias)), DIFFAB_ERR_ARG, "rowgemm128: unsupported operands");
+  const dim3 grid((M + RG_ROWS - 1) / RG_ROWS);
+#define RG_LAUNCH(R, AW_) \
+  hipLaunchKernelGGL((rowgemm128_kernel<R, AW_>), grid, dim3(512), 0, st, X, ldx, W, ldw, bias, bias_idx, bias_div, Y, ldy, M, Kd)
+  if (RG_DEEP_A && Kd % (4 * RG_KC) == 0) { if (relu) RG_LAUNCH(true, 2); else RG_LAUNCH(false, 2); }
+  else                                    { if (relu) RG_LAUNCH(true, 1); else RG_LAUNCH(false, 1); }
+#undef RG_LAUNCH
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
 }
 
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
@@ -319,15 +348,8 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
   segs.nseg = 1;
   const bool vec = (ldx % 4 == 0) && (Kd % 4 == 0) && aligned16(X) && aligned16(W);
 #ifndef DIFFAB_NO_ROWGEMM
-  if (N == 128 && vec && Kd % (2 * RG_KC) == 0 && ldy % 4 == 0 && aligned16(Y) && (!bias || aligned16(bias)) && M >= RG_ROWS) {
-    const dim3 grid((M + RG_ROWS - 1) / RG_ROWS);
-#define RG_LAUNCH(R, AW_) hipLaunchKernelGGL((rowgemm128_kernel<R, AW_>), grid, dim3(512), 0, st, X, ldx, W, bias, Y, ldy, M, Kd)
-    if (RG_DEEP_A && Kd % (4 * RG_KC) == 0) { if (relu) RG_LAUNCH(true, 2); else RG_LAUNCH(false, 2); }
-    else                       { if (relu) RG_LAUNCH(true, 1); else RG_LAUNCH(false, 1); }
-#undef RG_LAUNCH
-    DIFFAB_LAUNCH_CHECK();
-    return DIFFAB_OK;
-  }
+  if (N == 128 && vec && rowgemm128_ok(X, ldx, Y, ldy, M, Kd) && (!bias || aligned16(bias)))
+    return launch_rowgemm128(X, ldx, W, Kd, bias, nullptr, 0, Y, ldy, M, Kd, relu, st);
 #endif
   if (N > 64) return launch_linear_bn<128>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
   return launch_linear_bn<64>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
@@ -521,14 +543,22 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         // acc[r] = q_s[i0+4q+r] . k_s[key 16jt+l15]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float d2 = 0.f;
+          // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two coordinates per instruction, two partial sums added at the end
+          f32x2 d2v = {0.f, 0.f};
 #pragma unroll
-          for (int cc = 0; cc < 6; ++cc)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const float dd = gq[r][cc][s] - gk[cc][s];
-              d2 += dd * dd;
-            }
+          for (int cc = 0; cc < 6; ++cc) {
+            // packed subtract spelled in assembly: the compiler splits a vector fsub (and fma(b, -1, a)) into two v_sub_f32
+            f32x2 dlo, dhi;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+                : "=v"(dlo)
+                : "v"(__builtin_shufflevector(gq[r][cc], gq[r][cc], 0, 1)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 0, 1)));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+                : "=v"(dhi)
+                : "v"(__builtin_shufflevector(gq[r][cc], gq[r][cc], 2, 3)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 2, 3)));
+            d2v = __builtin_elementwise_fma(dlo, dlo, d2v);
+            d2v = __builtin_elementwise_fma(dhi, dhi, d2v);
+          }
+          const float d2 = d2v[0] + d2v[1];
           S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
         }
       }
@@ -940,6 +970,40 @@ __global__ __launch_bounds__(512) void proj_frames_kernel(const float* __restric
   pj_run_block<FULL, true, true>(c, w, a, wreg, accB, accA, PJNB - 1);
 #pragma unroll
   for (int q = 0; q < 8; ++q) pj_epilogue_piece<FULL, true>(c, accB, PJNB - 1, q);
+}
+
+// ================================================================== folded concatenations of the denoiser (D = 128)
+// cat[res_ctx, E[s]] W0^T + b0 = res_ctx W0[:, :D]^T + (E[s] W0[:, D:]^T + b0): the second term depends only on the residue type s
+// (25 rows), so it becomes a bias table indexed by seq_t and the 2D-wide concatenation is never materialised
+// (reference diffab_pytorch.py:572-574).  Likewise cat[h, (beta, sin beta, cos beta)] W^T + b = h W[:, :D]^T + per-patch row
+// (diffab_pytorch.py:584-588) for each of the three heads.
+__global__ void fold_embed_table_kernel(const float* __restrict__ emb, const float* __restrict__ W0, const float* __restrict__ b0, int D,
+                                        int n_types, float* __restrict__ tab) {
+  const int s_ = blockIdx.x, n = threadIdx.x;  // tab[s][n]
+  if (s_ >= n_types || n >= D) return;
+  float acc = 0.f;
+  for (int k = 0; k < D; ++k) acc += emb[s_ * D + k] * W0[n * 2 * D + D + k];
+  tab[s_ * D + n] = acc + b0[n];
+}
+__global__ void fold_beta_table_kernel(const float* __restrict__ beta, const float* __restrict__ Wa, const float* __restrict__ ba,
+                                       const float* __restrict__ Wb_, const float* __restrict__ bb, const float* __restrict__ Wc,
+                                       const float* __restrict__ bc, int D, int B, float* __restrict__ tab) {
+  const int b = blockIdx.x, hd = blockIdx.y, n = threadIdx.x;  // tab[hd][b][n]
+  if (b >= B || n >= D) return;
+  const float* W = hd == 0 ? Wa : (hd == 1 ? Wb_ : Wc);
+  const float* bias = hd == 0 ? ba : (hd == 1 ? bb : bc);
+  const float be = beta[b];
+  const float* wr = W + n * (D + 3) + D;
+  tab[(static_cast<int64_t>(hd) * B + b) * D + n] = ((be * wr[0] + sinf(be) * wr[1]) + cosf(be) * wr[2]) + bias[n];
+}
+int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25), dim3(d->D), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
+  DIFFAB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fold_beta_table_kernel, dim3(d->B, 3), dim3(d->D), 0, st, beta, w->coord.w0, w->coord.b0, w->orient.w0, w->orient.b0,
+                     w->seq.w0, w->seq.b0, d->D, d->B, beta_tab);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
 }
 
 bool fast_path_supported(const diffab_dims* d) {

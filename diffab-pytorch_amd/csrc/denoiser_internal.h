@@ -23,6 +23,15 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);
 
+// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + bias row), W rows ldw floats apart (4-byte aligned), bias row = bias (vector) or
+// bias[128 * bias_idx[row]] or bias[128 * (row / bias_div)]; requires rowgemm128_ok()
+bool rowgemm128_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
+int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                      int ldy, int M, int Kd, bool relu, hipStream_t st);
+// bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
+int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
+                       hipStream_t st);
+
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
 // api.hip: opt-in hipEvent bracket around the dominant (attention) kernel
