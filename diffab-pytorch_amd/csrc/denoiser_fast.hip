@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
       };
 #pragma unroll
-      for (int jt = 0; jt < SD - 1 && jt < NT; ++jt) load_keys(jt, jt);
+      for (int jt = 0; jt < SD && jt < NT; ++jt) load_keys(jt, jt);
       // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
       f32x4 qa[2];
       const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
@@ -519,34 +519,67 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int cc = 0; cc < 6; ++cc) gq[r][cc] = *reinterpret_cast<const f32x4*>(p + 4 * cc);
       }
       MEM_FENCE();
+      // Software pipeline over the key tiles (fully unrolled, so the fragment sets are renamed, not copied):
+      //   iteration jt:  registers -> LDS for tile jt+2 | LDS -> fragments of tile jt+1 | global -> registers for tile jt+1+SD-1
+      //                  | MFMA + VALU on the fragments of tile jt (read during iteration jt-1).
+      // Every LDS round trip and every L2 round trip is a full iteration (or SD-2 of them) old when its data is needed; before
+      // this the fragment reads of tile jt sat right behind the writes of tile jt+1 and were waited for at once.
+      struct KeyFrag { f32x4 kb0, kb1, gk[6]; };
+      auto read_frags = [&](int jt) {
+        KeyFrag f;
+        const float* t_ = scr + (jt & 1) * P1_TILE;
+        f.kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
+        f.kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) f.gk[cc] = *reinterpret_cast<const f32x4*>(t_ + 16 * KLD + l15 * GLD + 4 * cc);
+        return f;
+      };
       stage_keys(0, 0);
+      KeyFrag cur = read_frags(0);
+      if (NT > 1) stage_keys(1 % SD, 1);
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-        if (jt + 1 < NT) stage_keys((jt + 1) % SD, (jt + 1) & 1);  // tile jt+1: registers -> LDS (loads issued SD-2 tiles ago)
-        if (jt + SD - 1 < NT) {
-          load_keys((jt + SD - 1) % SD, jt + SD - 1);
+#ifndef AT_ABL_P1_NOSTAGE
+        if (jt + 2 < NT) stage_keys((jt + 2) % SD, jt & 1);  // tile jt+2 -> the buffer tile jt was read from (LDS ops retire in order)
+#endif
+        KeyFrag nxt = cur;
+        if (jt + 1 < NT) nxt = read_frags(jt + 1);
+#ifdef AT_ABL_P1_NOLOAD
+        if (false) {
+#else
+        if (jt + SD < NT) {
+#endif
+          load_keys(jt % SD, jt + SD);  // slot of tile jt (staged two iterations ago)
         } else if (jt + E_EARLY >= NT) {
           load_e_tile(0, c, jt + E_EARLY - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
         }
         MEM_FENCE();
-        const float* t_ = scr + (jt & 1) * P1_TILE;
-        const f32x4 kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
-        const f32x4 kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
+        const f32x4 kb0 = cur.kb0, kb1 = cur.kb1;
         f32x4 gk[6];
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc) gk[cc] = *reinterpret_cast<const f32x4*>(t_ + 16 * KLD + l15 * GLD + 4 * cc);
+        for (int cc = 0; cc < 6; ++cc) gk[cc] = cur.gk[cc];
+        cur = nxt;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifdef AT_ABL_P1_NOMFMA
+        acc = kb0 + kb1;
+#else
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
+#endif
         // acc[r] = q_s[i0+4q+r] . k_s[key 16jt+l15]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two coordinates per instruction, two partial sums added at the end
           f32x2 d2v = {0.f, 0.f};
+#ifdef AT_ABL_P1_NOVALU
+          d2v[0] = gk[r][0] + gk[r + 1][1];
+          for (int cc = 0; cc < 0; ++cc) {
+#else
 #pragma unroll
           for (int cc = 0; cc < 6; ++cc) {
+#endif
             // packed subtract spelled in assembly: the compiler splits a vector fsub (and fma(b, -1, a)) into two v_sub_f32
             f32x2 dlo, dhi;
             asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
