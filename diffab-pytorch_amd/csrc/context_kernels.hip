@@ -61,9 +61,12 @@ __global__ void residue_feat_kernel(const int64_t* __restrict__ seq, const float
 }
 
 // one thread per (pair row, atom pair): exp(-softplus(coef[s_i*21+s_j]) d^2) * atom_mask_i * atom_mask_j   (:288-295)
+// distmat == nullptr: the distance is taken from the coordinates, d = |xyz[b,i,a1] - xyz[b,j,a2]| (what the reference's data layer
+// computes with protstruc and then leaves out of its batches, data.py:76 / preprocess_pdb.py:61): the 14.7 MB/patch distance
+// tensor is then never materialised.
 __global__ void pair_dist_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const float* __restrict__ distmat,
-                                 const float* __restrict__ amask, const float* __restrict__ coefw, int K, int A, int64_t row0, int64_t nrows,
-                                 float* __restrict__ out) {
+                                 const float* __restrict__ xyz, const float* __restrict__ amask, const float* __restrict__ coefw, int K,
+                                 int A, int64_t row0, int64_t nrows, float* __restrict__ out) {
   const int AA2 = A * A;
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (gid >= nrows * AA2) return;
@@ -74,7 +77,15 @@ __global__ void pair_dist_kernel(const int64_t* __restrict__ seq, const uint8_t*
   const int64_t ri = b * K + i, rj = b * K + j;
   const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
   const float coef = softplus_f(coefw[(si * kAA + sj) * AA2 + p]);
-  const float d = distmat[row * AA2 + p];
+  float d;
+  if (distmat) {
+    d = distmat[row * AA2 + p];
+  } else {
+    const float* pa = xyz + (ri * A + a1) * 3;
+    const float* pb = xyz + (rj * A + a2) * 3;
+    const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+    d = sqrtf((dx * dx + dy * dy) + dz * dz);
+  }
   out[lr * AA2 + p] = expf(-1.0f * coef * (d * d)) * (amask[ri * A + a1] * amask[rj * A + a2]);
 }
 
@@ -170,16 +181,16 @@ size_t diffab_pair_embedding_workspace_bytes(const diffab_ctx_dims* d) {
   return (rows * (d->A * d->A + 7 * d->C + 18) + 64) * sizeof(float);
 }
 
-int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
-                              const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
-                              const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+static int pair_embedding_impl(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
+                               const float* xyz, const float* pairwise_dihedrals, const int64_t* residue_idx,
+                               int32_t residue_idx_batch_stride, const int64_t* chain_idx, const float* atom_mask,
+                               const uint8_t* sequence_context_mask, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_ctx(d, "pair_embedding_fwd")) return rc;
   DIFFAB_REQUIRE(w && w->aa_pair_emb && w->relpos_emb && w->pair2distcoef && w->dw0 && w->db0 && w->dw2 && w->db2 && w->mw0 && w->mb0 &&
                      w->mw2 && w->mb2 && w->mw4 && w->mb4,
                  DIFFAB_ERR_ARG, "pair_embedding_fwd: null weight");
-  DIFFAB_REQUIRE(seq_idx && distmat && pairwise_dihedrals && residue_idx && chain_idx && atom_mask && out && workspace, DIFFAB_ERR_ARG,
-                 "pair_embedding_fwd: null pointer");
+  DIFFAB_REQUIRE(seq_idx && (distmat || xyz) && pairwise_dihedrals && residue_idx && chain_idx && atom_mask && out && workspace,
+                 DIFFAB_ERR_ARG, "pair_embedding_fwd: null pointer");
   DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_fwd: workspace");
   hipStream_t st = as_stream(stream);
   const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18;
@@ -197,7 +208,7 @@ int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
     const int rows = static_cast<int>(nrows);
     const int64_t n1 = nrows * AA2;
     hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, seq_idx, sequence_context_mask,
-                       distmat, atom_mask, w->pair2distcoef, d->K, d->A, row0, nrows, din);
+                       distmat, xyz, atom_mask, w->pair2distcoef, d->K, d->A, row0, nrows, din);
     DIFFAB_LAUNCH_CHECK();
     if (int rc = launch_linear(din, AA2, w->dw0, w->db0, h1, C, rows, C, AA2, true, st)) return rc;
     if (int rc = launch_linear(h1, C, w->dw2, w->db2, df, C, rows, C, C, true, st)) return rc;
@@ -215,6 +226,24 @@ int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
                      total);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
+}
+
+int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
+                              const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
+                              const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  DIFFAB_REQUIRE(distmat != nullptr, DIFFAB_ERR_ARG, "pair_embedding_fwd: distmat is null");
+  return pair_embedding_impl(d, w, seq_idx, distmat, nullptr, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
+                             sequence_context_mask, out, workspace, workspace_bytes, stream);
+}
+
+int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* xyz,
+                                  const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
+                                  const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  DIFFAB_REQUIRE(xyz != nullptr, DIFFAB_ERR_ARG, "pair_embedding_xyz_fwd: xyz is null");
+  return pair_embedding_impl(d, w, seq_idx, nullptr, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
+                             sequence_context_mask, out, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -297,11 +297,17 @@ class PairEmbedding(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(3 * d_feat + 2 * (2 * 2 * 2 + 1), d_feat), nn.ReLU(), nn.Linear(d_feat, d_feat), nn.ReLU(),
                                  nn.Linear(d_feat, d_feat))
 
-    def forward(self, seq_idx, distmat, dihedrals, residue_idx, chain_idx, atom_mask, structure_context_mask, sequence_context_mask):
+    def forward(self, seq_idx, distmat, dihedrals, residue_idx, chain_idx, atom_mask, structure_context_mask, sequence_context_mask, *,
+                xyz=None):
+        """distmat (B,K,K,A,A) as in the reference; or distmat=None and xyz=(B,K,A,3): the atom-atom distances are then computed
+        inside the kernel and the 14.7 MB/patch tensor is never built."""
         lib = _hip.lib()
-        out_dev = distmat.device
+        if distmat is None and xyz is None:
+            raise ValueError("PairEmbedding.forward needs distmat or xyz")
+        from_xyz = distmat is None
+        out_dev = (xyz if from_xyz else distmat).device
         seq, ch, ri = _hip.dev_i64(seq_idx), _hip.dev_i64(chain_idx), _hip.dev_i64(residue_idx)
-        dm, dh, am = (_hip.dev_f32(a) for a in (distmat, dihedrals, atom_mask))
+        dm, dh, am = (_hip.dev_f32(a) for a in (xyz if from_xyz else distmat, dihedrals, atom_mask))
         qm = _opt_mask(sequence_context_mask)
         B, K = seq.shape
         A = self.max_n_atoms_per_residue
@@ -317,9 +323,10 @@ class PairEmbedding(nn.Module):
         stride = K if ri.shape[0] == B and B > 1 or ri.shape[0] == B else 0
         if ri.shape[0] not in (1, B):
             raise ValueError("residue_idx must be (1, K) or (B, K)")
-        _hip.check(lib.diffab_pair_embedding_fwd(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri),
-                                                 stride if ri.shape[0] == B else 0, _hip.ptr(ch), _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out),
-                                                 _hip.ptr(ws), ws.numel(), _hip.stream_ptr()), "diffab_pair_embedding_fwd")
+        entry = lib.diffab_pair_embedding_xyz_fwd if from_xyz else lib.diffab_pair_embedding_fwd
+        _hip.check(entry(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri),
+                         stride if ri.shape[0] == B else 0, _hip.ptr(ch), _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
+                         _hip.stream_ptr()), "diffab_pair_embedding_xyz_fwd" if from_xyz else "diffab_pair_embedding_fwd")
         return out.to(out_dev)
 
 
@@ -369,8 +376,10 @@ class DiffAb(_ModuleBase):
         sequence_context_mask = context_mask if generate_sequence else None
         res_context_emb = self.residue_context_embedding(seq_idx_t0, xyz_t0, orientations_t0, backbone_dihedrals, chain_idx, atom_mask,
                                                          structure_context_mask, sequence_context_mask)
+        # distmat=None: distances come from xyz_t0 inside the kernel (the reference's batches do not carry distmat, data.py:93-94)
         pair_context_emb = self.pair_context_embedding(seq_idx_t0, distmat, pairwise_dihedrals, residue_idx, chain_idx, atom_mask,
-                                                       structure_context_mask, sequence_context_mask)
+                                                       structure_context_mask, sequence_context_mask,
+                                                       xyz=xyz_t0 if distmat is None else None)
         return res_context_emb, pair_context_emb
 
     def denoise(self, seq_idx_t, translations_t, orientations_t, res_context_emb, pair_context_emb, beta, generation_mask, residue_mask
@@ -424,7 +433,7 @@ class DiffAb(_ModuleBase):
             res_ctx, pair_ctx = batch["res_context_emb"], batch["pair_context_emb"]
         else:
             res_ctx, pair_ctx = self.encode_context(batch["seq_idx"], xyz_t0, batch["orientations"], batch["backbone_dihedrals"],
-                                                    batch["distmat"], batch["pairwise_dihedrals"], batch["atom_mask"], batch["chain_idx"],
+                                                    batch.get("distmat"), batch["pairwise_dihedrals"], batch["atom_mask"], batch["chain_idx"],
                                                     batch["residue_idx"], batch["generation_mask"], batch["residue_mask"])
         if torch.is_grad_enabled():
             return self.hotpath_train_losses(noised, res_ctx, pair_ctx, beta, batch["orientations"], batch["generation_mask"],

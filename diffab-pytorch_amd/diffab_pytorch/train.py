@@ -33,8 +33,8 @@ import torch
 MODEL_HPARAMS = dict(d_residue_emb=128, d_pair_emb=64, n_ipa_layers=6, d_scalar_per_head=32, n_query_point_per_head=8,
                      n_value_point_per_head=8, n_head=8)  # reference train.py:62-70
 
-# keys of one preprocessed patch (reference preprocess_pdb.py:67-80); distmat is commented out upstream ("171M") and is
-# recomputed from xyz here (plain Euclidean atom-atom distances)
+# keys of one preprocessed patch (reference preprocess_pdb.py:67-80); distmat is commented out upstream ("171M"): the pair kernel
+# takes the (plain Euclidean atom-atom) distances from xyz instead
 PATCH_KEYS = ("xyz", "orientations", "backbone_dihedrals", "backbone_dihedrals_mask", "pairwise_dihedrals", "atom_mask", "seq_idx",
               "chain_idx", "residue_idx", "residue_mask")
 
@@ -66,7 +66,8 @@ def parse_argument(argv: Optional[List[str]] = None) -> argparse.Namespace:
 
 def pairwise_atom_distances(xyz: torch.Tensor) -> torch.Tensor:
     """(B,K,A,3) -> (B,K,K,A,A) Euclidean distances: the `distmat` the reference computes with protstruc (data.py:76) and then
-    leaves out of its batches; PairEmbedding.forward (diffab_pytorch.py:220-312) needs it."""
+    leaves out of its batches; PairEmbedding.forward (diffab_pytorch.py:220-312) needs it.  Host-side statement of what
+    diffab_pair_embedding_xyz_fwd computes in the kernel (used by the tests; the training path never builds this tensor)."""
     d = xyz[:, :, None, :, None, :] - xyz[:, None, :, None, :, :]
     return d.square().sum(-1).sqrt()
 
@@ -93,9 +94,7 @@ def collate(patches: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
             batch[k] = patches[0][k]
         else:
             batch[k] = torch.cat([p[k] for p in patches], dim=0)
-    if "distmat" not in batch:
-        batch["distmat"] = pairwise_atom_distances(batch["xyz"])
-    return batch
+    return batch  # no distmat: DiffAb.encode_context takes the distances from xyz inside the pair kernel
 
 
 class PatchSource:
@@ -142,6 +141,8 @@ class PatchSource:
                 yield collate([load_patch(self.files[i]) for i in mine])
             else:
                 parts = [self._syn.context_batch(1, self.args.k, seed=self.args.seed + self.offset + i) for i in mine]
+                for p_ in parts:
+                    p_.pop("distmat")  # as in the reference's batches (data.py:93-94): distances are taken from xyz on the device
                 yield collate(parts)
 
 

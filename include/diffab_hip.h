@@ -250,6 +250,14 @@ int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
                               const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
                               const float* atom_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Same, with the atom-atom distances taken from the coordinates xyz (B,K,A,3) inside the kernel instead of a materialised
+ * distmat (K*K*A*A*4 = 14.7 MB per K=128 patch).  The reference's data layer computes that tensor with protstruc
+ * (data.py:76, preprocess_pdb.py:61) and then leaves it out of its batches; d = |xyz[b,i,a] - xyz[b,j,a']|. */
+int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx,
+                                  const float* xyz /* (B,K,A,3) */, const float* pairwise_dihedrals /* (B,K,K,2) */,
+                                  const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                                  const float* atom_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* ---- reverse process (build-defined; reference stub diffab_pytorch.py:770-776) -- */
 /* One update t -> t-1 from denoiser outputs with explicit noise (z (B,K,3), rotvec (B,K,3), u_seq (B,K)),

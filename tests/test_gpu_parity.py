@@ -670,6 +670,13 @@ def test_encode_context_vs_reference_goldens(hip, golden):
             assert res.shape == (Bc, Kc, D_) and pair.shape == (Bc, Kc, Kc, C_)
             assert maxrel(res, g[f"res_{int(gs)}{int(gq)}"]) < 1e-5, (gs, gq, maxrel(res, g[f"res_{int(gs)}{int(gq)}"]))
             assert maxrel(pair, g[f"pair_{int(gs)}{int(gq)}"]) < 1e-5, (gs, gq, maxrel(pair, g[f"pair_{int(gs)}{int(gq)}"]))
+            # distmat=None: atom-atom distances taken from xyz inside the pair kernel - same goldens, which were
+            # produced by the real reference from the materialised distance tensor
+            res_x, pair_x = model.encode_context(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], None,
+                                                 cb["pairwise_dihedrals"], cb["atom_mask"], cb["chain_idx"], cb["residue_idx"],
+                                                 cb["generation_mask"], cb["residue_mask"], generate_structure=gs, generate_sequence=gq)
+            assert torch.equal(res_x, res)
+            assert maxrel(pair_x, g[f"pair_{int(gs)}{int(gq)}"]) < 1e-5, (gs, gq, maxrel(pair_x, g[f"pair_{int(gs)}{int(gq)}"]))
 
 
 def test_encode_context_benchmark_dims_and_end_to_end(hip):
@@ -698,6 +705,7 @@ def test_encode_context_benchmark_dims_and_end_to_end(hip):
                                     dev2["generation_mask"], dev2["residue_mask"])
     assert torch.equal(pair2, pair)
     batch = dict(dev)  # reference batch dict: no precomputed contexts
+    batch.pop("distmat")  # ... and, as upstream (data.py:93-94), no distance tensor: taken from xyz on the device
     with torch.no_grad():
         torch.manual_seed(3)
         ls = model._shared_step(batch, 0)

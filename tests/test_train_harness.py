@@ -64,13 +64,13 @@ def test_patch_files_round_trip_and_distmat(tmp_path):
     assert src.n == 3
     (batch,) = list(src.batches(0))
     assert batch["xyz"].shape == (3, 6, 15, 3) and batch["residue_idx"].shape == (1, 6)
-    # distmat is recomputed from xyz (preprocess_pdb.py leaves it out): same numbers as the generator's float64 distances
+    # distmat is not stored (preprocess_pdb.py leaves it out) and not rebuilt on the host: the pair kernel takes it from xyz.
+    # pairwise_atom_distances states what that kernel computes; same numbers as the generator's float64 distances.
+    assert "distmat" not in batch
     order = [int(os.path.basename(f)[5]) for f in src.files]
-    perm = torch.randperm(3, generator=torch.Generator().manual_seed(a.seed)).tolist()
-    g = torch.Generator().manual_seed(a.seed + 0)
-    epoch_order = torch.randperm(3, generator=g).tolist()
+    epoch_order = torch.randperm(3, generator=torch.Generator().manual_seed(a.seed + 0)).tolist()
     idx = [order[i] for i in epoch_order]
-    np.testing.assert_allclose(batch["distmat"].numpy(), b["distmat"][idx].numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(T.pairwise_atom_distances(batch["xyz"]).numpy(), b["distmat"][idx].numpy(), rtol=0, atol=2e-5)
     with pytest.raises(KeyError, match="preprocess_pdb"):
         torch.save({"xyz": b["xyz"][:1]}, tmp_path / "bad.pt")
         T.load_patch(str(tmp_path / "bad.pt"))

@@ -28,11 +28,18 @@ __global__ __launch_bounds__(512) void probe(float* out, const float* in, int it
 #pragma unroll
       for (int r = 0; r < 4; ++r) wreg[r] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(32 * r + (tid >> 4)) * 1024 + (it & 15) * 64 + 4 * (tid & 15));
     }
-    if (MODE >= 5) {
+    if (MODE == 5) {  // MFMA-fragment-shaped: 16 rows x 64 B per instruction
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) an[mt][kq] = *reinterpret_cast<const f32x4*>(xrow0 + (size_t)mt * 16 * 1024 + (it & 15) * 64 + 16 * kq);
+    }
+    if (MODE == 6) {  // same bytes, line-shaped: 4 rows x 256 B per instruction (not usable as fragments: timing only)
+      const float* xl = Xg + (size_t)(blockIdx.x * 128 + 32 * ((tid >> 6) & 3) + (lane >> 4)) * 1024 + 4 * (lane & 15);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) an[mt][kq] = *reinterpret_cast<const f32x4*>(xl + (size_t)(mt * 16 + kq * 4) * 1024 + (it & 15) * 64);
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -80,9 +87,9 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const char* names[6] = {"distinct regs, no LDS      ", "+ 16 ds_read_b128 / 128 MFMA", "+ barrier every 128 MFMA   ", "+ 4 ds_write_b128 / chunk   ",
-                          "+ W chunk loads (L2)        ", "+ A fragment loads (HBM)    "};
-  for (int mode = 0; mode < 6; ++mode) {
+  const char* names[7] = {"distinct regs, no LDS      ", "+ 16 ds_read_b128 / 128 MFMA", "+ barrier every 128 MFMA   ", "+ 4 ds_write_b128 / chunk   ",
+                          "+ W chunk loads (L2)        ", "+ A fragment loads (HBM)    ", "+ A line-shaped loads (HBM) "};
+  for (int mode = 0; mode < 7; ++mode) {
     const int iters = 4000;
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
@@ -93,6 +100,7 @@ int main() {
       if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(512), 0, 0, out, in, iters, Wg, Xg);
       if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(512), 0, 0, out, in, iters, Wg, Xg);
       if (mode == 5) hipLaunchKernelGGL(probe<5>, dim3(256), dim3(512), 0, 0, out, in, iters, Wg, Xg);
+      if (mode == 6) hipLaunchKernelGGL(probe<6>, dim3(256), dim3(512), 0, 0, out, in, iters, Wg, Xg);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       hipEventElapsedTime(&ms, e0, e1);
