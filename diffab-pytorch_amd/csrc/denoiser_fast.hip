@@ -1012,11 +1012,15 @@ __global__ __launch_bounds__(512) void proj_frames_kernel(const float* __restric
 // (diffab_pytorch.py:584-588) for each of the three heads.
 __global__ void fold_embed_table_kernel(const float* __restrict__ emb, const float* __restrict__ W0, const float* __restrict__ b0, int D,
                                         int n_types, float* __restrict__ tab) {
-  const int s_ = blockIdx.x, n = threadIdx.x;  // tab[s][n]
-  if (s_ >= n_types || n >= D) return;
-  float acc = 0.f;
-  for (int k = 0; k < D; ++k) acc += emb[s_ * D + k] * W0[n * 2 * D + D + k];
-  tab[s_ * D + n] = acc + b0[n];
+  // one block per residue type s; a wave per output n (strided), lanes along k so the weight row is read coalesced
+  const int s_ = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  if (s_ >= n_types) return;
+  for (int n = wave; n < D; n += nwave) {
+    float acc = 0.f;
+    for (int k = lane; k < D; k += 64) acc += emb[s_ * D + k] * W0[n * 2 * D + D + k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) tab[s_ * D + n] = acc + b0[n];
+  }
 }
 __global__ void fold_beta_table_kernel(const float* __restrict__ beta, const float* __restrict__ Wa, const float* __restrict__ ba,
                                        const float* __restrict__ Wb_, const float* __restrict__ bb, const float* __restrict__ Wc,
@@ -1031,7 +1035,7 @@ __global__ void fold_beta_table_kernel(const float* __restrict__ beta, const flo
 }
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
                        hipStream_t st) {
-  hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25), dim3(d->D), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
+  hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25), dim3(512), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
   DIFFAB_LAUNCH_CHECK();
   hipLaunchKernelGGL(fold_beta_table_kernel, dim3(d->B, 3), dim3(d->D), 0, st, beta, w->coord.w0, w->coord.b0, w->orient.w0, w->orient.b0,
                      w->seq.w0, w->seq.b0, d->D, d->B, beta_tab);
