@@ -61,39 +61,56 @@ __global__ void residue_feat_kernel(const int64_t* __restrict__ seq, const float
 }
 
 // one thread per (pair row, atom pair): exp(-softplus(coef[s_i*21+s_j]) d^2) * atom_mask_i * atom_mask_j   (:288-295)
+// softplus of the whole pair2distcoef table (441 x A*A) once per call: it depends on the residue-type pair only, not on the
+// residue pair, and the two transcendentals per element were most of pair_dist_kernel's time
+__global__ void softplus_table_kernel(const float* __restrict__ coefw, int n, float* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n) out[gid] = softplus_f(coefw[gid]);
+}
+
+// one block per pair row (b, i, j), one thread per atom pair: exp(-softplus(coef[s_i*21+s_j]) d^2) * atom_mask_i * atom_mask_j (:288-295).
 // distmat == nullptr: the distance is taken from the coordinates, d = |xyz[b,i,a1] - xyz[b,j,a2]| (what the reference's data layer
 // computes with protstruc and then leaves out of its batches, data.py:76 / preprocess_pdb.py:61): the 14.7 MB/patch distance
-// tensor is then never materialised.
+// tensor is then never materialised.  out rows are ldo = round_up(A*A, 4) floats apart, pad columns zero (vector path of the GEMM).
 __global__ void pair_dist_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const float* __restrict__ distmat,
-                                 const float* __restrict__ xyz, const float* __restrict__ amask, const float* __restrict__ coefw, int K,
-                                 int A, int64_t row0, int64_t nrows, float* __restrict__ out) {
+                                 const float* __restrict__ xyz, const float* __restrict__ amask, const float* __restrict__ coef_sp, int K,
+                                 int A, int64_t row0, int64_t nrows, float* __restrict__ out, int ldo) {
   const int AA2 = A * A;
-  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (gid >= nrows * AA2) return;
-  const int64_t lr = gid / AA2, row = row0 + lr;  // global pair row (b, i, j)
-  const int p = static_cast<int>(gid % AA2), a1 = p / A, a2 = p % A;
-  const int64_t b = row / (static_cast<int64_t>(K) * K);
-  const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
-  const int64_t ri = b * K + i, rj = b * K + j;
-  const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
-  const float coef = softplus_f(coefw[(si * kAA + sj) * AA2 + p]);
-  float d;
-  if (distmat) {
-    d = distmat[row * AA2 + p];
-  } else {
-    const float* pa = xyz + (ri * A + a1) * 3;
-    const float* pb = xyz + (rj * A + a2) * 3;
-    const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
-    d = sqrtf((dx * dx + dy * dy) + dz * dz);
+  constexpr int RPB = 8;  // pair rows per block: one row per block is bound by the work-group dispatch rate (174 k tiny groups)
+  for (int rr = 0; rr < RPB; ++rr) {
+    const int64_t lr = static_cast<int64_t>(blockIdx.x) * RPB + rr;
+    if (lr >= nrows) return;
+    const int64_t row = row0 + lr;  // global pair row (b, i, j)
+    const int64_t b = row / (static_cast<int64_t>(K) * K);
+    const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+    const int64_t ri = b * K + i, rj = b * K + j;
+    const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+    const float* crow = coef_sp + (si * kAA + sj) * AA2;
+    for (int p = threadIdx.x; p < ldo; p += blockDim.x) {
+      float v = 0.0f;
+      if (p < AA2) {
+        const int a1 = p / A, a2 = p % A;
+        float d;
+        if (distmat) {
+          d = distmat[row * AA2 + p];
+        } else {
+          const float* pa = xyz + (ri * A + a1) * 3;
+          const float* pb = xyz + (rj * A + a2) * 3;
+          const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+          d = sqrtf((dx * dx + dy * dy) + dz * dz);
+        }
+        v = expf(-1.0f * crow[p] * (d * d)) * (amask[ri * A + a1] * amask[rj * A + a2]);
+      }
+      out[lr * ldo + p] = v;
+    }
   }
-  out[lr * AA2 + p] = expf(-1.0f * coef * (d * d)) * (amask[ri * A + a1] * amask[rj * A + a2]);
 }
 
 // one block per pair row: [aa_pair_emb (C) | relpos_emb * chain_i*chain_j (C) | dist_feat (C) | dihedral enc (2*9)]
 __global__ void pair_cat_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
                                 int resid_bstride, const int64_t* __restrict__ chain, const float* __restrict__ pdih,
                                 const float* __restrict__ dist_feat, const float* __restrict__ pair_emb, const float* __restrict__ rel_emb,
-                                int K, int C, int max_dist, int64_t row0, float* __restrict__ out) {
+                                int K, int C, int max_dist, int64_t row0, float* __restrict__ out, int ldo) {
   const int64_t lr = blockIdx.x, row = row0 + lr;
   const int64_t b = row / (static_cast<int64_t>(K) * K);
   const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
@@ -103,7 +120,8 @@ __global__ void pair_cat_kernel(const int64_t* __restrict__ seq, const uint8_t* 
   rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
   const float same = static_cast<float>(chain[ri] * chain[rj]);  // a product, not an equality test (:279)
   const int W = 3 * C + 18;
-  float* o = out + lr * W;
+  float* o = out + lr * ldo;  // ldo = round_up(W, 4); pad columns zero
+  for (int c = W + threadIdx.x; c < ldo; c += blockDim.x) o[c] = 0.0f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     o[c] = pair_emb[(si * kAA + sj) * C + c];
     o[C + c] = rel_emb[(rel + max_dist) * C + c] * same;
@@ -168,8 +186,18 @@ int diffab_residue_embedding_fwd(const diffab_ctx_dims* d, const diffab_residue_
   return launch_linear(h3, D, w->w6, w->b6, out, D, rows, D, D, false, st);
 }
 
+static int round4(int n) { return (n + 3) & ~3; }
+
+// dst[r][0:ld_dst] = src[r][0:n] followed by zeros (weight rows padded to a multiple of 4 floats: 16-byte aligned rows)
+__global__ void pad_rows_kernel(const float* __restrict__ src, int n, int rows, float* __restrict__ dst, int ld_dst) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * ld_dst) return;
+  const int r = gid / ld_dst, c = gid % ld_dst;
+  dst[gid] = c < n ? src[r * n + c] : 0.0f;
+}
+
 static int pair_chunk_patches(const diffab_ctx_dims* d) {
-  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (d->A * d->A + 7 * d->C + 18) * sizeof(float);
+  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (round4(d->A * d->A) + 4 * d->C + round4(3 * d->C + 18)) * sizeof(float);
   const size_t budget = static_cast<size_t>(512) << 20;  // ~0.5 GiB of row buffers at a time
   const size_t n = budget / per_patch;
   return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
@@ -178,7 +206,8 @@ static int pair_chunk_patches(const diffab_ctx_dims* d) {
 size_t diffab_pair_embedding_workspace_bytes(const diffab_ctx_dims* d) {
   if (check_ctx(d, "pair_embedding_workspace_bytes")) return 0;
   const size_t rows = static_cast<size_t>(pair_chunk_patches(d)) * d->K * d->K;
-  return (rows * (d->A * d->A + 7 * d->C + 18) + 64) * sizeof(float);
+  const size_t wpad = static_cast<size_t>(d->C) * (round4(d->A * d->A) + round4(3 * d->C + 18)) + static_cast<size_t>(kAA) * kAA * d->A * d->A;
+  return (rows * (round4(d->A * d->A) + 4 * d->C + round4(3 * d->C + 18)) + wpad + 64) * sizeof(float);
 }
 
 static int pair_embedding_impl(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
@@ -193,31 +222,37 @@ static int pair_embedding_impl(const diffab_ctx_dims* d, const diffab_pair_emb_w
                  DIFFAB_ERR_ARG, "pair_embedding_fwd: null pointer");
   DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_fwd: workspace");
   hipStream_t st = as_stream(stream);
-  const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18;
+  const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18, AA2p = round4(AA2), Wp = round4(W);
   const int bc = pair_chunk_patches(d);
   const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
   float* din = static_cast<float*>(workspace);
-  float* h1 = din + static_cast<size_t>(bc) * per_patch * AA2;
+  float* h1 = din + static_cast<size_t>(bc) * per_patch * AA2p;
   float* df = h1 + static_cast<size_t>(bc) * per_patch * C;
   float* cat = df + static_cast<size_t>(bc) * per_patch * C;
-  float* m1 = cat + static_cast<size_t>(bc) * per_patch * W;
+  float* m1 = cat + static_cast<size_t>(bc) * per_patch * Wp;
   float* m2 = m1 + static_cast<size_t>(bc) * per_patch * C;
+  float* dw0p = m2 + static_cast<size_t>(bc) * per_patch * C;  // [C][AA2p]
+  float* mw0p = dw0p + static_cast<size_t>(C) * AA2p;          // [C][Wp]
+  float* coef_sp = mw0p + static_cast<size_t>(C) * Wp;          // [441][AA2] softplus(pair2distcoef)
+  hipLaunchKernelGGL(softplus_table_kernel, dim3((kAA * kAA * AA2 + 255) / 256), dim3(256), 0, st, w->pair2distcoef, kAA * kAA * AA2, coef_sp);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((C * AA2p + 255) / 256), dim3(256), 0, st, w->dw0, AA2, C, dw0p, AA2p);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((C * Wp + 255) / 256), dim3(256), 0, st, w->mw0, W, C, mw0p, Wp);
+  DIFFAB_LAUNCH_CHECK();
   for (int b0 = 0; b0 < d->B; b0 += bc) {
     const int nb = (d->B - b0) < bc ? (d->B - b0) : bc;
     const int64_t row0 = b0 * per_patch, nrows = nb * per_patch;
     const int rows = static_cast<int>(nrows);
-    const int64_t n1 = nrows * AA2;
-    hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, seq_idx, sequence_context_mask,
-                       distmat, xyz, atom_mask, w->pair2distcoef, d->K, d->A, row0, nrows, din);
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq_idx, sequence_context_mask, distmat, xyz,
+                       atom_mask, coef_sp, d->K, d->A, row0, nrows, din, AA2p);
     DIFFAB_LAUNCH_CHECK();
-    if (int rc = launch_linear(din, AA2, w->dw0, w->db0, h1, C, rows, C, AA2, true, st)) return rc;
+    if (int rc = launch_linear(din, AA2p, dw0p, w->db0, h1, C, rows, C, AA2p, true, st)) return rc;
     if (int rc = launch_linear(h1, C, w->dw2, w->db2, df, C, rows, C, C, true, st)) return rc;
     hipLaunchKernelGGL(pair_cat_kernel, dim3(static_cast<unsigned>(nrows)), dim3(64), 0, st, seq_idx, sequence_context_mask, residue_idx,
                        residue_idx_batch_stride, chain_idx, pairwise_dihedrals, df, w->aa_pair_emb, w->relpos_emb, d->K, C, d->max_dist,
-                       row0, cat);
+                       row0, cat, Wp);
     DIFFAB_LAUNCH_CHECK();
     float* o = out + row0 * C;
-    if (int rc = launch_linear(cat, W, w->mw0, w->mb0, m1, C, rows, C, W, true, st)) return rc;
+    if (int rc = launch_linear(cat, Wp, mw0p, w->mb0, m1, C, rows, C, Wp, true, st)) return rc;
     if (int rc = launch_linear(m1, C, w->mw2, w->mb2, m2, C, rows, C, C, true, st)) return rc;
     if (int rc = launch_linear(m2, C, w->mw4, w->mb4, o, C, rows, C, C, false, st)) return rc;
   }

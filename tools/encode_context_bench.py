@@ -1,0 +1,31 @@
+"""Timing of DiffAb.encode_context at the benchmark model: B patches of K residues, A=15 atoms;
+with the materialised distance tensor (reference signature) and with distances taken from xyz inside the pair kernel."""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "diffab-pytorch_amd"))
+import torch  # noqa: E402
+
+from diffab_pytorch import DiffAb, synthetic as syn  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+d = syn.BENCH_DIMS
+model = DiffAb(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+model.load_state_dict(syn.context_state_dict(d["D"], d["C"], 15, 32, seed=1), strict=False)
+cb = {k: v.cuda() for k, v in syn.context_batch(B, K, 15, seed=1).items()}
+args = lambda dm: (cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], dm, cb["pairwise_dihedrals"], cb["atom_mask"],
+                   cb["chain_idx"], cb["residue_idx"], cb["generation_mask"], cb["residue_mask"])
+for name, dm in (("distmat", cb["distmat"]), ("xyz", None)):
+    for _ in range(2):
+        model.encode_context(*args(dm))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        model.encode_context(*args(dm))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"encode_context[{name}] B={B} K={K}: {dt*1e3:.2f} ms = {dt*1e3/B:.4f} ms/patch; distmat stream {B*K*K*225*4/dt/1e9:.0f} GB/s-equivalent")
