@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=300)
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
+    ap.add_argument("--split-attention", action="store_true", help="attention as three launches (csrc/attention_split.hip) instead of fused")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,7 +141,7 @@ def main():
     sd_dev = model._sched_on_device()
     tab = model._reverse_so3().struct()
     ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
-    flags = _hip.FLAG_FORCE_GENERIC if args.generic else 0
+    flags = _hip.FLAG_FORCE_GENERIC if args.generic else (_hip.FLAG_SPLIT_ATTENTION if args.split_attention else 0)
     seed = 2024
     _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, model.T,
                                       _hip.stream_ptr()), "sample_init")
@@ -211,19 +212,21 @@ def main():
                 "workload": f"batch={B}/GPU synthetic K={K} patches, reverse sampling steps (T=100 schedule), benchmark model "
                             "D=128 C=64 NL=6 H=8 ds=32 P=8 (reference train.py:62-70), random-init weights",
                 "patches_per_gpu": B, "K": K, "global_batch": world * B, "parallelism": f"patch-sharded x{world}",
-                "path": "generic" if args.generic else "mfma",
+                "path": "generic" if args.generic else ("mfma-split-attention" if args.split_attention else "mfma"),
             },
             "residue_steps_per_s_per_gpu": value / world,
             "whole_path_hbm_frac": value / world * algorithmic_bytes_per_residue_step(K, dims["D"], dims["C"], dims["NL"]) / 1e9
                                    / HBM_PEAK_GBPS,
             "roofline": {
-                "kernel": "ipa_attention (pair-embedding stream: bias + softmax + attn-weighted pair/scalar/point sums)",
+                "kernel": ("ipa_pair_stream_kernel (pair-embedding stream: bias + softmax + attn-weighted pair sums; logits and P x V "
+                           "are separate launches)") if args.split_attention else
+                          "ipa_attention (pair-embedding stream: bias + softmax + attn-weighted pair/scalar/point sums)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
+                "traffic": None if args.split_attention else traffic,  # the PMC file under profiles/ is for the fused kernel
                 "launches": launches.value,
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg,

@@ -1,0 +1,376 @@
+// attention_split.hip - the IPA attention of the benchmark geometry as three kernels, each tiled for what bounds it
+// (single key chunk: K = 64 or 128; reference InvariantPointAttentionLayer.forward, diffab_pytorch.py:389-465).
+//
+// The fused kernel in denoiser_fast.hip runs its three phases back to back inside one work-group, so the pair stream is in
+// flight for only half of a work-group's life and the key-side operands are re-staged by each of the 8 row tiles of a patch.
+// Here the phases are separate launches that exchange the (B, 8, K, K) logits / probabilities through HBM (+25 % bytes on top
+// of the pair stream, which is not the bound):
+//   A  ipa_logits_kernel       work-group = (patch, head, 64 query rows): k_s / k_pts of the head staged ONCE in LDS for the
+//                              whole work-group, scalar logits on the MFMA, point logits as direct differences (packed fp32)
+//                              -> S[b][h][i][j] = 3^-1/2 (q.k / sqrt(ds) + coef_h |q_pts - k_pts|^2)
+//   B  ipa_pair_stream_kernel  wave = query rows, no barrier, no logits image in LDS: streams the pair row e[i] once
+//                              (non-temporal, 128 VGPRs), adds the pair bias (MFMA), softmax in registers, o_e on the MFMA,
+//                              writes the NORMALISED probabilities back in place of the logits and o_e to the feature row;
+//                              the next row's tiles are requested while the current row's are retired
+//   C  ipa_pv_kernel           work-group = (patch, head, 64 query rows): v_s / v_pts staged once in LDS, o_s and o_pts on the
+//                              MFMA with P as the A operand, global->local frames and norms -> feature row.
+#include <type_traits>
+
+#include "common.h"
+#include "denoiser_internal.h"
+
+namespace diffab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MEM_FENCE() asm volatile("" ::: "memory")
+#ifdef DIFFAB_ACCURATE_EXP
+#define FAST_EXP(x) expf(x)
+#else
+#define FAST_EXP(x) __expf(x)
+#endif
+
+namespace {
+constexpr int AH = 8, ADS = 32, AP = 8, AC = 64;
+constexpr int ANP = 3 * AH * ADS + 3 * AH * AP * 3;             // 1344 projection columns
+constexpr int AF = AH * ADS + AH * AC + AH * AP * 3 + AH * AP;  // 1024 feature columns
+constexpr int OFF_QS = 0, OFF_KS = 256, OFF_VS = 512, OFF_GQ = 768, OFF_GK = 960, OFF_GV = 1152;
+constexpr int FOFF_OS = 0, FOFF_OE = 256, FOFF_OL = 768, FOFF_ON = 960;
+constexpr int RB = 64;  // query rows per work-group in kernels A and C (4 waves x one 16-row MFMA tile)
+}  // namespace
+
+// ================================================================== A: logits
+constexpr int KLD = 40, GLD = 28;  // LDS row strides (floats) of the staged k_s / k_pts rows: ds_read_b128 conflict-free
+
+__global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
+                                                         float* __restrict__ SP, int K) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [K][KLD] k_s rows, then [K][GLD] k_pts rows of this head
+  float* ks_l = lds;
+  float* gk_l = lds + K * KLD;
+  const int nrb = K / RB;
+  const int rb = blockIdx.x % nrb, h = (blockIdx.x / nrb) % AH, b = blockIdx.x / (nrb * AH);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int64_t prow0 = static_cast<int64_t>(b) * K;
+  // stage the key side of head h: full 128-byte lines (8 lanes per k_s row, 6 per k_pts row)
+  for (int idx = tid; idx < K * 8; idx += 256) {
+    const int j = idx >> 3, c4 = idx & 7;
+    *reinterpret_cast<f32x4*>(ks_l + j * KLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_KS + h * ADS + 4 * c4);
+  }
+  for (int idx = tid; idx < K * 6; idx += 256) {
+    const int j = idx / 6, c4 = idx % 6;
+    *reinterpret_cast<f32x4*>(gk_l + j * GLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_GK + h * 24 + 4 * c4);
+  }
+  const int i0 = rb * RB + 16 * wv;  // this wave's 16 query rows
+  const float scale_t = 0.57735026918962576f;                     // 3^-1/2   (diffab_pytorch.py:387, :439)
+  const float scale_s = 0.17677669529663687f;                     // 32^-1/2  (:353)
+  const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];   // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
+  // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
+  f32x4 qa[2];
+  const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
+  qa[0] = *reinterpret_cast<const f32x4*>(qrow);
+  qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
+  // query points of the 4 rows this lane accumulates (rows i0 + 4q + r); the 16 lanes of a quarter share each address
+  f32x4 gq[4][6];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float* p = proj + (prow0 + i0 + 4 * q + r) * ANP + OFF_GQ + h * 24;
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) gq[r][cc] = *reinterpret_cast<const f32x4*>(p + 4 * cc);
+  }
+  __syncthreads();
+  float* srow = SP + ((static_cast<int64_t>(b) * AH + h) * K + i0 + 4 * q) * K + l15;  // + r rows, + 16 jt keys
+  const int ntile = K / 16;
+  for (int jt = 0; jt < ntile; ++jt) {
+    const float* kt = ks_l + (jt * 16 + l15) * KLD + 4 * q;
+    const f32x4 kb0 = *reinterpret_cast<const f32x4*>(kt);  // k_s[16 jt + l15][16 sg + 4 q + s]
+    const f32x4 kb1 = *reinterpret_cast<const f32x4*>(kt + 16);
+    f32x4 gk[6];
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) gk[cc] = *reinterpret_cast<const f32x4*>(gk_l + (jt * 16 + l15) * GLD + 4 * cc);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
+    // acc[r] = q_s[i0 + 4q + r] . k_s[key 16 jt + l15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x2 d2v = {0.f, 0.f};  // packed fp32: two coordinates per instruction, two partial sums added at the end
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        f32x2 dlo, dhi;  // packed subtract spelled in assembly: the compiler splits a vector fsub into two v_sub_f32
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+            : "=v"(dlo)
+            : "v"(__builtin_shufflevector(gq[r][cc], gq[r][cc], 0, 1)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 0, 1)));
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+            : "=v"(dhi)
+            : "v"(__builtin_shufflevector(gq[r][cc], gq[r][cc], 2, 3)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 2, 3)));
+        d2v = __builtin_elementwise_fma(dlo, dlo, d2v);
+        d2v = __builtin_elementwise_fma(dhi, dhi, d2v);
+      }
+      const float d2 = d2v[0] + d2v[1];
+      srow[static_cast<int64_t>(r) * K + jt * 16] = scale_t * (acc[r] * scale_s + coef_p * d2);
+    }
+  }
+}
+
+// ================================================================== C: probabilities x values
+constexpr int VLD = 36, PLD = 28;  // LDS row strides of the staged v_s (32) / v_pts (24) rows
+
+__global__ __launch_bounds__(256) void ipa_pv_kernel(const float* __restrict__ proj, const float* __restrict__ SP,
+                                                     const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ feat,
+                                                     int K) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [K][VLD] v_s rows, then [K][PLD] v_pts rows of this head
+  float* vs_l = lds;
+  float* gv_l = lds + K * VLD;
+  const int nrb = K / RB;
+  const int rb = blockIdx.x % nrb, h = (blockIdx.x / nrb) % AH, b = blockIdx.x / (nrb * AH);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int64_t prow0 = static_cast<int64_t>(b) * K;
+  for (int idx = tid; idx < K * 8; idx += 256) {
+    const int j = idx >> 3, c4 = idx & 7;
+    *reinterpret_cast<f32x4*>(vs_l + j * VLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_VS + h * ADS + 4 * c4);
+  }
+  for (int idx = tid; idx < K * 6; idx += 256) {
+    const int j = idx / 6, c4 = idx % 6;
+    *reinterpret_cast<f32x4*>(gv_l + j * PLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_GV + h * 24 + 4 * c4);
+  }
+  const int i0 = rb * RB + 16 * wv;
+  // A operand: P[i = i0 + l15][j = 16 jt + 4 q + r]; all tiles of the row requested up front (K / 16 <= 8 float4 per lane)
+  const float* prow = SP + ((static_cast<int64_t>(b) * AH + h) * K + i0 + l15) * K + 4 * q;
+  const int ntile = K / 16;
+  f32x4 pa[8];
+#pragma unroll
+  for (int jt = 0; jt < 8; ++jt)
+    if (jt < ntile) pa[jt] = *reinterpret_cast<const f32x4*>(prow + jt * 16);
+  __syncthreads();
+  f32x4 os[2], og[3];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) og[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int pp = l15 & 7;
+#pragma unroll
+  for (int jt = 0; jt < 8; ++jt) {
+    if (jt < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = jt * 16 + 4 * q + r;  // B operand row k = q (keys 4 q + r of the step), column n = l15
+        const f32x2 vv = *reinterpret_cast<const f32x2*>(vs_l + key * VLD + 2 * l15);  // d = 2 l15 + dt
+        const float* g = gv_l + key * PLD + 3 * pp;                                      // point pp, coords 0..2
+        const float gx = g[0], gy = g[1], gz = g[2];
+        os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[jt][r], vv[0], os[0], 0, 0, 0);
+        os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[jt][r], vv[1], os[1], 0, 0, 0);
+        og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[jt][r], gx, og[0], 0, 0, 0);
+        og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[jt][r], gy, og[1], 0, 0, 0);
+        og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[jt][r], gz, og[2], 0, 0, 0);
+      }
+    }
+  }
+  // D rows i = 4 q + r, column n = l15 (probabilities arrive normalised: no 1/L here)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = prow0 + i0 + 4 * q + r;
+    float* fr = feat + row * AF;
+    *reinterpret_cast<float2*>(fr + FOFF_OS + h * ADS + 2 * l15) = make_float2(os[0][r], os[1][r]);
+    if (l15 < 8) {
+      const float* Rr = R + row * 9;
+      const float* tr = t + row * 3;
+      const float dx = og[0][r] - tr[0], dy = og[1][r] - tr[1], dz = og[2][r] - tr[2];
+      const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
+      const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
+      const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
+      float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
+      fo[0] = lx; fo[1] = ly; fo[2] = lz;
+      fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
+    }
+  }
+}
+
+// ================================================================== B: pair stream
+// NT key tiles of 16 (K = 16 NT).  A work-group is 8 independent waves; wave w owns RPW consecutive query rows of one patch.
+constexpr int ELD = 72;  // pair-tile stride (floats) of the per-wave re-orientation scratch
+
+template <int NT, int RPW>
+__global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __restrict__ e, const float* __restrict__ Wb,
+                                                              float* __restrict__ SP, float* __restrict__ feat, int rows_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: 2 tiles [16][ELD]
+  constexpr int K = 16 * NT;
+  const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
+  float* scr = lds + wv * (2 * 16 * ELD);
+  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 8 + wv) * RPW;  // global row (b K + i) of this wave's first row
+  if (row_first >= rows_total) return;
+  const int l15 = lane0 & 15, q = lane0 >> 4;
+  const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15 - 8 (their MFMA columns are padding)
+  const float scale_t = 0.57735026918962576f;
+  // bias B fragments: Wb[h][16 sg + 4 q + s] for lane (h = l15 < 8, q), zero in the padding columns
+  f32x4 wb[4];
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg) {
+    wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
+  }
+  // e[row, :, :] streamed once in the orientation of the o_e product: lane (l15, q) holds e[row][j = 16 jt + 4 q + r][c = 4 l15 .. + 3]
+  f32x4 ev[2][NT][4];
+  auto load_e_tile = [&](int slot, int64_t row, int jt) {
+    const f32x4* ep = reinterpret_cast<const f32x4*>(e + (row * K + jt * 16 + 4 * q) * AC + 4 * l15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ev[slot][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
+  };
+  // logits of (row, head h, keys 16 jt + 4 q + r): S[b][h][i][j] with row = b K + i
+  auto sp_of = [&](int64_t row) { return SP + ((row / K) * AH * K + static_cast<int64_t>(h) * K + row % K) * K + 4 * q; };
+  auto stage_e = [&](int slot, int jt) {  // tile re-orientation for the bias product: write [key 4q+r][chunk l15], read [key l15][16 sg + 4 q ..]
+    float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[slot][jt][r];
+  };
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) load_e_tile(0, row_first, jt);
+  MEM_FENCE();
+
+  auto do_row = [&](auto slot_c, int64_t row, auto has_next_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr bool has_next = decltype(has_next_c)::value;
+    float* sp = sp_of(row);
+    f32x4 lgv[NT];  // logits, then exp(logit - M), of keys 16 jt + 4 q + r for head h
+#pragma unroll
+#ifdef SPB_ABL_NOSLOAD
+    for (int jt = 0; jt < NT; ++jt) lgv[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+    for (int jt = 0; jt < NT; ++jt) lgv[jt] = *reinterpret_cast<const f32x4*>(sp + jt * 16);
+#endif
+    MEM_FENCE();
+    float mx = -INFINITY;
+    stage_e(slot, 0);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      if (jt + 1 < NT) stage_e(slot, jt + 1);
+      const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains of 8: half the dependent-MFMA latency
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[row][16 jt + l15][16 sg + 4 q + s]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wb[sg][s], acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wb[sg][s], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = lgv[jt][r] + scale_t * (acc[r] + acc2[r]);
+        lgv[jt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = FAST_EXP(lgv[jt][r] - mx);
+        lgv[jt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // normalised probabilities back in place of the logits, BEFORE any load of the next row is issued: a later wait for those
+    // loads then finds these stores long acknowledged (a wait for loads with younger stores in flight waits for the stores too)
+#ifndef SPB_ABL_NOPSTORE
+    if (l15 < 8) {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) *reinterpret_cast<f32x4*>(sp + jt * 16) = lgv[jt] * inv;
+    }
+#endif
+    // o_e[h][c] = sum_j P[h][j] e[row][j][c]: P (unnormalised) is the B operand straight from registers
+    f32x4 oe[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)  // A: e[row][j = 16 jt + 4 q + r][c = 4 l15 + ct]
+          oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[slot][jt][r][ct], lgv[jt][r], oe[ct], 0, 0, 0);
+      if (has_next) {  // the retired tile frees its registers' twin in the other slot: request the next row's tile
+        load_e_tile(1 - slot, row + 1, jt);
+        MEM_FENCE();
+      }
+    }
+    // D: column h = l15, row m = 4 q + r' <-> channel 4 m + ct = 16 q + 4 r' + ct
+    if (l15 < 8) {
+      float* fo = feat + row * AF + FOFF_OE + h * AC + 16 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 v = {oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
+        *reinterpret_cast<f32x4*>(fo + 4 * r) = v * inv;
+      }
+    }
+  };
+  // RPW is small and even: the row loop is spelled out so that "is there a next row" is a compile-time fact (a run-time flag
+  // puts a branch around every prefetch, and the compiler's vmcnt bookkeeping then waits for loads it has just issued)
+  static_assert(RPW == 2 || RPW == 4 || RPW == 8, "rows per wave");
+  constexpr std::integral_constant<int, 0> s0{};
+  constexpr std::integral_constant<int, 1> s1{};
+  constexpr std::true_type more{};
+  constexpr std::false_type done{};
+  do_row(s0, row_first + 0, more);
+  if constexpr (RPW == 2) {
+    do_row(s1, row_first + 1, done);
+  } else {
+    do_row(s1, row_first + 1, more);
+    do_row(s0, row_first + 2, more);
+    if constexpr (RPW == 4) {
+      do_row(s1, row_first + 3, done);
+    } else {
+      do_row(s1, row_first + 3, more);
+      do_row(s0, row_first + 4, more);
+      do_row(s1, row_first + 5, more);
+      do_row(s0, row_first + 6, more);
+      do_row(s1, row_first + 7, done);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+bool attention_split_supported(const diffab_dims* d) { return d->K == 64 || d->K == 128; }
+
+size_t attention_split_workspace_floats(const diffab_dims* d) { return static_cast<size_t>(d->B) * AH * d->K * d->K; }
+
+int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
+                           const float* gamma, float* feat, float* SP, hipStream_t st) {
+  const int K = d->K, rows = d->B * K;
+  DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_split: K must be 64 or 128");
+  const dim3 grid_ac(d->B * AH * (K / RB));
+  const size_t lds_a = static_cast<size_t>(K) * (KLD + GLD) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
+  hipLaunchKernelGGL(ipa_logits_kernel, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, K);
+  DIFFAB_LAUNCH_CHECK();
+#ifndef SPB_RPW
+#define SPB_RPW 4
+#endif
+  constexpr int RPW = SPB_RPW;  // rows per wave: 8 RPW per work-group
+  const size_t lds_b = static_cast<size_t>(8) * 2 * 16 * ELD * sizeof(float);
+  const dim3 grid_b((rows + 8 * RPW - 1) / (8 * RPW));
+  timer_begin(st);
+  if (K == 128) {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_kernel<8, RPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+    hipLaunchKernelGGL((ipa_pair_stream_kernel<8, RPW>), grid_b, dim3(512), lds_b, st, e, Wb, SP, feat, rows);
+  } else {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_kernel<4, RPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+    hipLaunchKernelGGL((ipa_pair_stream_kernel<4, RPW>), grid_b, dim3(512), lds_b, st, e, Wb, SP, feat, rows);
+  }
+  timer_end(st);
+  DIFFAB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ipa_pv_kernel, grid_ac, dim3(256), lds_c, st, proj, SP, R, t, feat, K);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // namespace diffab

@@ -1050,11 +1050,11 @@ bool fast_path_supported(const diffab_dims* d) {
 
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
-  return rows * (ANP + AF) + 128;
+  return rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0);
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st) {
+                   float* y, float* ws, hipStream_t st, bool split_attention) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1086,6 +1086,14 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     DIFFAB_LAUNCH_CHECK();
   }
 #endif
+  // DIFFAB_FLAG_SPLIT_ATTENTION (K = 64 / 128): three launches exchanging logits / probabilities through HBM (attention_split.hip).
+  // Its pair-stream kernel sustains 3.8 TB/s (47 % of the HBM peak) against 2.9 for the fused kernel below, but the logits and
+  // P x V launches are not yet at their floors and the three together are slower (0.45 vs 0.37 ms) - hence opt-in.
+  if (split_attention && attention_split_supported(d)) {
+    float* SP = feat + static_cast<size_t>(rows) * AF + 128;
+    if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
+    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+  }
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
   const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);

@@ -18,7 +18,7 @@ int launch_heads_finish(const float* v, const float* O_t, const float* logits, i
 bool fast_path_supported(const diffab_dims* d);
 size_t ipa_fast_workspace_floats(const diffab_dims* d);
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st);
+                   float* y, float* ws, hipStream_t st, bool split_attention = false);
 // Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);
@@ -31,6 +31,13 @@ int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const fl
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
                        hipStream_t st);
+
+// attention_split.hip: the attention of one IPA layer as three launches (logits | pair stream | P x V) exchanging the
+// (B, 8, K, K) logits / probabilities through SP; single key chunk only (K = 64, 128)
+bool attention_split_supported(const diffab_dims* d);
+size_t attention_split_workspace_floats(const diffab_dims* d);
+int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
+                           const float* gamma, float* feat, float* SP, hipStream_t st);
 
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 

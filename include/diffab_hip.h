@@ -39,6 +39,8 @@ extern "C" {
 
 /* flags */
 #define DIFFAB_FLAG_FORCE_GENERIC 1u /* skip the MFMA kernels specialised for D=128,C=64,H=8,DS=32,P=8 */
+#define DIFFAB_FLAG_SPLIT_ATTENTION 2u /* K = 64 / 128: the attention of each layer as three launches (logits | pair stream | P x V)
+                                          instead of the fused kernel; same results to rounding, see csrc/attention_split.hip */
 
 /* Model and batch geometry.  Reference ctor: diffab_pytorch.py:629-647. */
 typedef struct {

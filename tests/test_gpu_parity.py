@@ -237,7 +237,7 @@ def build_case(g):
     return dims, den, inp
 
 
-@pytest.mark.parametrize("flags", [0, _hip.FLAG_FORCE_GENERIC], ids=["dispatch", "generic"])
+@pytest.mark.parametrize("flags", [0, _hip.FLAG_FORCE_GENERIC, _hip.FLAG_SPLIT_ATTENTION], ids=["dispatch", "generic", "split"])
 @pytest.mark.parametrize("name", CASES)
 def test_denoiser_vs_reference_goldens(hip, golden, name, flags):
     g = golden("denoiser_" + name)
