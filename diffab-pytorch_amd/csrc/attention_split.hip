@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int64_t prow0 = static_cast<int64_t>(b) * K;
   // stage the key side of head h: full 128-byte lines (8 lanes per k_s row, 6 per k_pts row)
+#ifdef SPA_ABL_NOSTAGE
+  for (int idx = tid; idx < 8; idx += 256) {
+#else
   for (int idx = tid; idx < K * 8; idx += 256) {
+#endif
     const int j = idx >> 3, c4 = idx & 7;
     *reinterpret_cast<f32x4*>(ks_l + j * KLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_KS + h * ADS + 4 * c4);
   }
@@ -78,7 +82,11 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
     for (int cc = 0; cc < 6; ++cc) gq[r][cc] = *reinterpret_cast<const f32x4*>(p + 4 * cc);
   }
   __syncthreads();
-  float* srow = SP + ((static_cast<int64_t>(b) * AH + h) * K + i0 + 4 * q) * K + l15;  // + r rows, + 16 jt keys
+  // Results leave through a per-wave LDS tile [16 rows][32 keys] (two key tiles): the MFMA layout gives a lane one key of four rows,
+  // i.e. 4-byte stores in 64-byte runs; re-read row-major, a lane stores 16 bytes and 8 lanes cover a full 128-byte line of a row.
+  constexpr int OLD = 36;  // tile row stride (floats)
+  float* otile = gk_l + K * GLD + wv * (16 * OLD);
+  float* sbase = SP + ((static_cast<int64_t>(b) * AH + h) * K + i0) * K;
   const int ntile = K / 16;
   for (int jt = 0; jt < ntile; ++jt) {
     const float* kt = ks_l + (jt * 16 + l15) * KLD + 4 * q;
@@ -96,8 +104,13 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       f32x2 d2v = {0.f, 0.f};  // packed fp32: two coordinates per instruction, two partial sums added at the end
+#ifdef SPA_ABL_NOVALU
+      d2v[0] = gk[r][0] + gq[r][0][0];
+      for (int cc = 0; cc < 0; ++cc) {
+#else
 #pragma unroll
       for (int cc = 0; cc < 6; ++cc) {
+#endif
         f32x2 dlo, dhi;  // packed subtract spelled in assembly: the compiler splits a vector fsub into two v_sub_f32
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
             : "=v"(dlo)
@@ -109,7 +122,18 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
         d2v = __builtin_elementwise_fma(dhi, dhi, d2v);
       }
       const float d2 = d2v[0] + d2v[1];
-      srow[static_cast<int64_t>(r) * K + jt * 16] = scale_t * (acc[r] * scale_s + coef_p * d2);
+      otile[(4 * q + r) * OLD + (jt & 1) * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
+    }
+    if (jt & 1) {  // two key tiles complete: rows (lane >> 3) and 8 + (lane >> 3), keys 4 (lane & 7) .. + 3 of the 32
+      const int orow = lane >> 3, oc = 4 * (lane & 7);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(otile + (orow + 8 * half) * OLD + oc);
+#ifdef SPA_ABL_NOSTORE
+        if (K < 0)
+#endif
+        *reinterpret_cast<f32x4*>(sbase + static_cast<int64_t>(orow + 8 * half) * K + (jt - 1) * 16 + oc) = v;
+      }
     }
   }
 }
@@ -347,7 +371,7 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
   const int K = d->K, rows = d->B * K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_split: K must be 64 or 128");
   const dim3 grid_ac(d->B * AH * (K / RB));
-  const size_t lds_a = static_cast<size_t>(K) * (KLD + GLD) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
+  const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 4 * 16 * 36) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
   hipLaunchKernelGGL(ipa_logits_kernel, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, K);
   DIFFAB_LAUNCH_CHECK();
 #ifndef SPB_RPW

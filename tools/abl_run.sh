@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 for name in "$@"; do
   export DIFFAB_HIP_LIB=$GRAFT_REPO_ROOT/diffab-pytorch_amd/build_abl/$name/libdiffab_hip.so
   rm -rf /tmp/abl_$name
-  timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$name -o run -- python3 $GRAFT_REPO_ROOT/tools/attn_phase_profile.py ${ABL_B:-256} ${ABL_K:-128} > /tmp/abl_$name.log 2>&1
+  timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$name -o run -- python3 $GRAFT_REPO_ROOT/tools/${ABL_TOOL:-attn_phase_profile.py} ${ABL_B:-256} ${ABL_K:-128} > /tmp/abl_$name.log 2>&1
   echo "== $name"; grep -E "phase1|phase2 prol|phase2 \(|phase3|lifetime" /tmp/abl_$name.log
   python3 - "$name" <<'P'
 import csv, sys
