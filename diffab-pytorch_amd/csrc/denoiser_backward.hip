@@ -541,6 +541,296 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
   }
 }
 
+// Same pass for RR consecutive query rows per work-group (vector path only: DS, C, 3 PQ, 3 PV multiples of 4, K % RR == 0).
+// The one-row kernel above re-reads the whole key side of the patch (k_s, k_pts, v_s, v_pts: 448 KiB at the benchmark geometry,
+// twice for k) from L2 for every query row - 0.9 MB per row, 15 GB per layer at B = 128 - and that traffic, not the arithmetic,
+// sets its 2.3 ms.  Here every key-side value is loaded once and used for RR rows; the per-row state lives in RR LDS slots.
+template <int RR>
+__global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* __restrict__ proj, const float* __restrict__ e,
+                                                                   const float* __restrict__ R, const float* __restrict__ Wb,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ feat,
+                                                                   const float* __restrict__ dfeat, float* __restrict__ dproj,
+                                                                   float* __restrict__ de, float* __restrict__ At, float* __restrict__ Gt,
+                                                                   float* __restrict__ dogbuf, float* __restrict__ wb_part, int K, int C,
+                                                                   int H, int DS, int PQ, int PV) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const int nblk = K / RR;
+  const int b = blockIdx.x / nblk, i0 = (blockIdx.x % nblk) * RR;
+  const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
+  const int F = H * DS + H * C + H * PV * 3 + H * PV;
+  const int off_ks = H * DS, off_vs = 2 * H * DS, off_gq = 3 * H * DS, off_gk = off_gq + H * PQ * 3, off_gv = off_gk + H * PQ * 3;
+  const int n_os = H * DS, n_oe = H * C, n_og = H * PV * 3;
+  const int HK = H * K, NQ = H * DS + H * PQ * 3;
+  const int PR = ((3 * HK + NQ + n_og + H + F) + 3) & ~3;  // floats per row slot
+  auto attn_of = [&](int rr) { return smem + rr * PR; };            // H*K probabilities
+  auto gl_of = [&](int rr) { return smem + rr * PR + HK; };         // H*K dA, then scale_t * dlogit
+  auto d2_of = [&](int rr) { return smem + rr * PR + 2 * HK; };     // H*K squared point distances
+  auto q_of = [&](int rr) { return smem + rr * PR + 3 * HK; };      // q_s | q_pts of the row
+  auto dog_of = [&](int rr) { return smem + rr * PR + 3 * HK + NQ; };
+  auto red_of = [&](int rr) { return smem + rr * PR + 3 * HK + NQ + n_og; };
+  auto dfl_of = [&](int rr) { return smem + rr * PR + 3 * HK + NQ + n_og + H; };
+  const int64_t row0 = static_cast<int64_t>(b) * K + i0;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int rr = 0; rr < RR; ++rr) {
+    const int64_t row_i = row0 + rr;
+    const float* prow = proj + row_i * NP;
+    const float* frow = feat + row_i * F;
+    const float* dfrow = dfeat + row_i * F;
+    const float* Rr = R + row_i * 9;
+    float* qrow = q_of(rr);
+    float* dfl = dfl_of(rr);
+    float* dog = dog_of(rr);
+    for (int d = tid; d < H * DS; d += nthr) qrow[d] = prow[d];
+    for (int d = tid; d < H * PQ * 3; d += nthr) qrow[H * DS + d] = prow[off_gq + d];
+    for (int d = tid; d < F; d += nthr) dfl[d] = dfrow[d];
+    for (int hp = tid; hp < H * PV; hp += nthr) {  // d o_g[k] = sum_c (do_l[c] + do_n o_l[c]/o_n) R[c][k]
+      const float on = frow[n_os + n_oe + n_og + hp], don = dfrow[n_os + n_oe + n_og + hp];
+      float dl[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float ol = frow[n_os + n_oe + hp * 3 + c];
+        dl[c] = dfrow[n_os + n_oe + hp * 3 + c] + (on > 0.0f ? don * ol / on : 0.0f);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float v = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
+        dog[hp * 3 + k] = v;
+        dogbuf[row_i * n_og + hp * 3 + k] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
+  const float scale_p = -0.5f / sqrtf(4.5f * PQ);
+  const float scale_t = 1.0f / sqrtf(3.0f);
+  const int lo = tid & 7, oct = tid >> 3, noct = nthr >> 3;
+  const float* e0 = e + row0 * K * C;  // + rr * K * C
+  // sum over the 8 lanes of an octet of 8 per-lane values, lane `lo` ending with total number `lo` (reduce-scatter: 7 shuffles)
+  auto octet_reduce_scatter = [&](const float (&v)[8]) {
+    float w4[4], w2[2];
+    const bool b2 = (lo & 4) != 0, b1 = (lo & 2) != 0, b0 = (lo & 1) != 0;
+#pragma unroll
+    for (int k_ = 0; k_ < 4; ++k_) {
+      const float send = b2 ? v[k_] : v[k_ + 4], keep = b2 ? v[k_ + 4] : v[k_];
+      w4[k_] = keep + __shfl_xor(send, 4);
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < 2; ++k_) {
+      const float send = b1 ? w4[k_] : w4[k_ + 2], keep = b1 ? w4[k_ + 2] : w4[k_];
+      w2[k_] = keep + __shfl_xor(send, 2);
+    }
+    const float send = b0 ? w2[0] : w2[1], keep = b0 ? w2[1] : w2[0];
+    return keep + __shfl_xor(send, 1);
+  };
+  // ---- recompute logits: key-side vectors loaded once per (h, j), used for the RR rows
+  for (int idx = oct; idx < HK; idx += noct) {
+    const int h = idx / K, j = idx % K;
+    const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+    float ls[RR], lp[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) ls[rr] = lp[rr] = 0.f;
+    for (int d = 4 * lo; d < DS; d += 32) {
+      const v4 kv = *reinterpret_cast<const v4*>(krow + off_ks + h * DS + d);
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const v4 qv = *reinterpret_cast<const v4*>(q_of(rr) + h * DS + d);
+        ls[rr] += (qv[0] * kv[0] + qv[1] * kv[1]) + (qv[2] * kv[2] + qv[3] * kv[3]);
+      }
+    }
+    for (int p = 4 * lo; p < PQ * 3; p += 32) {
+      const v4 kv = *reinterpret_cast<const v4*>(krow + off_gk + h * PQ * 3 + p);
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const v4 dd = *reinterpret_cast<const v4*>(q_of(rr) + H * DS + h * PQ * 3 + p) - kv;
+        lp[rr] += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        ls[rr] += __shfl_xor(ls[rr], o);
+        lp[rr] += __shfl_xor(lp[rr], o);
+      }
+      if (lo == 0) {
+        d2_of(rr)[idx] = lp[rr];
+        attn_of(rr)[idx] = scale_t * (ls[rr] * scale_s + (scale_p * gamma[h]) * lp[rr]);  // the pair bias is added below
+      }
+    }
+  }
+  __syncthreads();
+  // pair bias: one octet per (row, key) reads e[i][j][:] ONCE and forms the 8 heads' dot products (H <= 8: lane lo <-> head lo);
+  // per (head, key) octets would read every pair row H times
+  for (int idx = oct; idx < RR * K; idx += noct) {
+    const int rr = idx / K, j = idx % K;
+    float part[8];
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) part[hh] = 0.f;
+    for (int c = 4 * lo; c < C; c += 32) {
+      const v4 ev = *reinterpret_cast<const v4*>(e0 + (static_cast<int64_t>(rr) * K + j) * C + c);
+#pragma unroll
+      for (int hh = 0; hh < 8; ++hh) {
+        if (hh < H) {
+          const v4 wv = *reinterpret_cast<const v4*>(Wb + hh * C + c);
+          part[hh] += (ev[0] * wv[0] + ev[1] * wv[1]) + (ev[2] * wv[2] + ev[3] * wv[3]);
+        }
+      }
+    }
+    const float tot = octet_reduce_scatter(part);
+    if (lo < H) attn_of(rr)[lo * K + j] += scale_t * tot;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  for (int rh = wave; rh < RR * H; rh += nwave) {  // softmax per (row, head)
+    float* a = attn_of(rh / H) + (rh % H) * K;
+    float m = -INFINITY;
+    for (int j = lane; j < K; j += 64) m = fmaxf(m, a[j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sacc = 0.f;
+    for (int j = lane; j < K; j += 64) {
+      const float ex = expf(a[j] - m);
+      a[j] = ex;
+      sacc += ex;
+    }
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    const float inv = 1.0f / sacc;
+    for (int j = lane; j < K; j += 64) a[j] *= inv;
+  }
+  __syncthreads();
+  // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]
+  for (int idx = oct; idx < HK; idx += noct) {
+    const int h = idx / K, j = idx % K;
+    const float* vrow = proj + (static_cast<int64_t>(b) * K + j) * NP;
+    float sacc[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) sacc[rr] = 0.f;
+    for (int d = 4 * lo; d < DS; d += 32) {
+      const v4 v = *reinterpret_cast<const v4*>(vrow + off_vs + h * DS + d);
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const v4 a = *reinterpret_cast<const v4*>(dfl_of(rr) + h * DS + d);
+        sacc[rr] += (a[0] * v[0] + a[1] * v[1]) + (a[2] * v[2] + a[3] * v[3]);
+      }
+    }
+    for (int p = 4 * lo; p < PV * 3; p += 32) {
+      const v4 v = *reinterpret_cast<const v4*>(vrow + off_gv + h * PV * 3 + p);
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const v4 a = *reinterpret_cast<const v4*>(dog_of(rr) + h * PV * 3 + p);
+        sacc[rr] += (a[0] * v[0] + a[1] * v[1]) + (a[2] * v[2] + a[3] * v[3]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) sacc[rr] += __shfl_xor(sacc[rr], o);
+      if (lo == 0) gl_of(rr)[idx] = sacc[rr];
+    }
+  }
+  __syncthreads();
+  for (int idx = oct; idx < RR * K; idx += noct) {  // the do_e . e[i][j] term of dA, all heads from one read of the pair row
+    const int rr = idx / K, j = idx % K;
+    float part[8];
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) part[hh] = 0.f;
+    for (int c = 4 * lo; c < C; c += 32) {
+      const v4 ev = *reinterpret_cast<const v4*>(e0 + (static_cast<int64_t>(rr) * K + j) * C + c);
+#pragma unroll
+      for (int hh = 0; hh < 8; ++hh) {
+        if (hh < H) {
+          const v4 a = *reinterpret_cast<const v4*>(dfl_of(rr) + n_os + hh * C + c);
+          part[hh] += (a[0] * ev[0] + a[1] * ev[1]) + (a[2] * ev[2] + a[3] * ev[3]);
+        }
+      }
+    }
+    const float tot = octet_reduce_scatter(part);
+    if (lo < H) gl_of(rr)[lo * K + j] += tot;
+  }
+  __syncthreads();
+  // ---- softmax backward: dlogit = A (dA - sum_j A dA); keep g = scale_t * dlogit
+  for (int rh = wave; rh < RR * H; rh += nwave) {
+    const float* a = attn_of(rh / H) + (rh % H) * K;
+    const float* gg = gl_of(rh / H) + (rh % H) * K;
+    float sacc = 0.f;
+    for (int j = lane; j < K; j += 64) sacc += a[j] * gg[j];
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    if (lane == 0) red_of(rh / H)[rh % H] = sacc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < HK; idx += nthr) {
+    const int h = idx / K, j = idx % K;
+    const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + j) * K + i0;  // transposed: [b][h][j][i0 .. i0 + RR)
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const float a = attn_of(rr)[idx];
+      const float g = scale_t * a * (gl_of(rr)[idx] - red_of(rr)[h]);
+      gl_of(rr)[idx] = g;
+      At[o + rr] = a;
+      Gt[o + rr] = g;
+    }
+  }
+  __syncthreads();
+  for (int rh = wave; rh < RR * H; rh += nwave) {  // dgamma_h partial of the row: sum_j g scale_p d2
+    const int rr = rh / H, h = rh % H;
+    float sacc = 0.f;
+    for (int j = lane; j < K; j += 64) sacc += gl_of(rr)[h * K + j] * scale_p * d2_of(rr)[h * K + j];
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    if (lane == 0) wb_part[(row0 + rr) * (H * C + H) + H * C + h] = sacc;
+  }
+  // ---- query-side gradients: each key value is loaded once for the RR rows
+  for (int o = tid; o < NQ; o += nthr) {
+    float acc[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) acc[rr] = 0.f;
+    if (o < H * DS) {
+      const int h = o / DS;
+      for (int j = 0; j < K; ++j) {
+        const float kv = proj[(static_cast<int64_t>(b) * K + j) * NP + off_ks + o];
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) acc[rr] += gl_of(rr)[h * K + j] * kv;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) dproj[(row0 + rr) * NP + o] = acc[rr] * scale_s;
+    } else {
+      const int oo = o - H * DS, h = oo / (PQ * 3);
+      const float cp = 2.0f * scale_p * gamma[h];
+      float qv[RR];
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) qv[rr] = q_of(rr)[H * DS + oo];
+      for (int j = 0; j < K; ++j) {
+        const float kv = proj[(static_cast<int64_t>(b) * K + j) * NP + off_gk + oo];
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) acc[rr] += gl_of(rr)[h * K + j] * (qv[rr] - kv);
+      }
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) dproj[(row0 + rr) * NP + off_gq + oo] = cp * acc[rr];
+    }
+  }
+  // ---- pair embedding: de[i][j][c] += sum_h (A do_e[h][c] + g Wb[h][c]);   dWb[h][c] partial = sum_j g e[i][j][c]
+  for (int rr = 0; rr < RR; ++rr) {
+    const float* attn = attn_of(rr);
+    const float* gl = gl_of(rr);
+    const float* dfl = dfl_of(rr);
+    const float* erow = e0 + static_cast<int64_t>(rr) * K * C;
+    if (de) {
+      float* derow = de + (row0 + rr) * K * C;
+      for (int idx = tid; idx < K * C; idx += nthr) {
+        const int j = idx / C, c = idx % C;
+        float sacc = 0.f;
+        for (int h = 0; h < H; ++h) sacc += attn[h * K + j] * dfl[n_os + h * C + c] + gl[h * K + j] * Wb[h * C + c];
+        derow[idx] += sacc;
+      }
+    }
+    for (int o = tid; o < H * C; o += nthr) {
+      const int h = o / C, c = o % C;
+      float sacc = 0.f;
+      for (int j = 0; j < K; ++j) sacc += gl[h * K + j] * erow[static_cast<int64_t>(j) * C + c];
+      wb_part[(row0 + rr) * (H * C + H) + o] = sacc;
+    }
+  }
+}
+
 // Pass 2: key-side gradients of residue j = sums over the query rows i, read contiguously from the transposed A / g images.
 __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
                                                                 const float* __restrict__ dfeat, const float* __restrict__ At,
@@ -724,9 +1014,22 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     if (lds > 64 * 1024)
       DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(ipa_attn_bwd_rows_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, lw->w_bias, lw->gamma, feat, dfeat,
-                       dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), At, Gt, dogbuf, wb_part, d->K, C, H,
-                       DS, PQ, PV, vec);
+    constexpr int RRm = 4;  // query rows per work-group of the multi-row kernel
+    const size_t slot = ((3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) + 3) & ~static_cast<size_t>(3);
+    const size_t lds_mr = RRm * slot * sizeof(float);
+#ifndef DIFFAB_BWD_ONE_ROW
+    if (vec && H <= 8 && d->K % RRm == 0 && lds_mr <= 160 * 1024) {
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
+      hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t, lw->w_bias,
+                         lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV);
+    } else
+#endif
+    {
+      hipLaunchKernelGGL(ipa_attn_bwd_rows_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, lw->w_bias, lw->gamma, feat, dfeat,
+                         dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), At, Gt, dogbuf, wb_part, d->K, C, H,
+                         DS, PQ, PV, vec);
+    }
     DIFFAB_LAUNCH_CHECK();
     // d w_bias[h][c] += sum_rows partial, d gamma[h] += sum_rows partial (one column sum over the [rows][H*C + H] partials)
     if (int rc = colsum(wb_part, H * C + H, rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
