@@ -815,30 +815,11 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     const float* erow = e0 + static_cast<int64_t>(rr) * K * C;
     if (de) {
       float* derow = de + (row0 + rr) * K * C;
-      if (H <= 8 && C <= nthr && nthr % C == 0) {
-        // thread <-> channel c (fixed), key groups strided: the 2 H per-channel factors stay in registers, the probabilities and
-        // g come from LDS as wave-wide broadcasts
-        const int c = tid % C, jg = tid / C, njg = nthr / C;
-        float fa[8], fw[8];
-#pragma unroll
-        for (int hh = 0; hh < 8; ++hh) {
-          fa[hh] = hh < H ? dfl[n_os + hh * C + c] : 0.f;
-          fw[hh] = hh < H ? Wb[hh * C + c] : 0.f;
-        }
-        for (int j = jg; j < K; j += njg) {
-          float sacc = 0.f;
-#pragma unroll
-          for (int hh = 0; hh < 8; ++hh)
-            if (hh < H) sacc += attn[hh * K + j] * fa[hh] + gl[hh * K + j] * fw[hh];
-          derow[static_cast<int64_t>(j) * C + c] += sacc;
-        }
-      } else {
-        for (int idx = tid; idx < K * C; idx += nthr) {
-          const int j = idx / C, c = idx % C;
-          float sacc = 0.f;
-          for (int h = 0; h < H; ++h) sacc += attn[h * K + j] * dfl[n_os + h * C + c] + gl[h * K + j] * Wb[h * C + c];
-          derow[idx] += sacc;
-        }
+      for (int idx = tid; idx < K * C; idx += nthr) {
+        const int j = idx / C, c = idx % C;
+        float sacc = 0.f;
+        for (int h = 0; h < H; ++h) sacc += attn[h * K + j] * dfl[n_os + h * C + c] + gl[h * K + j] * Wb[h * C + c];
+        derow[idx] += sacc;
       }
     }
     for (int o = tid; o < H * C; o += nthr) {
