@@ -95,6 +95,73 @@ def cpu_baseline(dims, sd, K, n_patches, n_steps, seed):
     }
 
 
+def other_configs(model, dims, flags):
+    """Short secondary measurements on one GPU, reported next to the headline line (never part of `value`):
+    BASELINE config 5 (K=256 long-CDR stress, 128 patches: per-GPU share of 512 on 4 GPUs) and config 4 (training step,
+    128 patches per GPU: forward + HIP backward + Adam).  Failures are reported as strings, they never break the headline."""
+    import gc
+
+    from diffab_pytorch import _hip, synthetic as syn
+
+    res = {}
+    lib = _hip.lib()
+    try:
+        B, K, steps = 128, 256, 10
+        inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=1).items()}
+        seq, x, O = inp["seq_idx"].clone(), inp["translations"].clone(), inp["orientations"].clone()
+        hd, w = model.denoiser.hip_dims(B, K), model.denoiser.hip_weights()
+        sd_dev, tab = model._sched_on_device(), model._reverse_so3().struct()
+        ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
+        _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(inp["generation_mask"]), 7, 0, B, K, model.T,
+                                          _hip.stream_ptr()), "sample_init")
+
+        def loop(t_hi, n):
+            _hip.check(lib.diffab_sample_loop(C.byref(hd), C.byref(w.struct), C.byref(sd_dev.struct), C.byref(tab), _hip.ptr(seq), _hip.ptr(x),
+                                              _hip.ptr(O), _hip.ptr(inp["res_context_emb"]), _hip.ptr(inp["pair_context_emb"]),
+                                              _hip.ptr(inp["generation_mask"]), 7, 0, t_hi, t_hi - n, _hip.ptr(ws), ws.numel(), flags,
+                                              _hip.stream_ptr()), "sample_loop")
+
+        loop(model.T, 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(model.T - 2, steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res["k256_sampling"] = {"patches": B, "K": K, "steps": steps, "ms_per_step": dt / steps * 1e3,
+                                "residue_steps_per_s": B * K * steps / dt, "finite": bool(torch.isfinite(x).all())}
+        del inp, seq, x, O, ws
+    except Exception as ex:  # noqa: BLE001
+        res["k256_sampling"] = f"failed: {type(ex).__name__}: {ex}"
+    gc.collect()
+    torch.cuda.empty_cache()
+    try:
+        B, K, steps = 128, 128, 3
+        inp = syn.patches(B, K, dims, seed=2)
+        batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
+                 "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),
+                 "res_context_emb": inp["res_context_emb"].cuda(), "pair_context_emb": inp["pair_context_emb"].cuda()}
+        opt = model.configure_optimizers()
+        loss = None
+        for it in range(2 + steps):
+            if it == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            opt.zero_grad()
+            loss = model.training_step(batch, it)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res["training_step"] = {"patches": B, "K": K, "steps": steps, "ms_per_step": dt * 1e3, "residue_steps_per_s": B * K / dt,
+                                "loss_finite": bool(torch.isfinite(loss.detach()).item()),
+                                "what": "noise + taped forward + 3 losses + HIP backward + Adam, contexts given"}
+    except Exception as ex:  # noqa: BLE001
+        res["training_step"] = f"failed: {type(ex).__name__}: {ex}"
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +173,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=300)
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
     ap.add_argument("--split-attention", action="store_true", help="attention as three launches (csrc/attention_split.hip) instead of fused")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short BASELINE config 4 / 5 measurements (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -234,6 +302,8 @@ def main():
             "outputs_finite": finite,
             "input_gen_s": t_gen,
         }
+        if world == 1 and not args.no_other_configs and not args.generic:
+            out["other_configs"] = other_configs(model, dims, flags)
         if world == 1 and not args.no_cpu_baseline:
             torch.manual_seed(0)
             sd = {k: v.detach().cpu() for k, v in model.denoiser.state_dict().items()}

@@ -11,12 +11,12 @@ cd /tmp && export TMPDIR=/tmp
 echo "[1] bench"; timeout -k 10 600 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 tail -c 600 $O/bench_n1.json; echo
 echo "[2] kernel stats"; rm -rf /tmp/ks
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o run -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/ks.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o run -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $O/ks.log 2>&1 || exit 1
 cp /tmp/ks/run_kernel_stats.csv $O/kernel_stats.csv
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1)); echo "[3.$i] pmc $pass"; rm -rf /tmp/pmc$i
-  timeout -k 10 240 rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc$i -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc$i.log 2>&1 || { echo "pass $i failed"; tail -3 $O/pmc$i.log; exit 1; }
+  timeout -k 10 240 rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc$i -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > $O/pmc$i.log 2>&1 || { echo "pass $i failed"; tail -3 $O/pmc$i.log; exit 1; }
 done
 python3 $R/tools/pmc_summarise.py $O/pmc_counters_per_launch.json /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4
 echo done
