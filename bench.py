@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=300)
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
     ap.add_argument("--split-attention", action="store_true", help="attention as three launches (csrc/attention_split.hip) instead of fused")
+    ap.add_argument("--external-logits", action="store_true", help="logits in their own launch, fused kernel for the rest")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short BASELINE config 4 / 5 measurements (N=1 only)")
     args = ap.parse_args()
 
@@ -209,7 +210,8 @@ def main():
     sd_dev = model._sched_on_device()
     tab = model._reverse_so3().struct()
     ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
-    flags = _hip.FLAG_FORCE_GENERIC if args.generic else (_hip.FLAG_SPLIT_ATTENTION if args.split_attention else 0)
+    flags = _hip.FLAG_FORCE_GENERIC if args.generic else (_hip.FLAG_SPLIT_ATTENTION if args.split_attention else
+                                                          (_hip.FLAG_EXTERNAL_LOGITS if args.external_logits else 0))
     seed = 2024
     _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, model.T,
                                       _hip.stream_ptr()), "sample_init")
@@ -280,7 +282,7 @@ def main():
                 "workload": f"batch={B}/GPU synthetic K={K} patches, reverse sampling steps (T=100 schedule), benchmark model "
                             "D=128 C=64 NL=6 H=8 ds=32 P=8 (reference train.py:62-70), random-init weights",
                 "patches_per_gpu": B, "K": K, "global_batch": world * B, "parallelism": f"patch-sharded x{world}",
-                "path": "generic" if args.generic else ("mfma-split-attention" if args.split_attention else "mfma"),
+                "path": "generic" if args.generic else ("mfma-split-attention" if args.split_attention else ("mfma-external-logits" if args.external_logits else "mfma")),
             },
             "residue_steps_per_s_per_gpu": value / world,
             "whole_path_hbm_frac": value / world * algorithmic_bytes_per_residue_step(K, dims["D"], dims["C"], dims["NL"]) / 1e9

@@ -366,6 +366,15 @@ bool attention_split_supported(const diffab_dims* d) { return d->K == 64 || d->K
 
 size_t attention_split_workspace_floats(const diffab_dims* d) { return static_cast<size_t>(d->B) * AH * d->K * d->K; }
 
+int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamma, float* SP, hipStream_t st) {
+  const int K = d->K;
+  DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "ipa_logits: K must be 64 or 128");
+  const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 4 * 16 * 36) * sizeof(float);
+  hipLaunchKernelGGL(ipa_logits_kernel, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, SP, K);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
                            const float* gamma, float* feat, float* SP, hipStream_t st) {
   const int K = d->K, rows = d->B * K;

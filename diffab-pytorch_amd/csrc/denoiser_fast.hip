@@ -377,12 +377,16 @@ constexpr int TI = 16;  // query residues per work-group
 // NT: key tiles (16 keys each) per chunk: 8 when K % 128 == 0, else 4; compile-time so per-lane arrays stay in VGPRs.
 // MULTI: more than one chunk.  The single-chunk instantiation (K = 64, 128) has NC == 1 at compile time: the chunk loop and every
 // rescale branch fold away and it is the same straight-line kernel as before the chunk loop existed (the loop costs 13 % at K=128).
-template <int NT, bool MULTI>
+// EXT_S (single chunk only): phase 1 is not computed here; the logits image is copied from Sg[b][h][i][j], written by
+// ipa_logits_kernel (attention_split.hip), whose work-groups share the staged key side over 64 query rows instead of 16.
+template <int NT, bool MULTI, bool EXT_S = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
-                                                            unsigned long long* __restrict__ stamps) {
+                                                            unsigned long long* __restrict__ stamps,
+                                                            const float* __restrict__ Sg = nullptr) {
+  static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
   // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
@@ -476,7 +480,25 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
     };
     // ---------------------------------------------------------------- phase 1: wave = head
-    {
+    if constexpr (EXT_S) {
+      // logits of the 16 rows x 8 heads x KC keys from global memory: 512 contiguous bytes per (row, head); the pair stream of
+      // phase 2's first row is requested right behind them
+      constexpr int F4 = KC / 4;  // float4 per (row, head)
+      f32x4 sreg[TI * AH * F4 / 512];
+#pragma unroll
+      for (int k_ = 0; k_ < TI * AH * F4 / 512; ++k_) {
+        const int idx = tid + 512 * k_, rh = idx / F4, c4 = idx % F4, il = rh / AH, hh = rh % AH;
+        sreg[k_] = *reinterpret_cast<const f32x4*>(Sg + ((static_cast<int64_t>(b) * AH + hh) * K + i0 + il) * K + 4 * c4);
+      }
+#pragma unroll
+      for (int jt = 0; jt < E_EARLY; ++jt) load_e_tile(0, c, jt);
+      MEM_FENCE();
+#pragma unroll
+      for (int k_ = 0; k_ < TI * AH * F4 / 512; ++k_) {
+        const int idx = tid + 512 * k_, rh = idx / F4, c4 = idx % F4, il = rh / AH, hh = rh % AH;
+        *reinterpret_cast<f32x4*>(S + il * IS + hh * HS + 4 * c4) = sreg[k_];
+      }
+    } else {
       const int h = wv;
       const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
       const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
@@ -1054,7 +1076,7 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d) {
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, bool split_attention) {
+                   float* y, float* ws, hipStream_t st, int attn_mode) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1089,7 +1111,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   // DIFFAB_FLAG_SPLIT_ATTENTION (K = 64 / 128): three launches exchanging logits / probabilities through HBM (attention_split.hip).
   // Its pair-stream kernel sustains 3.8 TB/s (47 % of the HBM peak) against 2.9 for the fused kernel below, but the logits and
   // P x V launches are not yet at their floors and the three together are slower (0.45 vs 0.37 ms) - hence opt-in.
-  if (split_attention && attention_split_supported(d)) {
+  if (attn_mode == 1 && attention_split_supported(d)) {
     float* SP = feat + static_cast<size_t>(rows) * AF + 128;
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
     return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
@@ -1098,19 +1120,27 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
   const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
   const dim3 grid(d->B * (d->K / TI));
-#define ATTN_LAUNCH(NT_, MULTI_)                                                                                                      \
+  const bool ext_logits = attn_mode == 2 && attention_split_supported(d);  // single chunk by construction (K = 64 / 128)
+  float* SPx = feat + static_cast<size_t>(rows) * AF + 128;
+  if (ext_logits)
+    if (int rc = launch_ipa_logits(d, proj, w->gamma, SPx, st)) return rc;
+#define ATTN_LAUNCH_X(NT_, MULTI_, EXT_)                                                                                              \
   do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_>),                            \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, EXT_>),                      \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_>), grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, d->B, \
-                       nc, g_attn_stamps);                                                                                            \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, EXT_>), grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, \
+                       d->B, nc, g_attn_stamps, SPx);                                                                                 \
     timer_end(st);                                                                                                                    \
   } while (0)
-  if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
+#define ATTN_LAUNCH(NT_, MULTI_) ATTN_LAUNCH_X(NT_, MULTI_, false)
+  if (ext_logits && nt == 8) ATTN_LAUNCH_X(8, false, true);
+  else if (ext_logits) ATTN_LAUNCH_X(4, false, true);
+  else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
   else if (nt == 8) ATTN_LAUNCH(8, true);
   else if (nc == 1) ATTN_LAUNCH(4, false);
   else ATTN_LAUNCH(4, true);
+#undef ATTN_LAUNCH_X
 #undef ATTN_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);

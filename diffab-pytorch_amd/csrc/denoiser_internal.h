@@ -18,7 +18,7 @@ int launch_heads_finish(const float* v, const float* O_t, const float* logits, i
 bool fast_path_supported(const diffab_dims* d);
 size_t ipa_fast_workspace_floats(const diffab_dims* d);
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, bool split_attention = false);
+                   float* y, float* ws, hipStream_t st, int attn_mode = 0);  // 0 fused | 1 three launches | 2 logits launch + fused rest
 // Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);
@@ -36,6 +36,7 @@ int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, c
 // (B, 8, K, K) logits / probabilities through SP; single key chunk only (K = 64, 128)
 bool attention_split_supported(const diffab_dims* d);
 size_t attention_split_workspace_floats(const diffab_dims* d);
+int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamma, float* SP, hipStream_t st);  // S[b][h][i][j] only
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
                            const float* gamma, float* feat, float* SP, hipStream_t st);
 

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFAB_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdiffab_hip.so")
 
 FLAG_FORCE_GENERIC = 1
+FLAG_EXTERNAL_LOGITS = 4  # K = 64 / 128: logits in their own launch, the fused kernel copies them (csrc/attention_split.hip)
 FLAG_SPLIT_ATTENTION = 2  # K = 64 / 128: attention as three launches (csrc/attention_split.hip); default is the fused kernel
 
 

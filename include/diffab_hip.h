@@ -39,6 +39,8 @@ extern "C" {
 
 /* flags */
 #define DIFFAB_FLAG_FORCE_GENERIC 1u /* skip the MFMA kernels specialised for D=128,C=64,H=8,DS=32,P=8 */
+#define DIFFAB_FLAG_EXTERNAL_LOGITS 4u /* K = 64 / 128: the logits of each layer in their own launch (key side staged once per 64 query
+                                          rows), the fused kernel copies them instead of computing its phase 1 */
 #define DIFFAB_FLAG_SPLIT_ATTENTION 2u /* K = 64 / 128: the attention of each layer as three launches (logits | pair stream | P x V)
                                           instead of the fused kernel; same results to rounding, see csrc/attention_split.hip */
 

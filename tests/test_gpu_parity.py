@@ -237,7 +237,8 @@ def build_case(g):
     return dims, den, inp
 
 
-@pytest.mark.parametrize("flags", [0, _hip.FLAG_FORCE_GENERIC, _hip.FLAG_SPLIT_ATTENTION], ids=["dispatch", "generic", "split"])
+@pytest.mark.parametrize("flags", [0, _hip.FLAG_FORCE_GENERIC, _hip.FLAG_SPLIT_ATTENTION, _hip.FLAG_EXTERNAL_LOGITS],
+                         ids=["dispatch", "generic", "split", "extlogits"])
 @pytest.mark.parametrize("name", CASES)
 def test_denoiser_vs_reference_goldens(hip, golden, name, flags):
     g = golden("denoiser_" + name)
