@@ -125,10 +125,66 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   if (ty == 0 && n < N) atomicAdd(db + n, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
 }
 
+// MFMA version of C[M,N] (+)= A[M,K] B[K,N] for 16-byte-aligned operands with lda, ldb, ldc, N multiples of 4: a wave owns 16 rows
+// x 64 columns.  A is read along its contiguous (k) direction - one float4 per lane = four k-steps, k order permuted identically
+// for both operands - and B along ITS contiguous (n) direction: lane (l15, g) loads B[k0 + 4 g + s][n0 + 4 l15 ..], whose four
+// components are column 4 l15 + c of four accumulators, so a lane ends with four consecutive columns per row (float4 stores).
+typedef float nn_f32x4 __attribute__((ext_vector_type(4)));
+template <bool ACC>
+__global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                           float* __restrict__ C, int ldc, int M, int N, int K) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.y * 64 + 16 * wv, n0 = blockIdx.x * 64;
+  const int arow = min(m0 + l15, M - 1);  // rows past M are clamped (never stored)
+  const bool col_ok = n0 + 4 * l15 < N;
+  nn_f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = nn_f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = A + static_cast<int64_t>(arow) * lda + 4 * g;
+  const float* bp = Bm + static_cast<int64_t>(4 * g) * ldb + n0 + 4 * l15;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    nn_f32x4 a = {0.f, 0.f, 0.f, 0.f}, b[4];
+    if (k0 + 4 * g + 3 < K) {
+      a = *reinterpret_cast<const nn_f32x4*>(ap + k0);
+    } else {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+        if (k0 + 4 * g + s_ < K) a[s_] = ap[k0 + s_];
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      b[s_] = nn_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col_ok && k0 + 4 * g + s_ < K) b[s_] = *reinterpret_cast<const nn_f32x4*>(bp + static_cast<int64_t>(k0 + s_) * ldb);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b[s_][c], acc[c], 0, 0, 0);
+  }
+  // acc[c][r]: row 4 g + r of the wave's 16, column 4 l15 + c of the block's 64
+  if (!col_ok) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gm = m0 + 4 * g + r;
+    if (gm >= M) continue;
+    nn_f32x4* cp = reinterpret_cast<nn_f32x4*>(C + static_cast<int64_t>(gm) * ldc + n0 + 4 * l15);
+    nn_f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    if (ACC) v += *cp;
+    *cp = v;
+  }
+}
+
 static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st) {
+  const bool mfma = lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && N % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
   dim3 grid((N + TB - 1) / TB, (M + TB - 1) / TB);
-  if (acc) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
-  else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+  if (mfma) {
+    if (acc) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+    else hipLaunchKernelGGL(gemm_nn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+  } else {
+    if (acc) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+    else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+  }
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -138,8 +194,9 @@ static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, i
 // the B vector column 4 l15 + c', so the 16 MFMAs (c, c') of a step fill 16 accumulators whose (row, col) = (l15, l15') element
 // is C[4 l15 + c][4 l15' + c'].  Two 1 KiB loads feed 16 MFMAs - no LDS staging needed.
 typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
+template <bool ALIGNED>  // false: any N1, N2, lda, ldb (per-element guarded loads and stores); true: the vector path described above
 __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                           float* __restrict__ C, int ldc, int M, int m_chunk) {
+                                                           float* __restrict__ C, int ldc, int M, int m_chunk, int N1, int N2) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
   const int m_lo = (blockIdx.z * 4 + wv) * m_chunk, m_hi = min(M, m_lo + m_chunk);
@@ -155,8 +212,16 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restri
   tn_f32x4 va[U], vb[U];
   auto load = [&](int u, int m) {
     const bool ok = m + g < m_hi;
-    va[u] = ok ? *reinterpret_cast<const tn_f32x4*>(ap + static_cast<int64_t>(m - m_lo) * lda) : tn_f32x4{0.f, 0.f, 0.f, 0.f};
-    vb[u] = ok ? *reinterpret_cast<const tn_f32x4*>(bp + static_cast<int64_t>(m - m_lo) * ldb) : tn_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ALIGNED) {
+      va[u] = ok ? *reinterpret_cast<const tn_f32x4*>(ap + static_cast<int64_t>(m - m_lo) * lda) : tn_f32x4{0.f, 0.f, 0.f, 0.f};
+      vb[u] = ok ? *reinterpret_cast<const tn_f32x4*>(bp + static_cast<int64_t>(m - m_lo) * ldb) : tn_f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        va[u][c] = (ok && a0 + 4 * l15 + c < N1) ? ap[static_cast<int64_t>(m - m_lo) * lda + c] : 0.0f;
+        vb[u][c] = (ok && b0 + 4 * l15 + c < N2) ? bp[static_cast<int64_t>(m - m_lo) * ldb + c] : 0.0f;
+      }
+    }
   };
 #pragma unroll
   for (int u = 0; u < U; ++u) load(u, m_lo + 4 * u);
@@ -176,30 +241,27 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restri
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float* crow = C + static_cast<int64_t>(a0 + 4 * (4 * g + r) + c) * ldc + b0 + 4 * l15;
+      const int crow_i = a0 + 4 * (4 * g + r) + c;
+      if (!ALIGNED && crow_i >= N1) continue;
+      float* crow = C + static_cast<int64_t>(crow_i) * ldc + b0 + 4 * l15;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) atomicAdd(crow + d, acc[c][d][r]);
+      for (int d = 0; d < 4; ++d)
+        if (ALIGNED || b0 + 4 * l15 + d < N2) atomicAdd(crow + d, acc[c][d][r]);
     }
 }
 
 static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st) {
-  const bool mfma = N1 % 64 == 0 && N2 % 64 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(B) & 15) == 0;
-  if (mfma) {
-    // enough (tile, M-chunk) waves to fill the chip: ~2048 waves, chunks of at least 256 rows
-    const int tiles = (N1 / 64) * (N2 / 64);
-    int splits = (2048 + tiles - 1) / tiles;  // M chunks wanted
-    int m_chunk = (M + splits - 1) / splits;
-    m_chunk = ((max(m_chunk, 256) + 15) / 16) * 16;
-    const int nchunks = (M + m_chunk - 1) / m_chunk;
-    dim3 grid(N2 / 64, N1 / 64, (nchunks + 3) / 4);
-    hipLaunchKernelGGL(gemm_tn_mfma_kernel, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk);
-    DIFFAB_LAUNCH_CHECK();
-    return DIFFAB_OK;
-  }
-  const int m_chunk = 2048;
-  dim3 grid((N2 + TB - 1) / TB, (N1 + TB - 1) / TB, (M + m_chunk - 1) / m_chunk);
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N1, N2, m_chunk);
+  const bool aligned = N1 % 64 == 0 && N2 % 64 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  // enough (tile, M-chunk) waves to fill the chip: ~2048 waves, chunks of at least 256 rows
+  const int t1 = (N1 + 63) / 64, t2 = (N2 + 63) / 64, tiles = t1 * t2;
+  int splits = (2048 + tiles - 1) / tiles;  // M chunks wanted
+  int m_chunk = (M + splits - 1) / splits;
+  m_chunk = ((max(m_chunk, 256) + 15) / 16) * 16;
+  const int nchunks = (M + m_chunk - 1) / m_chunk;
+  dim3 grid(t2, t1, (nchunks + 3) / 4);
+  if (aligned) hipLaunchKernelGGL(gemm_tn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2);
+  else hipLaunchKernelGGL(gemm_tn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
