@@ -942,6 +942,80 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_kernel(const float* __r
   }
 }
 
+// Key-side pass for JJ consecutive keys per work-group: every query-side value (q_s, q_pts, do_s, dog of row i) is loaded once and
+// used for the JJ keys; the one-key kernel above re-reads that 0.45 MB per key.
+template <int JJ>
+__global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mr_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ dfeat, const float* __restrict__ At,
+                                                                   const float* __restrict__ Gt, const float* __restrict__ dogbuf,
+                                                                   float* __restrict__ dproj, int K, int C, int H, int DS, int PQ, int PV) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nblk = K / JJ;
+  const int b = blockIdx.x / nblk, j0 = (blockIdx.x % nblk) * JJ;
+  const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
+  const int F = H * DS + H * C + H * PV * 3 + H * PV;
+  const int off_ks = H * DS, off_vs = 2 * H * DS, off_gq = 3 * H * DS, off_gk = off_gq + H * PQ * 3, off_gv = off_gk + H * PQ * 3;
+  const int n_og = H * PV * 3, HK = H * K;
+  float* a = smem;            // [JJ][H*K]  A[h][i] of key j0 + jj
+  float* g = a + JJ * HK;     // [JJ][H*K]  g[h][i]
+  for (int idx = threadIdx.x; idx < JJ * HK; idx += blockDim.x) {
+    const int jj = idx / HK, hi = idx % HK, h = hi / K, i = hi % K;
+    const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + j0 + jj) * K + i;
+    a[idx] = At[o];
+    g[idx] = Gt[o];
+  }
+  __syncthreads();
+  const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
+  const float scale_p = -0.5f / sqrtf(4.5f * PQ);
+  const int64_t row_j0 = static_cast<int64_t>(b) * K + j0;
+  const int n_ks = H * DS, n_gk = H * PQ * 3, n_vs = H * DS, n_gv = H * PV * 3;
+  for (int o = threadIdx.x; o < n_ks + n_gk + n_vs + n_gv; o += blockDim.x) {
+    float acc[JJ];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) acc[jj] = 0.f;
+    if (o < n_ks) {  // dk_s[j][h][d] = scale_s sum_i g q_s[i][h][d]
+      const int h = o / DS;
+      for (int i = 0; i < K; ++i) {
+        const float v = proj[(static_cast<int64_t>(b) * K + i) * NP + o];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) acc[jj] += g[jj * HK + h * K + i] * v;
+      }
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) dproj[(row_j0 + jj) * NP + off_ks + o] = acc[jj] * scale_s;
+    } else if (o < n_ks + n_gk) {  // dgk = -2 scale_p gamma sum_i g (gq[i] - gk[j])
+      const int oo = o - n_ks, h = oo / (PQ * 3);
+      float kj[JJ];
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) kj[jj] = proj[(row_j0 + jj) * NP + off_gk + oo];
+      for (int i = 0; i < K; ++i) {
+        const float v = proj[(static_cast<int64_t>(b) * K + i) * NP + off_gq + oo];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) acc[jj] += g[jj * HK + h * K + i] * (v - kj[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) dproj[(row_j0 + jj) * NP + off_gk + oo] = -2.0f * scale_p * gamma[h] * acc[jj];
+    } else if (o < n_ks + n_gk + n_vs) {  // dv_s[j][h][d] = sum_i A do_s[i][h][d]
+      const int oo = o - n_ks - n_gk, h = oo / DS;
+      for (int i = 0; i < K; ++i) {
+        const float v = dfeat[(static_cast<int64_t>(b) * K + i) * F + oo];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) acc[jj] += a[jj * HK + h * K + i] * v;
+      }
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) dproj[(row_j0 + jj) * NP + off_vs + oo] = acc[jj];
+    } else {  // dgv[j][h][p][k] = sum_i A dog[i][h][p][k]
+      const int oo = o - n_ks - n_gk - n_vs, h = oo / (PV * 3);
+      for (int i = 0; i < K; ++i) {
+        const float v = dogbuf[(static_cast<int64_t>(b) * K + i) * n_og + oo];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) acc[jj] += a[jj * HK + h * K + i] * v;
+      }
+#pragma unroll
+      for (int jj = 0; jj < JJ; ++jj) dproj[(row_j0 + jj) * NP + off_gv + oo] = acc[jj];
+    }
+  }
+}
+
 // gradient w.r.t. global points -> local points, in place: g = p R + t  =>  dp[k] = sum_c dg[c] R[k][c]
 __global__ void points_bwd_kernel(float* __restrict__ dproj, int ld, int col0, int n_pts, const float* __restrict__ R, int64_t rows) {
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -1097,8 +1171,14 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     if (int rc = colsum(wb_part, H * C + H, rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
     if (int rc = colsum(wb_part + H * C, H * C + H, rows, H, const_cast<float*>(lg->gamma), st)) return rc;
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
-    hipLaunchKernelGGL(ipa_attn_bwd_keys_kernel, dim3(rows), dim3(256), lds2, st, proj, lw->gamma, dfeat, At, Gt, dogbuf, dproj, d->K, C, H,
-                       DS, PQ, PV);
+    constexpr int JJm = 4;  // keys per work-group of the multi-key kernel
+    if (d->K % JJm == 0 && JJm * lds2 <= 64 * 1024) {
+      hipLaunchKernelGGL((ipa_attn_bwd_keys_mr_kernel<JJm>), dim3(rows / JJm), dim3(256), JJm * lds2, st, proj, lw->gamma, dfeat, At, Gt,
+                         dogbuf, dproj, d->K, C, H, DS, PQ, PV);
+    } else {
+      hipLaunchKernelGGL(ipa_attn_bwd_keys_kernel, dim3(rows), dim3(256), lds2, st, proj, lw->gamma, dfeat, At, Gt, dogbuf, dproj, d->K, C, H,
+                         DS, PQ, PV);
+    }
     DIFFAB_LAUNCH_CHECK();
     // global-point gradients -> local-point gradients (three point blocks)
     const int cols[3] = {3 * H * DS, 3 * H * DS + H * PQ * 3, 3 * H * DS + 2 * H * PQ * 3};
