@@ -42,8 +42,9 @@ constexpr int RB = 64;  // query rows per work-group in kernels A and C (4 waves
 // ================================================================== A: logits
 constexpr int KLD = 40, GLD = 28;  // LDS row strides (floats) of the staged k_s / k_pts rows: ds_read_b128 conflict-free
 
+template <bool WD2>  // WD2: also write the squared point distances (the training backward needs them for d gamma)
 __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
-                                                         float* __restrict__ SP, int K) {
+                                                         float* __restrict__ SP, float* __restrict__ D2, int K) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [K][KLD] k_s rows, then [K][GLD] k_pts rows of this head
   float* ks_l = lds;
   float* gk_l = lds + K * KLD;
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
   // i.e. 4-byte stores in 64-byte runs; re-read row-major, a lane stores 16 bytes and 8 lanes cover a full 128-byte line of a row.
   constexpr int OLD = 36;  // tile row stride (floats)
   float* otile = gk_l + K * GLD + wv * (16 * OLD);
+  float* dtile = gk_l + K * GLD + 4 * (16 * OLD) + wv * (16 * OLD);  // second tile: squared distances (WD2 only)
   float* sbase = SP + ((static_cast<int64_t>(b) * AH + h) * K + i0) * K;
+  float* dbase = WD2 ? D2 + ((static_cast<int64_t>(b) * AH + h) * K + i0) * K : nullptr;
   const int ntile = K / 16;
   for (int jt = 0; jt < ntile; ++jt) {
     const float* kt = ks_l + (jt * 16 + l15) * KLD + 4 * q;
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
       }
       const float d2 = d2v[0] + d2v[1];
       otile[(4 * q + r) * OLD + (jt & 1) * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
+      if (WD2) dtile[(4 * q + r) * OLD + (jt & 1) * 16 + l15] = d2;
     }
     if (jt & 1) {  // two key tiles complete: rows (lane >> 3) and 8 + (lane >> 3), keys 4 (lane & 7) .. + 3 of the 32
       const int orow = lane >> 3, oc = 4 * (lane & 7);
@@ -133,6 +137,9 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
         if (K < 0)
 #endif
         *reinterpret_cast<f32x4*>(sbase + static_cast<int64_t>(orow + 8 * half) * K + (jt - 1) * 16 + oc) = v;
+        if (WD2)
+          *reinterpret_cast<f32x4*>(dbase + static_cast<int64_t>(orow + 8 * half) * K + (jt - 1) * 16 + oc) =
+              *reinterpret_cast<const f32x4*>(dtile + (orow + 8 * half) * OLD + oc);
       }
     }
   }
@@ -215,7 +222,8 @@ __global__ __launch_bounds__(256) void ipa_pv_kernel(const float* __restrict__ p
 // NT key tiles of 16 (K = 16 NT).  A work-group is 8 independent waves; wave w owns RPW consecutive query rows of one patch.
 constexpr int ELD = 72;  // pair-tile stride (floats) of the per-wave re-orientation scratch
 
-template <int NT, int RPW>
+// OE = false (training backward: only the probabilities are wanted): no o_e product, no feature-row store
+template <int NT, int RPW, bool OE = true>
 __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __restrict__ e, const float* __restrict__ Wb,
                                                               float* __restrict__ SP, float* __restrict__ feat, int rows_total) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: 2 tiles [16][ELD]
@@ -310,6 +318,14 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __res
       for (int jt = 0; jt < NT; ++jt) *reinterpret_cast<f32x4*>(sp + jt * 16) = lgv[jt] * inv;
     }
 #endif
+    if constexpr (!OE) {
+      if (has_next) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) load_e_tile(1 - slot, row + 1, jt);
+        MEM_FENCE();
+      }
+      return;
+    } else {
     // o_e[h][c] = sum_j P[h][j] e[row][j][c]: P (unnormalised) is the B operand straight from registers
     f32x4 oe[4];
 #pragma unroll
@@ -334,6 +350,7 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __res
         f32x4 v = {oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
         *reinterpret_cast<f32x4*>(fo + 4 * r) = v * inv;
       }
+    }
     }
   };
   // RPW is small and even: the row loop is spelled out so that "is there a next row" is a compile-time fact (a run-time flag
@@ -370,7 +387,31 @@ int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamm
   const int K = d->K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "ipa_logits: K must be 64 or 128");
   const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 4 * 16 * 36) * sizeof(float);
-  hipLaunchKernelGGL(ipa_logits_kernel, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, SP, K);
+  hipLaunchKernelGGL(ipa_logits_kernel<false>, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, SP, nullptr, K);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// training backward: P[b][h][i][j] (normalised probabilities) and D2[b][h][i][j] (squared point distances), nothing else
+int launch_attention_probs(const diffab_dims* d, const float* proj, const float* e, const float* Wb, const float* gamma, float* P,
+                           float* D2, hipStream_t st) {
+  const int K = d->K, rows = d->B * K;
+  DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_probs: K must be 64 or 128");
+  const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 8 * 16 * 36) * sizeof(float);
+  hipLaunchKernelGGL(ipa_logits_kernel<true>, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, P, D2, K);
+  DIFFAB_LAUNCH_CHECK();
+  constexpr int RPW = 4;
+  const size_t lds_b = static_cast<size_t>(8) * 2 * 16 * ELD * sizeof(float);
+  const dim3 grid_b((rows + 8 * RPW - 1) / (8 * RPW));
+  if (K == 128) {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_kernel<8, RPW, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+    hipLaunchKernelGGL((ipa_pair_stream_kernel<8, RPW, false>), grid_b, dim3(512), lds_b, st, e, Wb, P, nullptr, rows);
+  } else {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_kernel<4, RPW, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+    hipLaunchKernelGGL((ipa_pair_stream_kernel<4, RPW, false>), grid_b, dim3(512), lds_b, st, e, Wb, P, nullptr, rows);
+  }
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -381,7 +422,7 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_split: K must be 64 or 128");
   const dim3 grid_ac(d->B * AH * (K / RB));
   const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 4 * 16 * 36) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
-  hipLaunchKernelGGL(ipa_logits_kernel, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, K);
+  hipLaunchKernelGGL(ipa_logits_kernel<false>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, nullptr, K);
   DIFFAB_LAUNCH_CHECK();
 #ifndef SPB_RPW
 #define SPB_RPW 4

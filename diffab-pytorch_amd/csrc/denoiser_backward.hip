@@ -607,14 +607,17 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
 // The one-row kernel above re-reads the whole key side of the patch (k_s, k_pts, v_s, v_pts: 448 KiB at the benchmark geometry,
 // twice for k) from L2 for every query row - 0.9 MB per row, 15 GB per layer at B = 128 - and that traffic, not the arithmetic,
 // sets its 2.3 ms.  Here every key-side value is loaded once and used for RR rows; the per-row state lives in RR LDS slots.
-template <int RR>
+// HAVE_P: the probabilities and the squared point distances come from global memory (Pn, D2g: [b][h][i][j], written by
+// launch_attention_probs - the MFMA forward kernels re-run), instead of being recomputed here on the VALU.
+template <int RR, bool HAVE_P>
 __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                                    const float* __restrict__ R, const float* __restrict__ Wb,
                                                                    const float* __restrict__ gamma, const float* __restrict__ feat,
                                                                    const float* __restrict__ dfeat, float* __restrict__ dproj,
                                                                    float* __restrict__ de, float* __restrict__ At, float* __restrict__ Gt,
                                                                    float* __restrict__ dogbuf, float* __restrict__ wb_part, int K, int C,
-                                                                   int H, int DS, int PQ, int PV) {
+                                                                   int H, int DS, int PQ, int PV, const float* __restrict__ Pn,
+                                                                   const float* __restrict__ D2g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef float v4 __attribute__((ext_vector_type(4)));
   const int nblk = K / RR;
@@ -685,6 +688,19 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     const float send = b0 ? w2[0] : w2[1], keep = b0 ? w2[1] : w2[0];
     return keep + __shfl_xor(send, 1);
   };
+  const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  if constexpr (HAVE_P) {
+    for (int idx = tid; idx < HK; idx += nthr) {
+      const int h = idx / K, j = idx % K;
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + i0 + rr) * K + j;
+        attn_of(rr)[idx] = Pn[o];
+        d2_of(rr)[idx] = D2g[o];
+      }
+    }
+    __syncthreads();
+  } else {
   // ---- recompute logits: key-side vectors loaded once per (h, j), used for the RR rows
   for (int idx = oct; idx < HK; idx += noct) {
     const int h = idx / K, j = idx % K;
@@ -743,7 +759,6 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     if (lo < H) attn_of(rr)[lo * K + j] += scale_t * tot;
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
   for (int rh = wave; rh < RR * H; rh += nwave) {  // softmax per (row, head)
     float* a = attn_of(rh / H) + (rh % H) * K;
     float m = -INFINITY;
@@ -760,6 +775,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     for (int j = lane; j < K; j += 64) a[j] *= inv;
   }
   __syncthreads();
+  }
   // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]
   for (int idx = oct; idx < HK; idx += noct) {
     const int h = idx / K, j = idx % K;
@@ -1077,7 +1093,8 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
   const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
   return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64 + 2 * HKK +
-         rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64;
+         rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64 +
+         ((fast_path_supported(d) && attention_split_supported(d)) ? 2 * HKK : 0);  // probabilities + squared distances (MFMA recompute)
 }
 
 int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
@@ -1107,6 +1124,9 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
   float* Gt = take(HKK);
   float* dogbuf = take(static_cast<size_t>(rows) * H * PV * 3);
   float* wb_part = take(static_cast<size_t>(rows) * (H * C + H));  // per-row partials of d w_bias (H*C) and d gamma (H)
+  const bool mfma_probs = fast_path_supported(d) && attention_split_supported(d);
+  float* Pn = mfma_probs ? take(HKK) : nullptr;
+  float* D2g = mfma_probs ? take(HKK) : nullptr;
 
   hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
   DIFFAB_LAUNCH_CHECK();
@@ -1155,10 +1175,19 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     const size_t lds_mr = RRm * slot * sizeof(float);
 #ifndef DIFFAB_BWD_ONE_ROW
     if (vec && H <= 8 && d->K % RRm == 0 && lds_mr <= 160 * 1024) {
-      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
-      hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t, lw->w_bias,
-                         lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV);
+      if (mfma_probs) {  // probabilities by the forward's MFMA kernels instead of the VALU recompute inside the row pass
+        if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) return rc;
+        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
+        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, true>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
+                           lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, Pn, D2g);
+      } else {
+        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
+        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, false>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
+                           lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, nullptr,
+                           nullptr);
+      }
     } else
 #endif
     {

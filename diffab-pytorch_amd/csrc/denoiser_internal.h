@@ -37,6 +37,8 @@ int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, c
 bool attention_split_supported(const diffab_dims* d);
 size_t attention_split_workspace_floats(const diffab_dims* d);
 int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamma, float* SP, hipStream_t st);  // S[b][h][i][j] only
+int launch_attention_probs(const diffab_dims* d, const float* proj, const float* e, const float* Wb, const float* gamma, float* P,
+                           float* D2, hipStream_t st);  // training backward: normalised probabilities + squared point distances
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
                            const float* gamma, float* feat, float* SP, hipStream_t st);
 
