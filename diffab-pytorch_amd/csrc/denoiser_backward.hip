@@ -1032,6 +1032,76 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mr_kernel(const float* 
   }
 }
 
+// Key-side pass on the MFMA for the benchmark head geometry (DS = 32, 3 PQ = 3 PV = 24), one work-group per (patch, head, 64 keys),
+// one wave per 16 keys.  The transposed images At / Gt [b][h][j][i] are the A operand (rows j, k = i contiguous: one float4 per
+// lane = four k-steps); the query-side rows are staged once per work-group in LDS as [i][64]:
+//   PART 0:  [q_s (32) | q_pts (24) | 1 | 0...]  x Gt  ->  dk_s = scale_s sum_i g q_s,  sum_i g q_pts,  sum_i g  (for d k_pts)
+//   PART 1:  [do_s (32) | dog (24) | 0...]       x At  ->  dv_s,  d v_pts
+constexpr int KM_LD = 68;  // LDS row stride (floats)
+template <int PART>
+__global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ dfeat, const float* __restrict__ AGt,
+                                                                     const float* __restrict__ dogbuf, float* __restrict__ dproj, int K) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][KM_LD]
+  constexpr int H = 8, DS = 32, NPT = 24;
+  constexpr int NP = 3 * H * DS + 3 * H * NPT, F = H * DS + H * 64 + H * NPT + H * 8;
+  constexpr int off_ks = H * DS, off_vs = 2 * H * DS, off_gq = 3 * H * DS, off_gk = off_gq + H * NPT, off_gv = off_gk + H * NPT;
+  const int nkb = K / 64;
+  const int kb = blockIdx.x % nkb, h = (blockIdx.x / nkb) % H, b = blockIdx.x / (nkb * H);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int64_t prow0 = static_cast<int64_t>(b) * K;
+  for (int idx = tid; idx < K * 16; idx += 256) {  // 16 float4 per staged row
+    const int i = idx >> 4, c4 = idx & 15;
+    v4 v = {0.f, 0.f, 0.f, 0.f};
+    if (PART == 0) {
+      if (c4 < 8) v = *reinterpret_cast<const v4*>(proj + (prow0 + i) * NP + h * DS + 4 * c4);
+      else if (c4 < 14) v = *reinterpret_cast<const v4*>(proj + (prow0 + i) * NP + off_gq + h * NPT + 4 * (c4 - 8));
+      else if (c4 == 14) v[0] = 1.0f;  // column 56: sum_i g
+    } else {
+      if (c4 < 8) v = *reinterpret_cast<const v4*>(dfeat + (prow0 + i) * F + h * DS + 4 * c4);
+      else if (c4 < 14) v = *reinterpret_cast<const v4*>(dogbuf + (prow0 + i) * (H * NPT) + h * NPT + 4 * (c4 - 8));
+    }
+    *reinterpret_cast<v4*>(smem + i * KM_LD + 4 * c4) = v;
+  }
+  __syncthreads();
+  const int j0 = kb * 64 + 16 * wv;
+  const float* arow = AGt + ((static_cast<int64_t>(b) * H + h) * K + j0 + l15) * K + 4 * g;  // [j][i]: + 16 grp
+  v4 acc[4];
+#pragma unroll
+  for (int t_ = 0; t_ < 4; ++t_) acc[t_] = v4{0.f, 0.f, 0.f, 0.f};
+  for (int grp = 0; grp < K / 16; ++grp) {
+    const v4 a = *reinterpret_cast<const v4*>(arow + 16 * grp);  // A[j = l15][i = 16 grp + 4 g + s]
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const float* brow = smem + (16 * grp + 4 * g + s_) * KM_LD + l15;
+#pragma unroll
+      for (int t_ = 0; t_ < 4; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], brow[16 * t_], acc[t_], 0, 0, 0);
+    }
+  }
+  // acc[t][r]: key j0 + 4 g + r, column 16 t + l15
+  const float scale_s = 0.17677669529663687f, scale_p = -0.5f * 0.16666666666666666f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row_j = prow0 + j0 + 4 * g + r;
+    float* drow = dproj + row_j * NP;
+    if (PART == 0) {
+      drow[off_ks + h * DS + l15] = acc[0][r] * scale_s;
+      drow[off_ks + h * DS + 16 + l15] = acc[1][r] * scale_s;
+      const float colsum = __shfl(acc[3][r], (lane & 48) | 8);  // column 56 = 48 + 8
+      const float cpg = -2.0f * scale_p * gamma[h];
+      const float* kj = proj + row_j * NP + off_gk + h * NPT;
+      drow[off_gk + h * NPT + l15] = cpg * (acc[2][r] - kj[l15] * colsum);             // columns 32..47 -> point component 0..15
+      if (l15 < 8) drow[off_gk + h * NPT + 16 + l15] = cpg * (acc[3][r] - kj[16 + l15] * colsum);  // columns 48..55 -> 16..23
+    } else {
+      drow[off_vs + h * DS + l15] = acc[0][r];
+      drow[off_vs + h * DS + 16 + l15] = acc[1][r];
+      drow[off_gv + h * NPT + l15] = acc[2][r];
+      if (l15 < 8) drow[off_gv + h * NPT + 16 + l15] = acc[3][r];
+    }
+  }
+}
+
 // gradient w.r.t. global points -> local points, in place: g = p R + t  =>  dp[k] = sum_c dg[c] R[k][c]
 __global__ void points_bwd_kernel(float* __restrict__ dproj, int ld, int col0, int n_pts, const float* __restrict__ R, int64_t rows) {
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -1201,7 +1271,12 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     if (int rc = colsum(wb_part + H * C, H * C + H, rows, H, const_cast<float*>(lg->gamma), st)) return rc;
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
     constexpr int JJm = 4;  // keys per work-group of the multi-key kernel
-    if (d->K % JJm == 0 && JJm * lds2 <= 64 * 1024) {
+    if (fast_path_supported(d) && d->K % 64 == 0 && static_cast<size_t>(d->K) * KM_LD * sizeof(float) <= 64 * 1024) {
+      const size_t lds_km = static_cast<size_t>(d->K) * KM_LD * sizeof(float);
+      const dim3 grid_km(d->B * H * (d->K / 64));
+      hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<0>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Gt, dogbuf, dproj, d->K);
+      hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<1>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, At, dogbuf, dproj, d->K);
+    } else if (d->K % JJm == 0 && JJm * lds2 <= 64 * 1024) {
       hipLaunchKernelGGL((ipa_attn_bwd_keys_mr_kernel<JJm>), dim3(rows / JJm), dim3(256), JJm * lds2, st, proj, lw->gamma, dfeat, At, Gt,
                          dogbuf, dproj, d->K, C, H, DS, PQ, PV);
     } else {
