@@ -616,8 +616,10 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
                                                                    const float* __restrict__ dfeat, float* __restrict__ dproj,
                                                                    float* __restrict__ de, float* __restrict__ At, float* __restrict__ Gt,
                                                                    float* __restrict__ dogbuf, float* __restrict__ wb_part, int K, int C,
-                                                                   int H, int DS, int PQ, int PV, const float* __restrict__ Pn,
-                                                                   const float* __restrict__ D2g) {
+                                                                   int H, int DS, int PQ, int PV, float* __restrict__ Pn,
+                                                                   const float* __restrict__ D2g, const float* __restrict__ dAkv) {
+  // HAVE_P additionally: the key/value part of dA comes from dAkv (ipa_attn_bwd_dakv_mfma_kernel), g is written back over the
+  // probabilities in Pn ([b][h][i][j], for the query-side MFMA pass) and the query-side gradients are not computed here.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef float v4 __attribute__((ext_vector_type(4)));
   const int nblk = K / RR;
@@ -697,6 +699,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
         const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + i0 + rr) * K + j;
         attn_of(rr)[idx] = Pn[o];
         d2_of(rr)[idx] = D2g[o];
+        gl_of(rr)[idx] = dAkv[o];
       }
     }
     __syncthreads();
@@ -776,6 +779,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
   }
   __syncthreads();
   }
+  if constexpr (!HAVE_P) {
   // ---- dA[h][j] = do_s . v_s[j] + do_e . e[i][j] + do_g . gv[j]
   for (int idx = oct; idx < HK; idx += noct) {
     const int h = idx / K, j = idx % K;
@@ -807,6 +811,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     }
   }
   __syncthreads();
+  }
   for (int idx = oct; idx < RR * K; idx += noct) {  // the do_e . e[i][j] term of dA, all heads from one read of the pair row
     const int rr = idx / K, j = idx % K;
     float part[8];
@@ -846,6 +851,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
       gl_of(rr)[idx] = g;
       At[o + rr] = a;
       Gt[o + rr] = g;
+      if constexpr (HAVE_P) Pn[((static_cast<int64_t>(b) * H + h) * K + i0 + rr) * K + j] = g;
     }
   }
   __syncthreads();
@@ -856,6 +862,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
     if (lane == 0) wb_part[(row0 + rr) * (H * C + H) + H * C + h] = sacc;
   }
+  if constexpr (!HAVE_P) {
   // ---- query-side gradients: each key value is loaded once for the RR rows
   for (int o = tid; o < NQ; o += nthr) {
     float acc[RR];
@@ -884,6 +891,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr) dproj[(row0 + rr) * NP + off_gq + oo] = cp * acc[rr];
     }
+  }
   }
   // ---- pair embedding: de[i][j][c] += sum_h (A do_e[h][c] + g Wb[h][c]);   dWb[h][c] partial = sum_j g e[i][j][c]
   for (int rr = 0; rr < RR; ++rr) {
@@ -1037,6 +1045,8 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mr_kernel(const float* 
 // lane = four k-steps); the query-side rows are staged once per work-group in LDS as [i][64]:
 //   PART 0:  [q_s (32) | q_pts (24) | 1 | 0...]  x Gt  ->  dk_s = scale_s sum_i g q_s,  sum_i g q_pts,  sum_i g  (for d k_pts)
 //   PART 1:  [do_s (32) | dog (24) | 0...]       x At  ->  dv_s,  d v_pts
+//   PART 2 (query side, same shape with the roles of i and j swapped; A = g [b][h][i][j], staged rows are the KEY side):
+//            [k_s (32) | k_pts (24) | 1 | 0...]  x g   ->  dq_s = scale_s sum_j g k_s,  sum_j g k_pts,  sum_j g  (for d q_pts)
 constexpr int KM_LD = 68;  // LDS row stride (floats)
 template <int PART>
 __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
@@ -1058,6 +1068,10 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float
       if (c4 < 8) v = *reinterpret_cast<const v4*>(proj + (prow0 + i) * NP + h * DS + 4 * c4);
       else if (c4 < 14) v = *reinterpret_cast<const v4*>(proj + (prow0 + i) * NP + off_gq + h * NPT + 4 * (c4 - 8));
       else if (c4 == 14) v[0] = 1.0f;  // column 56: sum_i g
+    } else if (PART == 2) {
+      if (c4 < 8) v = *reinterpret_cast<const v4*>(proj + (prow0 + i) * NP + off_ks + h * DS + 4 * c4);
+      else if (c4 < 14) v = *reinterpret_cast<const v4*>(proj + (prow0 + i) * NP + off_gk + h * NPT + 4 * (c4 - 8));
+      else if (c4 == 14) v[0] = 1.0f;  // column 56: sum_j g
     } else {
       if (c4 < 8) v = *reinterpret_cast<const v4*>(dfeat + (prow0 + i) * F + h * DS + 4 * c4);
       else if (c4 < 14) v = *reinterpret_cast<const v4*>(dogbuf + (prow0 + i) * (H * NPT) + h * NPT + 4 * (c4 - 8));
@@ -1093,6 +1107,14 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float
       const float* kj = proj + row_j * NP + off_gk + h * NPT;
       drow[off_gk + h * NPT + l15] = cpg * (acc[2][r] - kj[l15] * colsum);             // columns 32..47 -> point component 0..15
       if (l15 < 8) drow[off_gk + h * NPT + 16 + l15] = cpg * (acc[3][r] - kj[16 + l15] * colsum);  // columns 48..55 -> 16..23
+    } else if (PART == 2) {  // "row_j" is the query row here
+      drow[h * DS + l15] = acc[0][r] * scale_s;
+      drow[h * DS + 16 + l15] = acc[1][r] * scale_s;
+      const float rowsum = __shfl(acc[3][r], (lane & 48) | 8);
+      const float cpq = 2.0f * scale_p * gamma[h];
+      const float* qi = proj + row_j * NP + off_gq + h * NPT;
+      drow[off_gq + h * NPT + l15] = cpq * (qi[l15] * rowsum - acc[2][r]);
+      if (l15 < 8) drow[off_gq + h * NPT + 16 + l15] = cpq * (qi[16 + l15] * rowsum - acc[3][r]);
     } else {
       drow[off_vs + h * DS + l15] = acc[0][r];
       drow[off_vs + h * DS + 16 + l15] = acc[1][r];
@@ -1100,6 +1122,73 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float
       if (l15 < 8) drow[off_gv + h * NPT + 16 + l15] = acc[3][r];
     }
   }
+}
+
+// dA_kv[b][h][i][j] = do_s[i] . v_s[j] + dog[i] . v_pts[j] on the MFMA (benchmark head geometry): work-group = (patch, head, 64
+// query rows), the value side [j][v_s (32) | v_pts (24) | 0...] staged once in LDS, A = [do_s | dog] of 16 query rows per wave in
+// registers (K-contiguous float4s, k order permuted identically for both operands).  The pair term do_e . e is added by the row pass.
+__global__ __launch_bounds__(256) void ipa_attn_bwd_dakv_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ dfeat,
+                                                                     const float* __restrict__ dogbuf, float* __restrict__ dA, int K) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [K][KM_LD]
+  constexpr int H = 8, DS = 32, NPT = 24;
+  constexpr int NP = 3 * H * DS + 3 * H * NPT, F = H * DS + H * 64 + H * NPT + H * 8;
+  constexpr int off_vs = 2 * H * DS, off_gv = 3 * H * DS + 2 * H * NPT;
+  const int nrb = K / 64;
+  const int rb = blockIdx.x % nrb, h = (blockIdx.x / nrb) % H, b = blockIdx.x / (nrb * H);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int64_t prow0 = static_cast<int64_t>(b) * K;
+  for (int idx = tid; idx < K * 16; idx += 256) {
+    const int j = idx >> 4, c4 = idx & 15;
+    v4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < 8) v = *reinterpret_cast<const v4*>(proj + (prow0 + j) * NP + off_vs + h * DS + 4 * c4);
+    else if (c4 < 14) v = *reinterpret_cast<const v4*>(proj + (prow0 + j) * NP + off_gv + h * NPT + 4 * (c4 - 8));
+    *reinterpret_cast<v4*>(smem + j * KM_LD + 4 * c4) = v;
+  }
+  const int i0 = rb * 64 + 16 * wv;
+  const int64_t row_i = prow0 + i0 + l15;
+  v4 a[4];  // A[i = l15][k = 16 grp + 4 g + s]: do_s (grp 0, 1), dog 0..15 (grp 2), dog 16..23 | 0 (grp 3)
+  a[0] = *reinterpret_cast<const v4*>(dfeat + row_i * F + h * DS + 4 * g);
+  a[1] = *reinterpret_cast<const v4*>(dfeat + row_i * F + h * DS + 16 + 4 * g);
+  a[2] = *reinterpret_cast<const v4*>(dogbuf + row_i * (H * NPT) + h * NPT + 4 * g);
+  a[3] = g < 2 ? *reinterpret_cast<const v4*>(dogbuf + row_i * (H * NPT) + h * NPT + 16 + 4 * g) : v4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  float* drow = dA + ((static_cast<int64_t>(b) * H + h) * K + i0 + 4 * g) * K + l15;  // + r rows, + 16 jt keys
+  for (int jt = 0; jt < K / 16; ++jt) {
+    v4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      const v4 bv = *reinterpret_cast<const v4*>(smem + (16 * jt + l15) * KM_LD + 16 * grp + 4 * g);  // B[k][n = key 16 jt + l15]
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[grp][s_], bv[s_], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) drow[static_cast<int64_t>(r) * K + 16 * jt] = acc[r];
+  }
+}
+
+// d o_g (gradient w.r.t. the attention-weighted global value-point sums) of every (row, head, point):
+// o_l = (o_g - t) R^T, o_n = |o_l|  ->  d o_g[k] = sum_c (do_l[c] + do_n o_l[c]/o_n) R[c][k]   (same expression as the row pass)
+__global__ void ipa_dog_kernel(const float* __restrict__ feat, const float* __restrict__ dfeat, const float* __restrict__ R, int H, int C,
+                               int DS, int PV, int64_t rows, float* __restrict__ dogbuf) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int HP = H * PV;
+  if (gid >= rows * HP) return;
+  const int64_t row = gid / HP;
+  const int hp = static_cast<int>(gid % HP);
+  const int F = H * DS + H * C + H * PV * 3 + H * PV, n_os = H * DS, n_oe = H * C, n_og = H * PV * 3;
+  const float* frow = feat + row * F;
+  const float* dfrow = dfeat + row * F;
+  const float* Rr = R + row * 9;
+  const float on = frow[n_os + n_oe + n_og + hp], don = dfrow[n_os + n_oe + n_og + hp];
+  float dl[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float ol = frow[n_os + n_oe + hp * 3 + c];
+    dl[c] = dfrow[n_os + n_oe + hp * 3 + c] + (on > 0.0f ? don * ol / on : 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dogbuf[row * n_og + hp * 3 + k] = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
 }
 
 // gradient w.r.t. global points -> local points, in place: g = p R + t  =>  dp[k] = sum_c dg[c] R[k][c]
@@ -1164,7 +1253,7 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
   return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64 + 2 * HKK +
          rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64 +
-         ((fast_path_supported(d) && attention_split_supported(d)) ? 2 * HKK : 0);  // probabilities + squared distances (MFMA recompute)
+         ((fast_path_supported(d) && attention_split_supported(d)) ? 3 * HKK : 0);  // probabilities / g, squared distances, dA_kv
 }
 
 int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
@@ -1197,6 +1286,7 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
   const bool mfma_probs = fast_path_supported(d) && attention_split_supported(d);
   float* Pn = mfma_probs ? take(HKK) : nullptr;
   float* D2g = mfma_probs ? take(HKK) : nullptr;
+  float* dAkv = mfma_probs ? take(HKK) : nullptr;
 
   hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
   DIFFAB_LAUNCH_CHECK();
@@ -1245,18 +1335,31 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     const size_t lds_mr = RRm * slot * sizeof(float);
 #ifndef DIFFAB_BWD_ONE_ROW
     if (vec && H <= 8 && d->K % RRm == 0 && lds_mr <= 160 * 1024) {
-      if (mfma_probs) {  // probabilities by the forward's MFMA kernels instead of the VALU recompute inside the row pass
+      if (mfma_probs) {
+        // MFMA path: probabilities and squared distances by the forward's kernels, the key/value part of dA as a batched GEMM; the
+        // row pass keeps what needs the pair row (do_e . e, softmax backward, d e, d w_bias, d gamma) and hands g to two more GEMMs
+        const size_t lds_km = static_cast<size_t>(d->K) * KM_LD * sizeof(float);
+        const dim3 grid_km(d->B * H * (d->K / 64));
+        const int64_t ndog = static_cast<int64_t>(rows) * H * PV;
+        hipLaunchKernelGGL(ipa_dog_kernel, dim3(static_cast<unsigned>((ndog + 255) / 256)), dim3(256), 0, st, feat, dfeat, O_t, H, C, DS, PV,
+                           static_cast<int64_t>(rows), dogbuf);
+        DIFFAB_LAUNCH_CHECK();
         if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) return rc;
+        hipLaunchKernelGGL(ipa_attn_bwd_dakv_mfma_kernel, grid_km, dim3(256), lds_km, st, proj, dfeat, dogbuf, dAkv, d->K);
+        DIFFAB_LAUNCH_CHECK();
         DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
         hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, true>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
-                           lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, Pn, D2g);
+                           lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, Pn, D2g,
+                           dAkv);
+        DIFFAB_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Pn, dogbuf, dproj, d->K);
       } else {
         DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
         hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, false>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
                            lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, nullptr,
-                           nullptr);
+                           nullptr, nullptr);
       }
     } else
 #endif
