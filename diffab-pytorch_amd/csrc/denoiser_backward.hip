@@ -125,6 +125,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   if (ty == 0 && n < N) atomicAdd(db + n, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
 }
 
+struct GemmSegs {  // the six IPA projection matrices side by side: segment s covers columns [n_end[s-1], n_end[s]) of the wide operand
+  float* p[6];
+  int n_end[6];
+  int nseg;  // 0: one plain matrix
+};
+__device__ __forceinline__ int seg_of(const GemmSegs& sg, int col, int* begin) {
+  int s_ = 0, beg = 0;
+  while (s_ + 1 < sg.nseg && col >= sg.n_end[s_]) { beg = sg.n_end[s_]; ++s_; }
+  *begin = beg;
+  return s_;
+}
 // MFMA version of C[M,N] (+)= A[M,K] B[K,N] for 16-byte-aligned operands with lda, ldb, ldc, N multiples of 4: a wave owns 16 rows
 // x 64 columns.  A is read along its contiguous (k) direction - one float4 per lane = four k-steps, k order permuted identically
 // for both operands - and B along ITS contiguous (n) direction: lane (l15, g) loads B[k0 + 4 g + s][n0 + 4 l15 ..], whose four
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
 typedef float nn_f32x4 __attribute__((ext_vector_type(4)));
 template <bool ACC>
 __global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                           float* __restrict__ C, int ldc, int M, int N, int K) {
+                                                           float* __restrict__ C, int ldc, int M, int N, int K, GemmSegs segs) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * 64 + 16 * wv, n0 = blockIdx.x * 64;
   const int arow = min(m0 + l15, M - 1);  // rows past M are clamped (never stored)
@@ -143,6 +154,11 @@ __global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restri
   const float* ap = A + static_cast<int64_t>(arow) * lda + 4 * g;
   const float* bp = Bm + static_cast<int64_t>(4 * g) * ldb + n0 + 4 * l15;
   for (int k0 = 0; k0 < K; k0 += 16) {
+    if (segs.nseg > 0) {  // rows k of B live in the segment's own matrix (segments are multiples of 16 deep: uniform per k-group)
+      int beg;
+      const float* sb = segs.p[seg_of(segs, k0, &beg)];
+      bp = sb + static_cast<int64_t>(4 * g - beg) * ldb + n0 + 4 * l15;
+    }
     nn_f32x4 a = {0.f, 0.f, 0.f, 0.f}, b[4];
     if (k0 + 4 * g + 3 < K) {
       a = *reinterpret_cast<const nn_f32x4*>(ap + k0);
@@ -174,13 +190,17 @@ __global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restri
   }
 }
 
-static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st) {
+static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st,
+                   const GemmSegs* segs = nullptr) {
+  GemmSegs sg{};
+  if (segs) sg = *segs;
   const bool mfma = lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && N % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
   dim3 grid((N + TB - 1) / TB, (M + TB - 1) / TB);
+  DIFFAB_REQUIRE(sg.nseg == 0 || mfma, DIFFAB_ERR_ARG, "gemm_nn: segmented operand needs the aligned path");
   if (mfma) {
-    if (acc) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
-    else hipLaunchKernelGGL(gemm_nn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
+    if (acc) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, sg);
+    else hipLaunchKernelGGL(gemm_nn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, sg);
   } else {
     if (acc) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
     else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
@@ -196,7 +216,8 @@ static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, i
 typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
 template <bool ALIGNED>  // false: any N1, N2, lda, ldb (per-element guarded loads and stores); true: the vector path described above
 __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                           float* __restrict__ C, int ldc, int M, int m_chunk, int N1, int N2) {
+                                                           float* __restrict__ C, int ldc, int M, int m_chunk, int N1, int N2,
+                                                           GemmSegs segs) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
   const int m_lo = (blockIdx.z * 4 + wv) * m_chunk, m_hi = min(M, m_lo + m_chunk);
@@ -243,14 +264,24 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restri
     for (int r = 0; r < 4; ++r) {
       const int crow_i = a0 + 4 * (4 * g + r) + c;
       if (!ALIGNED && crow_i >= N1) continue;
-      float* crow = C + static_cast<int64_t>(crow_i) * ldc + b0 + 4 * l15;
+      float* cbase = C;
+      int crow_l = crow_i;
+      if (segs.nseg > 0) {  // rows of C live in the segment's own matrix (segments are multiples of 64 wide: uniform per tile)
+        int beg;
+        cbase = segs.p[seg_of(segs, a0, &beg)];
+        crow_l = crow_i - beg;
+      }
+      float* crow = cbase + static_cast<int64_t>(crow_l) * ldc + b0 + 4 * l15;
 #pragma unroll
       for (int d = 0; d < 4; ++d)
         if (ALIGNED || b0 + 4 * l15 + d < N2) atomicAdd(crow + d, acc[c][d][r]);
     }
 }
 
-static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st) {
+static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st,
+                   const GemmSegs* segs = nullptr) {
+  GemmSegs sg{};
+  if (segs) sg = *segs;
   const bool aligned = N1 % 64 == 0 && N2 % 64 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(B) & 15) == 0;
   // enough (tile, M-chunk) waves to fill the chip: ~2048 waves, chunks of at least 256 rows
@@ -260,8 +291,9 @@ static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
   m_chunk = ((max(m_chunk, 256) + 15) / 16) * 16;
   const int nchunks = (M + m_chunk - 1) / m_chunk;
   dim3 grid(t2, t1, (nchunks + 3) / 4);
-  if (aligned) hipLaunchKernelGGL(gemm_tn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2);
-  else hipLaunchKernelGGL(gemm_tn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2);
+  DIFFAB_REQUIRE(sg.nseg == 0 || aligned, DIFFAB_ERR_ARG, "gemm_tn: segmented output needs the aligned path");
+  if (aligned) hipLaunchKernelGGL(gemm_tn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2, sg);
+  else hipLaunchKernelGGL(gemm_tn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2, sg);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -1401,10 +1433,27 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     float* dWs[6] = {const_cast<float*>(lg->wq_s), const_cast<float*>(lg->wk_s), const_cast<float*>(lg->wv_s),
                      const_cast<float*>(lg->wq_p), const_cast<float*>(lg->wk_p), const_cast<float*>(lg->wv_p)};
     const int Ns[6] = {H * DS, H * DS, H * DS, H * PQ * 3, H * PQ * 3, H * PV * 3};
+    bool segs_ok = D % 4 == 0 && NP % 4 == 0 && D % 64 == 0 && (reinterpret_cast<uintptr_t>(xin) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(dproj) & 15) == 0 && (reinterpret_cast<uintptr_t>(dnxt) & 15) == 0;
+    GemmSegs gw{}, gd{};
+    gw.nseg = gd.nseg = 6;
     int col = 0;
     for (int q = 0; q < 6; ++q) {
-      if (int rc = linear_bwd(dproj + col, NP, xin, D, Ws[q], dWs[q], nullptr, dnxt, D, rows, Ns[q], D, q > 0, st)) return rc;
       col += Ns[q];
+      gw.p[q] = const_cast<float*>(Ws[q]);
+      gd.p[q] = dWs[q];
+      gw.n_end[q] = gd.n_end[q] = col;
+      segs_ok = segs_ok && Ns[q] % 64 == 0 && (reinterpret_cast<uintptr_t>(Ws[q]) & 15) == 0;
+    }
+    if (segs_ok) {  // the six projections as ONE weight-gradient product and ONE input-gradient product over the 1344-wide dproj
+      if (int rc = gemm_tn(dproj, NP, xin, D, nullptr, D, rows, NP, D, st, &gd)) return rc;
+      if (int rc = gemm_nn(dproj, NP, nullptr, D, dnxt, D, rows, D, NP, false, st, &gw)) return rc;
+    } else {
+      col = 0;
+      for (int q = 0; q < 6; ++q) {
+        if (int rc = linear_bwd(dproj + col, NP, xin, D, Ws[q], dWs[q], nullptr, dnxt, D, rows, Ns[q], D, q > 0, st)) return rc;
+        col += Ns[q];
+      }
     }
     float* tmp = dcur; dcur = dnxt; dnxt = tmp;
   }
