@@ -378,6 +378,157 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __res
   }
 }
 
+// ================================================================== B': pair stream of the training backward
+// Same streaming structure as ipa_pair_stream_kernel (wave = RPW query rows, pair row in registers, no barrier), for the terms of the
+// attention backward that need the pair row:
+//   dA[h][j]  = dA_kv[h][j] (from ipa_attn_bwd_dakv_mfma_kernel) + do_e[h] . e[i][j]          (the bias-shaped MFMA product)
+//   g[h][j]   = 3^-1/2 P (dA - sum_j P dA)                     -> written over dA_kv ([b][h][i][j])
+//   d gamma_h partial = sum_j g scale_p d2,   d w_bias[h][c] partial = sum_j g e[i][j][c]       (the o_e-shaped MFMA product)
+// Partials go to wb_part[row][8 * 64 + 8]; one column sum over the rows finishes them.
+template <int NT, int RPW>
+__global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* __restrict__ e, const float* __restrict__ P,
+                                                                  float* __restrict__ G /* in: dA_kv, out: g */,
+                                                                  const float* __restrict__ D2, const float* __restrict__ dfeat,
+                                                                  float* __restrict__ wb_part, int rows_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: 2 tiles [16][ELD]
+  constexpr int K = 16 * NT;
+  const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
+  float* scr = lds + wv * (2 * 16 * ELD);
+  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 8 + wv) * RPW;
+  if (row_first >= rows_total) return;
+  const int l15 = lane0 & 15, q = lane0 >> 4;
+  const int h = l15 & 7;
+  const float scale_t = 0.57735026918962576f, scale_p = -0.5f * 0.16666666666666666f;
+  f32x4 ev[2][NT][4];
+  auto load_e_tile = [&](int slot, int64_t row, int jt) {
+    const f32x4* ep = reinterpret_cast<const f32x4*>(e + (row * K + jt * 16 + 4 * q) * AC + 4 * l15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ev[slot][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
+  };
+  auto off_of = [&](int64_t row) { return ((row / K) * AH * K + static_cast<int64_t>(h) * K + row % K) * K + 4 * q; };
+  auto stage_e = [&](int slot, int jt) {
+    float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[slot][jt][r];
+  };
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) load_e_tile(0, row_first, jt);
+  MEM_FENCE();
+
+  auto do_row = [&](auto slot_c, int64_t row, auto has_next_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr bool has_next = decltype(has_next_c)::value;
+    const int64_t off = off_of(row);
+    f32x4 dv[NT];  // dA, then g, of keys 16 jt + 4 q + r for head h (P is read per tile, twice, from L2: 32 VGPRs short otherwise)
+    f32x4 wb[4];   // B fragments of the dA_e product: do_e[h][16 sg + 4 q + s] of THIS row, zero in the padding columns
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+      wb[sg] = *reinterpret_cast<const f32x4*>(dfeat + row * AF + FOFF_OE + h * AC + 16 * sg + 4 * q);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
+    }
+    MEM_FENCE();
+    float red = 0.f;
+    stage_e(slot, 0);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      if (jt + 1 < NT) stage_e(slot, jt + 1);
+      const f32x4 pj = *reinterpret_cast<const f32x4*>(P + off + jt * 16);
+      const f32x4 dj = *reinterpret_cast<const f32x4*>(G + off + jt * 16);
+      MEM_FENCE();
+      const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[row][16 jt + l15][16 sg + 4 q + s]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wb[sg][s], acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wb[sg][s], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = dj[r] + (acc[r] + acc2[r]);
+        dv[jt][r] = v;
+        red += pj[r] * v;
+      }
+    }
+    red += __shfl_xor(red, 16);
+    red += __shfl_xor(red, 32);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {  // g out, before any load of the next row is issued (see ipa_pair_stream_kernel)
+      const f32x4 pj = *reinterpret_cast<const f32x4*>(P + off + jt * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dv[jt][r] = scale_t * pj[r] * (dv[jt][r] - red);
+      if (l15 < 8) *reinterpret_cast<f32x4*>(G + off + jt * 16) = dv[jt];
+    }
+    // d gamma partial
+    float dg = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(D2 + off + jt * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dg += dv[jt][r] * d2[r];
+    }
+    dg += __shfl_xor(dg, 16);
+    dg += __shfl_xor(dg, 32);
+    float* wrow = wb_part + row * (AH * AC + AH);
+    if (l15 < 8 && q == 0) wrow[AH * AC + h] = dg * scale_p;
+    // d w_bias partial: sum_j g[h][j] e[row][j][c], g as the B operand straight from registers
+    f32x4 oe[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[slot][jt][r][ct], dv[jt][r], oe[ct], 0, 0, 0);
+      if (has_next) {
+        load_e_tile(1 - slot, row + 1, jt);
+        MEM_FENCE();
+      }
+    }
+    if (l15 < 8) {  // D: column h = l15, row m = 4 q + r' <-> channel 16 q + 4 r' + ct
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 v = {oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
+        *reinterpret_cast<f32x4*>(wrow + h * AC + 16 * q + 4 * r) = v;
+      }
+    }
+  };
+  static_assert(RPW == 4, "rows per wave");
+  constexpr std::integral_constant<int, 0> s0{};
+  constexpr std::integral_constant<int, 1> s1{};
+  constexpr std::true_type more{};
+  constexpr std::false_type done{};
+  do_row(s0, row_first + 0, more);
+  do_row(s1, row_first + 1, more);
+  do_row(s0, row_first + 2, more);
+  do_row(s1, row_first + 3, done);
+}
+
+int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P, float* G, const float* D2, const float* dfeat,
+                           float* wb_part, hipStream_t st) {
+  const int K = d->K, rows = d->B * K;
+  DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "pair_stream_bwd: K must be 64 or 128");
+  constexpr int RPW = 4;
+  const size_t lds_b = static_cast<size_t>(8) * 2 * 16 * ELD * sizeof(float);
+  const dim3 grid_b((rows + 8 * RPW - 1) / (8 * RPW));
+  if (K == 128) {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_bwd_kernel<8, RPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+    hipLaunchKernelGGL((ipa_pair_stream_bwd_kernel<8, RPW>), grid_b, dim3(512), lds_b, st, e, P, G, D2, dfeat, wb_part, rows);
+  } else {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_bwd_kernel<4, RPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
+    hipLaunchKernelGGL((ipa_pair_stream_bwd_kernel<4, RPW>), grid_b, dim3(512), lds_b, st, e, P, G, D2, dfeat, wb_part, rows);
+  }
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 // ------------------------------------------------------------------ host side
 bool attention_split_supported(const diffab_dims* d) { return d->K == 64 || d->K == 128; }
 

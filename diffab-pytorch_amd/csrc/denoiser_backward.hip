@@ -641,7 +641,9 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
 // sets its 2.3 ms.  Here every key-side value is loaded once and used for RR rows; the per-row state lives in RR LDS slots.
 // HAVE_P: the probabilities and the squared point distances come from global memory (Pn, D2g: [b][h][i][j], written by
 // launch_attention_probs - the MFMA forward kernels re-run), instead of being recomputed here on the VALU.
-template <int RR, bool HAVE_P>
+// MODE 0: everything here on the VALU.  1 (HAVE_P): see above.  2 (HAVE_G): g itself comes from global memory too (dAkv then holds g,
+// written by ipa_pair_stream_bwd_kernel together with the d gamma / d w_bias partials): only the transposed copies and d e remain.
+template <int RR, int MODE>
 __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                                    const float* __restrict__ R, const float* __restrict__ Wb,
                                                                    const float* __restrict__ gamma, const float* __restrict__ feat,
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
   // probabilities in Pn ([b][h][i][j], for the query-side MFMA pass) and the query-side gradients are not computed here.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef float v4 __attribute__((ext_vector_type(4)));
+  constexpr bool HAVE_P = MODE >= 1, HAVE_G = MODE == 2;
   const int nblk = K / RR;
   const int b = blockIdx.x / nblk, i0 = (blockIdx.x % nblk) * RR;
   const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
       for (int rr = 0; rr < RR; ++rr) {
         const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + i0 + rr) * K + j;
         attn_of(rr)[idx] = Pn[o];
-        d2_of(rr)[idx] = D2g[o];
+        if (!HAVE_G) d2_of(rr)[idx] = D2g[o];
         gl_of(rr)[idx] = dAkv[o];
       }
     }
@@ -844,6 +847,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
   }
   __syncthreads();
   }
+  if constexpr (!HAVE_G) {
   for (int idx = oct; idx < RR * K; idx += noct) {  // the do_e . e[i][j] term of dA, all heads from one read of the pair row
     const int rr = idx / K, j = idx % K;
     float part[8];
@@ -863,6 +867,8 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     if (lo < H) gl_of(rr)[lo * K + j] += tot;
   }
   __syncthreads();
+  }
+  if constexpr (!HAVE_G) {
   // ---- softmax backward: dlogit = A (dA - sum_j A dA); keep g = scale_t * dlogit
   for (int rh = wave; rh < RR * H; rh += nwave) {
     const float* a = attn_of(rh / H) + (rh % H) * K;
@@ -873,26 +879,34 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
     if (lane == 0) red_of(rh / H)[rh % H] = sacc;
   }
   __syncthreads();
+  }
   for (int idx = tid; idx < HK; idx += nthr) {
     const int h = idx / K, j = idx % K;
     const int64_t o = ((static_cast<int64_t>(b) * H + h) * K + j) * K + i0;  // transposed: [b][h][j][i0 .. i0 + RR)
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       const float a = attn_of(rr)[idx];
-      const float g = scale_t * a * (gl_of(rr)[idx] - red_of(rr)[h]);
-      gl_of(rr)[idx] = g;
+      float g;
+      if constexpr (HAVE_G) {
+        g = gl_of(rr)[idx];
+      } else {
+        g = scale_t * a * (gl_of(rr)[idx] - red_of(rr)[h]);
+        gl_of(rr)[idx] = g;
+      }
       At[o + rr] = a;
       Gt[o + rr] = g;
-      if constexpr (HAVE_P) Pn[((static_cast<int64_t>(b) * H + h) * K + i0 + rr) * K + j] = g;
+      if constexpr (HAVE_P && !HAVE_G) Pn[((static_cast<int64_t>(b) * H + h) * K + i0 + rr) * K + j] = g;
     }
   }
   __syncthreads();
+  if constexpr (!HAVE_G) {
   for (int rh = wave; rh < RR * H; rh += nwave) {  // dgamma_h partial of the row: sum_j g scale_p d2
     const int rr = rh / H, h = rh % H;
     float sacc = 0.f;
     for (int j = lane; j < K; j += 64) sacc += gl_of(rr)[h * K + j] * scale_p * d2_of(rr)[h * K + j];
     for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
     if (lane == 0) wb_part[(row0 + rr) * (H * C + H) + H * C + h] = sacc;
+  }
   }
   if constexpr (!HAVE_P) {
   // ---- query-side gradients: each key value is loaded once for the RR rows
@@ -940,11 +954,13 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
         derow[idx] += sacc;
       }
     }
+    if constexpr (!HAVE_G) {
     for (int o = tid; o < H * C; o += nthr) {
       const int h = o / C, c = o % C;
       float sacc = 0.f;
       for (int j = 0; j < K; ++j) sacc += gl[h * K + j] * erow[static_cast<int64_t>(j) * C + c];
       wb_part[(row0 + rr) * (H * C + H) + o] = sacc;
+    }
     }
   }
 }
@@ -1379,17 +1395,18 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
         if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) return rc;
         hipLaunchKernelGGL(ipa_attn_bwd_dakv_mfma_kernel, grid_km, dim3(256), lds_km, st, proj, dfeat, dogbuf, dAkv, d->K);
         DIFFAB_LAUNCH_CHECK();
-        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, true>),
+        if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, st)) return rc;  // dAkv now holds g
+        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 2>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
-        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, true>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
+        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, 2>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
                            lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, Pn, D2g,
                            dAkv);
         DIFFAB_LAUNCH_CHECK();
-        hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Pn, dogbuf, dproj, d->K);
+        hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf, dproj, d->K);
       } else {
-        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, false>),
+        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 0>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
-        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, false>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
+        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, 0>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
                            lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, nullptr,
                            nullptr, nullptr);
       }
