@@ -220,8 +220,7 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restri
                                                            GemmSegs segs) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
-  const int m_lo = (blockIdx.z * 4 + wv) * m_chunk, m_hi = min(M, m_lo + m_chunk);
-  if (m_lo >= M) return;
+  const int m_lo = min((blockIdx.z * 4 + wv) * m_chunk, M), m_hi = min(M, m_lo + m_chunk);  // past M: an empty range (zeros)
   tn_f32x4 acc[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -257,25 +256,37 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restri
         for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[c], xb[d], acc[c][d], 0, 0, 0);
     }
   }
-  // D layout: acc[c][d][r] = tile row 4 (4 g + r) + c, tile column 4 l15 + d
+  // The four waves of a work-group hold partial sums of the SAME tile (consecutive chunks of M): they are added through LDS and
+  // wave w finishes accumulator row group c = w, so the tile costs one set of atomics per work-group instead of four.
+  __shared__ float red[4 * 64 * 64];  // [wave][value (c, d, r)][lane]
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int crow_i = a0 + 4 * (4 * g + r) + c;
-      if (!ALIGNED && crow_i >= N1) continue;
-      float* cbase = C;
-      int crow_l = crow_i;
-      if (segs.nseg > 0) {  // rows of C live in the segment's own matrix (segments are multiples of 64 wide: uniform per tile)
-        int beg;
-        cbase = segs.p[seg_of(segs, a0, &beg)];
-        crow_l = crow_i - beg;
-      }
-      float* crow = cbase + static_cast<int64_t>(crow_l) * ldc + b0 + 4 * l15;
+    for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
-        if (ALIGNED || b0 + 4 * l15 + d < N2) atomicAdd(crow + d, acc[c][d][r]);
+      for (int r = 0; r < 4; ++r) red[(wv * 64 + (c * 4 + d) * 4 + r) * 64 + lane] = acc[c][d][r];
+  __syncthreads();
+  // D layout: acc[c][d][r] = tile row 4 (4 g + r) + c, tile column 4 l15 + d
+  const int c = wv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int crow_i = a0 + 4 * (4 * g + r) + c;
+    if (!ALIGNED && crow_i >= N1) continue;
+    float* cbase = C;
+    int crow_l = crow_i;
+    if (segs.nseg > 0) {  // rows of C live in the segment's own matrix (segments are multiples of 64 wide: uniform per tile)
+      int beg;
+      cbase = segs.p[seg_of(segs, a0, &beg)];
+      crow_l = crow_i - beg;
     }
+    float* crow = cbase + static_cast<int64_t>(crow_l) * ldc + b0 + 4 * l15;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int v = (c * 4 + d) * 4 + r;
+      const float sum = (red[(0 * 64 + v) * 64 + lane] + red[(1 * 64 + v) * 64 + lane]) + (red[(2 * 64 + v) * 64 + lane] + red[(3 * 64 + v) * 64 + lane]);
+      if (ALIGNED || b0 + 4 * l15 + d < N2) atomicAdd(crow + d, sum);
+    }
+  }
 }
 
 static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st,
