@@ -389,7 +389,10 @@ template <int NT, int RPW>
 __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* __restrict__ e, const float* __restrict__ P,
                                                                   float* __restrict__ G /* in: dA_kv, out: g */,
                                                                   const float* __restrict__ D2, const float* __restrict__ dfeat,
-                                                                  float* __restrict__ wb_part, int rows_total) {
+                                                                  float* __restrict__ wb_part, int rows_total,
+                                                                  const float* __restrict__ Wb, float* __restrict__ de) {
+  // de != nullptr:  de[i][j][c] += sum_h (P[h][j] do_e[h][c] + g[h][j] w_bias[h][c])  as an MFMA product over the 16 "heads"
+  // (8 x P, 8 x g): D[c][j] with A[c][h'] = [do_e ; w_bias] and B[h'][j] = [P ; g], the B tile re-oriented through the wave's LDS.
   extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: 2 tiles [16][ELD]
   constexpr int K = 16 * NT;
   const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
@@ -411,6 +414,15 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[slot][jt][r];
   };
+  // A fragments of the d e product: lane (l15, q) holds M[h' = 4 q + s][c = 16 ct + l15]; h' < 8: do_e of the row (reloaded per row
+  // by the lanes q < 2), h' >= 8: w_bias (lanes q >= 2, loaded once)
+  float af[4][4];
+  if (de != nullptr && q >= 2) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) af[ct][s] = Wb[(4 * (q - 2) + s) * AC + 16 * ct + l15];
+  }
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) load_e_tile(0, row_first, jt);
   MEM_FENCE();
@@ -426,6 +438,12 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
       wb[sg] = *reinterpret_cast<const f32x4*>(dfeat + row * AF + FOFF_OE + h * AC + 16 * sg + 4 * q);
 #pragma unroll
       for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
+    }
+    if (de != nullptr && q < 2) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) af[ct][s] = dfeat[row * AF + FOFF_OE + (4 * q + s) * AC + 16 * ct + l15];
     }
     MEM_FENCE();
     float red = 0.f;
@@ -479,12 +497,36 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
     f32x4 oe[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* pg = scr;  // [16 h'][PGLD] tile of [P ; g] for 16 keys (the pair-tile scratch is idle after the dA_e product)
+    constexpr int PGLD = 20;
+    float* derow = de != nullptr ? de + (row * K + l15) * AC + 4 * q : nullptr;  // + 16 jt keys, + 16 ct channels
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
+      f32x4 dold[4];
+      if (de != nullptr) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) dold[ct] = *reinterpret_cast<const f32x4*>(derow + static_cast<int64_t>(jt) * 16 * AC + 16 * ct);
+        if (l15 < 8) {
+          *reinterpret_cast<f32x4*>(pg + h * PGLD + 4 * q) = *reinterpret_cast<const f32x4*>(P + off + jt * 16);
+          *reinterpret_cast<f32x4*>(pg + (8 + h) * PGLD + 4 * q) = dv[jt];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[slot][jt][r][ct], dv[jt][r], oe[ct], 0, 0, 0);
+      if (de != nullptr) {
+        float bf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[s] = pg[(4 * q + s) * PGLD + l15];  // B[h' = 4 q + s][key 16 jt + l15]
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x4 dacc = dold[ct];  // D[c = 16 ct + 4 q' + r'][key l15]: accumulate straight onto the old values
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct][s], bf[s], dacc, 0, 0, 0);
+          *reinterpret_cast<f32x4*>(derow + static_cast<int64_t>(jt) * 16 * AC + 16 * ct) = dacc;
+        }
+      }
       if (has_next) {
         load_e_tile(1 - slot, row + 1, jt);
         MEM_FENCE();
@@ -510,7 +552,7 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
 }
 
 int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P, float* G, const float* D2, const float* dfeat,
-                           float* wb_part, hipStream_t st) {
+                           float* wb_part, const float* Wb, float* de, hipStream_t st) {
   const int K = d->K, rows = d->B * K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "pair_stream_bwd: K must be 64 or 128");
   constexpr int RPW = 4;
@@ -519,11 +561,11 @@ int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P,
   if (K == 128) {
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_bwd_kernel<8, RPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
-    hipLaunchKernelGGL((ipa_pair_stream_bwd_kernel<8, RPW>), grid_b, dim3(512), lds_b, st, e, P, G, D2, dfeat, wb_part, rows);
+    hipLaunchKernelGGL((ipa_pair_stream_bwd_kernel<8, RPW>), grid_b, dim3(512), lds_b, st, e, P, G, D2, dfeat, wb_part, rows, Wb, de);
   } else {
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_bwd_kernel<4, RPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));
-    hipLaunchKernelGGL((ipa_pair_stream_bwd_kernel<4, RPW>), grid_b, dim3(512), lds_b, st, e, P, G, D2, dfeat, wb_part, rows);
+    hipLaunchKernelGGL((ipa_pair_stream_bwd_kernel<4, RPW>), grid_b, dim3(512), lds_b, st, e, P, G, D2, dfeat, wb_part, rows, Wb, de);
   }
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;

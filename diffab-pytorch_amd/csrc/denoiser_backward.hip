@@ -1406,12 +1406,13 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
         if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) return rc;
         hipLaunchKernelGGL(ipa_attn_bwd_dakv_mfma_kernel, grid_km, dim3(256), lds_km, st, proj, dfeat, dogbuf, dAkv, d->K);
         DIFFAB_LAUNCH_CHECK();
-        if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, st)) return rc;  // dAkv now holds g
+        // dAkv holds g afterwards; d pair_ctx is accumulated there too (MFMA), so the row pass below only writes the transposed copies
+        if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, lw->w_bias, d_pair_ctx, st)) return rc;
         DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 2>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
         hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, 2>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
-                           lw->w_bias, lw->gamma, feat, dfeat, dproj, d_pair_ctx, At, Gt, dogbuf, wb_part, d->K, C, H, DS, PQ, PV, Pn, D2g,
-                           dAkv);
+                           lw->w_bias, lw->gamma, feat, dfeat, dproj, static_cast<float*>(nullptr), At, Gt, dogbuf, wb_part, d->K, C, H, DS,
+                           PQ, PV, Pn, D2g, dAkv);
         DIFFAB_LAUNCH_CHECK();
         hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf, dproj, d->K);
       } else {

@@ -40,7 +40,8 @@ int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamm
 int launch_attention_probs(const diffab_dims* d, const float* proj, const float* e, const float* Wb, const float* gamma, float* P,
                            float* D2, hipStream_t st);  // training backward: normalised probabilities + squared point distances
 int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P, float* G /* in dA_kv, out g */, const float* D2,
-                           const float* dfeat, float* wb_part, hipStream_t st);  // training backward: g, d gamma / d w_bias partials
+                           const float* dfeat, float* wb_part, const float* Wb, float* de /* nullable: += d pair_ctx */,
+                           hipStream_t st);  // training backward: g, d gamma / d w_bias partials, d e
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
                            const float* gamma, float* feat, float* SP, hipStream_t st);
 
