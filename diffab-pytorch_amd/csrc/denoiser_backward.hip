@@ -1107,7 +1107,9 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mr_kernel(const float* 
 //   PART 2 (query side, same shape with the roles of i and j swapped; A = g [b][h][i][j], staged rows are the KEY side):
 //            [k_s (32) | k_pts (24) | 1 | 0...]  x g   ->  dq_s = scale_s sum_j g k_s,  sum_j g k_pts,  sum_j g  (for d q_pts)
 constexpr int KM_LD = 68;  // LDS row stride (floats)
-template <int PART>
+// TSRC: the image is stored transposed ([b][h][j][i]: one float4 per lane along k); otherwise [b][h][i][j] is read with the key as
+// the lane index and the query row as k (four 4-byte loads per lane and 16 k, 64 contiguous bytes per 16 lanes) - no transposed copy
+template <int PART, bool TSRC = true>
 __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
                                                                      const float* __restrict__ dfeat, const float* __restrict__ AGt,
                                                                      const float* __restrict__ dogbuf, float* __restrict__ dproj, int K) {
@@ -1139,12 +1141,19 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float
   }
   __syncthreads();
   const int j0 = kb * 64 + 16 * wv;
-  const float* arow = AGt + ((static_cast<int64_t>(b) * H + h) * K + j0 + l15) * K + 4 * g;  // [j][i]: + 16 grp
+  const float* arow = TSRC ? AGt + ((static_cast<int64_t>(b) * H + h) * K + j0 + l15) * K + 4 * g   // [j][i]: + 16 grp
+                           : AGt + ((static_cast<int64_t>(b) * H + h) * K + 4 * g) * K + j0 + l15;  // [i][j]: + 16 grp rows
   v4 acc[4];
 #pragma unroll
   for (int t_ = 0; t_ < 4; ++t_) acc[t_] = v4{0.f, 0.f, 0.f, 0.f};
   for (int grp = 0; grp < K / 16; ++grp) {
-    const v4 a = *reinterpret_cast<const v4*>(arow + 16 * grp);  // A[j = l15][i = 16 grp + 4 g + s]
+    v4 a;  // A[j = l15][i = 16 grp + 4 g + s]
+    if (TSRC) {
+      a = *reinterpret_cast<const v4*>(arow + 16 * grp);
+    } else {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) a[s_] = arow[static_cast<int64_t>(16 * grp + s_) * K];
+    }
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_) {
       const float* brow = smem + (16 * grp + 4 * g + s_) * KM_LD + l15;
@@ -1389,6 +1398,7 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     if (lds > 64 * 1024)
       DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    bool keys_done = false;  // the MFMA path below also does the key-side pass
     constexpr int RRm = 4;  // query rows per work-group of the multi-row kernel
     const size_t slot = ((3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) + 3) & ~static_cast<size_t>(3);
     const size_t lds_mr = RRm * slot * sizeof(float);
@@ -1408,12 +1418,12 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
         DIFFAB_LAUNCH_CHECK();
         // dAkv holds g afterwards; d pair_ctx is accumulated there too (MFMA), so the row pass below only writes the transposed copies
         if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, lw->w_bias, d_pair_ctx, st)) return rc;
-        DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 2>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));
-        hipLaunchKernelGGL((ipa_attn_bwd_rows_mr_kernel<RRm, 2>), dim3(rows / RRm), dim3(512), lds_mr, st, proj, pair_ctx, O_t,
-                           lw->w_bias, lw->gamma, feat, dfeat, dproj, static_cast<float*>(nullptr), At, Gt, dogbuf, wb_part, d->K, C, H, DS,
-                           PQ, PV, Pn, D2g, dAkv);
-        DIFFAB_LAUNCH_CHECK();
+        keys_done = true;
+        // key side straight from the [b][h][i][j] images (g in dAkv, P in Pn): no transposed copies, no VALU row pass at all
+        hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<0, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf,
+                           dproj, d->K);
+        hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<1, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Pn, dogbuf,
+                           dproj, d->K);
         hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf, dproj, d->K);
       } else {
         DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 0>),
@@ -1435,7 +1445,8 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     if (int rc = colsum(wb_part + H * C, H * C + H, rows, H, const_cast<float*>(lg->gamma), st)) return rc;
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
     constexpr int JJm = 4;  // keys per work-group of the multi-key kernel
-    if (fast_path_supported(d) && d->K % 64 == 0 && static_cast<size_t>(d->K) * KM_LD * sizeof(float) <= 64 * 1024) {
+    if (keys_done) {
+    } else if (fast_path_supported(d) && d->K % 64 == 0 && static_cast<size_t>(d->K) * KM_LD * sizeof(float) <= 64 * 1024) {
       const size_t lds_km = static_cast<size_t>(d->K) * KM_LD * sizeof(float);
       const dim3 grid_km(d->B * H * (d->K / 64));
       hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<0>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Gt, dogbuf, dproj, d->K);
