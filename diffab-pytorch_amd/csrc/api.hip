@@ -81,11 +81,13 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
 }
 
 static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
-                              const float* t, float* y, float* ws, uint32_t flags, hipStream_t st) {
+                              const float* t, float* y, float* ws, uint32_t flags, hipStream_t st, float* sp_keep = nullptr,
+                              float* d2_keep = nullptr) {
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
-    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : 0));
+    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : 0),
+                          sp_keep, d2_keep);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -152,7 +154,8 @@ static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weight
   if (int rc = launch_linear(tp.cat2, 2 * D, w->res_w0, w->res_b0, tp.h1, D, rows, D, 2 * D, true, st)) return rc;
   if (int rc = launch_linear(tp.h1, D, w->res_w2, w->res_b2, tp.x[0], D, rows, D, D, false, st)) return rc;
   for (int l = 0; l < d->NL; ++l)
-    if (int rc = ipa_layer_dispatch(d, &w->layers[l], tp.x[l], pair_ctx, O_t, x_t, tp.x[l + 1], tp.ipa_ws[l], flags, st)) return rc;
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], tp.x[l], pair_ctx, O_t, x_t, tp.x[l + 1], tp.ipa_ws[l], flags, st, tp.sp[l], tp.d2[l]))
+      return rc;
   if (int rc = launch_beta_concat(tp.x[d->NL], beta, D, d->K, rows, tp.cat3, st)) return rc;
   const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
   float* outs[3] = {out_eps, tp.vbuf, tp.logits};

@@ -610,12 +610,13 @@ int launch_attention_probs(const diffab_dims* d, const float* proj, const float*
 }
 
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
-                           const float* gamma, float* feat, float* SP, hipStream_t st) {
+                           const float* gamma, float* feat, float* SP, hipStream_t st, float* D2) {
   const int K = d->K, rows = d->B * K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_split: K must be 64 or 128");
   const dim3 grid_ac(d->B * AH * (K / RB));
-  const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 4 * 16 * 36) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
-  hipLaunchKernelGGL(ipa_logits_kernel<false>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, nullptr, K);
+  const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 8 * 16 * 36) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
+  if (D2) hipLaunchKernelGGL(ipa_logits_kernel<true>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, D2, K);
+  else hipLaunchKernelGGL(ipa_logits_kernel<false>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, nullptr, K);
   DIFFAB_LAUNCH_CHECK();
 #ifndef SPB_RPW
 #define SPB_RPW 4

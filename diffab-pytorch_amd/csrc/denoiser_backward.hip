@@ -1289,7 +1289,8 @@ size_t train_tape_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
   const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
-  return rows * (2 * D + D + D) + static_cast<size_t>(d->NL) * rows * (NP + F + D) + rows * (D + 3) + 6 * rows * D + rows * 3 +
+  const size_t keep = (fast_path_supported(d) && attention_split_supported(d)) ? 2 * static_cast<size_t>(d->B) * d->H * d->K * d->K : 0;
+  return rows * (2 * D + D + D) + static_cast<size_t>(d->NL) * (rows * (NP + F + D) + keep) + rows * (D + 3) + 6 * rows * D + rows * 3 +
          rows * d->V + 1024;
 }
 
@@ -1303,9 +1304,16 @@ TrainTape carve_tape(const diffab_dims* d, float* base) {
   t.cat2 = take(rows * 2 * D);
   t.h1 = take(rows * D);
   t.x[0] = take(rows * D);
+  const bool keep = fast_path_supported(d) && attention_split_supported(d);
+  const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
+  for (int l = 0; l < kMaxLayers; ++l) t.sp[l] = t.d2[l] = nullptr;
   for (int l = 0; l < d->NL; ++l) {
     t.ipa_ws[l] = take(rows * (NP + F));
     t.x[l + 1] = take(rows * D);
+    if (keep) {
+      t.sp[l] = take(HKK);
+      t.d2[l] = take(HKK);
+    }
   }
   t.cat3 = take(rows * (D + 3));
   for (int hd = 0; hd < 3; ++hd) { t.t1[hd] = take(rows * D); t.t2[hd] = take(rows * D); }
@@ -1413,7 +1421,12 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
         hipLaunchKernelGGL(ipa_dog_kernel, dim3(static_cast<unsigned>((ndog + 255) / 256)), dim3(256), 0, st, feat, dfeat, O_t, H, C, DS, PV,
                            static_cast<int64_t>(rows), dogbuf);
         DIFFAB_LAUNCH_CHECK();
-        if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) return rc;
+        if (tp.sp[l] != nullptr) {  // saved by the taped forward
+          Pn = tp.sp[l];
+          D2g = tp.d2[l];
+        } else if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) {
+          return rc;
+        }
         hipLaunchKernelGGL(ipa_attn_bwd_dakv_mfma_kernel, grid_km, dim3(256), lds_km, st, proj, dfeat, dogbuf, dAkv, d->K);
         DIFFAB_LAUNCH_CHECK();
         // dAkv holds g afterwards; d pair_ctx is accumulated there too (MFMA), so the row pass below only writes the transposed copies

@@ -1076,7 +1076,7 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d) {
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, int attn_mode) {
+                   float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1111,6 +1111,10 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   // DIFFAB_FLAG_SPLIT_ATTENTION (K = 64 / 128): three launches exchanging logits / probabilities through HBM (attention_split.hip).
   // Its pair-stream kernel sustains 3.8 TB/s (47 % of the HBM peak) against 2.9 for the fused kernel below, but the logits and
   // P x V launches are not yet at their floors and the three together are slower (0.45 vs 0.37 ms) - hence opt-in.
+  if (sp_keep != nullptr && attention_split_supported(d)) {  // training tape: ws has no tail here, P / d2 go to the tape's own slots
+    if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, sp_keep, st, d2_keep)) return rc;
+    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+  }
   if (attn_mode == 1 && attention_split_supported(d)) {
     float* SP = feat + static_cast<size_t>(rows) * AF + 128;
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;

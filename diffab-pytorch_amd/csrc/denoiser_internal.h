@@ -18,7 +18,8 @@ int launch_heads_finish(const float* v, const float* O_t, const float* logits, i
 bool fast_path_supported(const diffab_dims* d);
 size_t ipa_fast_workspace_floats(const diffab_dims* d);
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, int attn_mode = 0);  // 0 fused | 1 three launches | 2 logits launch + fused rest
+                   float* y, float* ws, hipStream_t st, int attn_mode = 0,  // 0 fused | 1 three launches | 2 logits launch + fused rest
+                   float* sp_keep = nullptr, float* d2_keep = nullptr);  // training tape: three launches, P and d2 kept in these buffers
 // Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);
@@ -43,7 +44,7 @@ int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P,
                            const float* dfeat, float* wb_part, const float* Wb, float* de /* nullable: += d pair_ctx */,
                            hipStream_t st);  // training backward: g, d gamma / d w_bias partials, d e
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
-                           const float* gamma, float* feat, float* SP, hipStream_t st);
+                           const float* gamma, float* feat, float* SP, hipStream_t st, float* D2 = nullptr);
 
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
@@ -55,6 +56,9 @@ void timer_end(hipStream_t st);
 constexpr int kMaxLayers = 16;
 struct TrainTape {
   float *cat2, *h1, *x[kMaxLayers + 1], *ipa_ws[kMaxLayers], *cat3, *t1[3], *t2[3], *vbuf, *logits;
+  // per layer, benchmark geometry with K = 64 / 128 only (else null): the attention probabilities and the squared point distances
+  // [b][h][i][j], saved by the three-launch forward so that the backward does not recompute them
+  float *sp[kMaxLayers], *d2[kMaxLayers];
 };
 size_t train_tape_floats(const diffab_dims* d);
 TrainTape carve_tape(const diffab_dims* d, float* base);
