@@ -65,48 +65,6 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   }
 }
 
-// C[N1,N2] += A[M,N1]^T B[M,N2]       (dW += dY^T X), the long M reduction is split over blockIdx.z and added atomically
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                      float* __restrict__ C, int ldc, int M, int N1, int N2, int m_chunk) {
-  __shared__ float As[TK][TB + 4];
-  __shared__ float Bs[TK][TB + 4];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int a0 = blockIdx.y * TB, b0 = blockIdx.x * TB;
-  const int m_lo = blockIdx.z * m_chunk, m_hi = min(M, m_lo + m_chunk);
-  float acc[4][4] = {};
-  for (int k0 = m_lo; k0 < m_hi; k0 += TK) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = tid + r * 256, kk = idx >> 6, col = idx & 63;
-      const int gm = k0 + kk;
-      As[kk][col] = (gm < m_hi && a0 + col < N1) ? A[static_cast<int64_t>(gm) * lda + a0 + col] : 0.0f;
-      Bs[kk][col] = (gm < m_hi && b0 + col < N2) ? Bm[static_cast<int64_t>(gm) * ldb + b0 + col] : 0.0f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < TK; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = a0 + ty * 4 + i;
-    if (r >= N1) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = b0 + tx * 4 + j;
-      if (c < N2) atomicAdd(C + static_cast<int64_t>(r) * ldc + c, acc[i][j]);
-    }
-  }
-}
-
 // db[n] += sum_m dY[m][n]; optionally dY *= (act > 0) first (ReLU backward, in place)
 __global__ void relu_mask_kernel(float* __restrict__ dY, const float* __restrict__ act, int64_t n) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
