@@ -36,7 +36,8 @@ constexpr int ANP = 3 * AH * ADS + 3 * AH * AP * 3;             // 1344 projecti
 constexpr int AF = AH * ADS + AH * AC + AH * AP * 3 + AH * AP;  // 1024 feature columns
 constexpr int OFF_QS = 0, OFF_KS = 256, OFF_VS = 512, OFF_GQ = 768, OFF_GK = 960, OFF_GV = 1152;
 constexpr int FOFF_OS = 0, FOFF_OE = 256, FOFF_OL = 768, FOFF_ON = 960;
-constexpr int RB = 64;  // query rows per work-group in kernels A and C (4 waves x one 16-row MFMA tile)
+// query rows per work-group in kernels A and C: 4 waves x RB / 64 16-row MFMA tiles; 128 when K allows, else 64
+inline int rows_per_wg(int K) { return K % 128 == 0 ? 128 : 64; }
 }  // namespace
 
 // ================================================================== A: logits
@@ -44,7 +45,7 @@ constexpr int KLD = 40, GLD = 28;  // LDS row strides (floats) of the staged k_s
 
 template <bool WD2>  // WD2: also write the squared point distances (the training backward needs them for d gamma)
 __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
-                                                         float* __restrict__ SP, float* __restrict__ D2, int K) {
+                                                         float* __restrict__ SP, float* __restrict__ D2, int K, int RB) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [K][KLD] k_s rows, then [K][GLD] k_pts rows of this head
   float* ks_l = lds;
   float* gk_l = lds + K * KLD;
@@ -65,10 +66,15 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
     const int j = idx / 6, c4 = idx % 6;
     *reinterpret_cast<f32x4*>(gk_l + j * GLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_GK + h * 24 + 4 * c4);
   }
-  const int i0 = rb * RB + 16 * wv;  // this wave's 16 query rows
+  // Waves are launched at a limited rate (about one per 90 cycles per XCD, measured: with one 16-row tile per wave this kernel
+  // was bound by that, CUs idle a third of the time), so a wave walks RT row tiles of the same (patch, head) instead of one.
+  const int RT = RB / 64;  // row tiles per wave
   const float scale_t = 0.57735026918962576f;                     // 3^-1/2   (diffab_pytorch.py:387, :439)
   const float scale_s = 0.17677669529663687f;                     // 32^-1/2  (:353)
   const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];   // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
+  __syncthreads();
+  for (int rt = 0; rt < RT; ++rt) {
+  const int i0 = rb * RB + 16 * (wv + 4 * rt);  // this pass's 16 query rows
   // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
   f32x4 qa[2];
   const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
@@ -82,7 +88,6 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
 #pragma unroll
     for (int cc = 0; cc < 6; ++cc) gq[r][cc] = *reinterpret_cast<const f32x4*>(p + 4 * cc);
   }
-  __syncthreads();
   // Results leave through a per-wave LDS tile [16 rows][32 keys] (two key tiles): the MFMA layout gives a lane one key of four rows,
   // i.e. 4-byte stores in 64-byte runs; re-read row-major, a lane stores 16 bytes and 8 lanes cover a full 128-byte line of a row.
   constexpr int OLD = 36;  // tile row stride (floats)
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
       }
     }
   }
+  }
 }
 
 // ================================================================== C: probabilities x values
@@ -150,7 +156,7 @@ constexpr int VLD = 36, PLD = 28;  // LDS row strides of the staged v_s (32) / v
 
 __global__ __launch_bounds__(256) void ipa_pv_kernel(const float* __restrict__ proj, const float* __restrict__ SP,
                                                      const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ feat,
-                                                     int K) {
+                                                     int K, int RB) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [K][VLD] v_s rows, then [K][PLD] v_pts rows of this head
   float* vs_l = lds;
   float* gv_l = lds + K * VLD;
@@ -166,15 +172,25 @@ __global__ __launch_bounds__(256) void ipa_pv_kernel(const float* __restrict__ p
     const int j = idx / 6, c4 = idx % 6;
     *reinterpret_cast<f32x4*>(gv_l + j * PLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_GV + h * 24 + 4 * c4);
   }
-  const int i0 = rb * RB + 16 * wv;
-  // A operand: P[i = i0 + l15][j = 16 jt + 4 q + r]; all tiles of the row requested up front (K / 16 <= 8 float4 per lane)
-  const float* prow = SP + ((static_cast<int64_t>(b) * AH + h) * K + i0 + l15) * K + 4 * q;
+  const int RT = RB / 64;  // row tiles per wave (see ipa_logits_kernel)
   const int ntile = K / 16;
-  f32x4 pa[8];
+  // A operand: P[i = i0 + l15][j = 16 jt + 4 q + r]; all tiles of the row requested up front (K / 16 <= 8 float4 per lane), the
+  // next row tile's while the current one is multiplied
+  auto prow_of = [&](int rt) {
+    return SP + ((static_cast<int64_t>(b) * AH + h) * K + rb * RB + 16 * (wv + 4 * rt) + l15) * K + 4 * q;
+  };
+  f32x4 pa[8], pn[8];
 #pragma unroll
   for (int jt = 0; jt < 8; ++jt)
-    if (jt < ntile) pa[jt] = *reinterpret_cast<const f32x4*>(prow + jt * 16);
+    if (jt < ntile) pa[jt] = *reinterpret_cast<const f32x4*>(prow_of(0) + jt * 16);
   __syncthreads();
+  for (int rt = 0; rt < RT; ++rt) {
+  const int i0 = rb * RB + 16 * (wv + 4 * rt);
+  if (rt + 1 < RT) {
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+      if (jt < ntile) pn[jt] = *reinterpret_cast<const f32x4*>(prow_of(rt + 1) + jt * 16);
+  }
   f32x4 os[2], og[3];
 #pragma unroll
   for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -215,6 +231,9 @@ __global__ __launch_bounds__(256) void ipa_pv_kernel(const float* __restrict__ p
       fo[0] = lx; fo[1] = ly; fo[2] = lz;
       fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
     }
+  }
+#pragma unroll
+  for (int jt = 0; jt < 8; ++jt) pa[jt] = pn[jt];
   }
 }
 
@@ -580,7 +599,8 @@ int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamm
   const int K = d->K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "ipa_logits: K must be 64 or 128");
   const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 4 * 16 * 36) * sizeof(float);
-  hipLaunchKernelGGL(ipa_logits_kernel<false>, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, SP, nullptr, K);
+  const int RB = rows_per_wg(K);
+  hipLaunchKernelGGL(ipa_logits_kernel<false>, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, SP, nullptr, K, RB);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -591,7 +611,8 @@ int launch_attention_probs(const diffab_dims* d, const float* proj, const float*
   const int K = d->K, rows = d->B * K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_probs: K must be 64 or 128");
   const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 8 * 16 * 36) * sizeof(float);
-  hipLaunchKernelGGL(ipa_logits_kernel<true>, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, P, D2, K);
+  const int RB = rows_per_wg(K);
+  hipLaunchKernelGGL(ipa_logits_kernel<true>, dim3(d->B * AH * (K / RB)), dim3(256), lds_a, st, proj, gamma, P, D2, K, RB);
   DIFFAB_LAUNCH_CHECK();
   constexpr int RPW = 4;
   const size_t lds_b = static_cast<size_t>(8) * 2 * 16 * ELD * sizeof(float);
@@ -613,10 +634,11 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
                            const float* gamma, float* feat, float* SP, hipStream_t st, float* D2) {
   const int K = d->K, rows = d->B * K;
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_split: K must be 64 or 128");
+  const int RB = rows_per_wg(K);
   const dim3 grid_ac(d->B * AH * (K / RB));
   const size_t lds_a = (static_cast<size_t>(K) * (KLD + GLD) + 8 * 16 * 36) * sizeof(float), lds_c = static_cast<size_t>(K) * (VLD + PLD) * sizeof(float);
-  if (D2) hipLaunchKernelGGL(ipa_logits_kernel<true>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, D2, K);
-  else hipLaunchKernelGGL(ipa_logits_kernel<false>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, nullptr, K);
+  if (D2) hipLaunchKernelGGL(ipa_logits_kernel<true>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, D2, K, RB);
+  else hipLaunchKernelGGL(ipa_logits_kernel<false>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, nullptr, K, RB);
   DIFFAB_LAUNCH_CHECK();
 #ifndef SPB_RPW
 #define SPB_RPW 4
@@ -636,7 +658,7 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
   }
   timer_end(st);
   DIFFAB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ipa_pv_kernel, grid_ac, dim3(256), lds_c, st, proj, SP, R, t, feat, K);
+  hipLaunchKernelGGL(ipa_pv_kernel, grid_ac, dim3(256), lds_c, st, proj, SP, R, t, feat, K, RB);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
