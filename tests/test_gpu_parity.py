@@ -629,28 +629,36 @@ def test_training_step_runs_and_learns(hip):
     big = DiffAb(bd["D"], bd["C"], bd["NL"], bd["DS"], bd["PQ"], bd["PV"], bd["H"]).cuda()
     sd = syn.denoiser_state_dict(bd, seed=4, prefix="")
     big.denoiser.load_state_dict(sd)
-    bi = syn.patches(1, 128, bd, seed=4, coord_sigma=6.0)
-    rc = bi["res_context_emb"].cuda().requires_grad_(True)
-    t = torch.tensor([40])
-    torch.manual_seed(0)
-    nz = big._add_noise(bi["seq_idx"].cuda(), bi["translations"].cuda(), bi["orientations"].cuda(), bi["generation_mask"].cuda(), t.cuda())
-    ls = big.hotpath_train_losses(nz, rc, bi["pair_context_emb"].cuda(), big.sched["beta"][t].cuda(), bi["orientations"].cuda(),
-                                  bi["generation_mask"].cuda(), bi["residue_mask"].cuda())
-    sum(ls).backward()
-    # oracle autograd on the same noised state
-    rco = bi["res_context_emb"].clone().requires_grad_(True)
-    sdo = {"denoiser." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    den = orc.denoiser(sdo, nz["seq_idx_t"].cpu(), nz["translations_t"].cpu(), nz["orientations_t"].cpu(), rco, bi["pair_context_emb"],
-                       big.sched["beta"][t], bd["NL"], bd["H"])
-    lo = orc.hotpath_losses(den, nz["seq_posterior"].cpu(), nz["translations_eps"].cpu(), bi["orientations"], bi["generation_mask"],
-                            bi["residue_mask"])
-    sum(lo).backward()
-    np.testing.assert_allclose([float(x) for x in ls], [float(x) for x in lo], rtol=1e-4)
-    assert maxrel(rc.grad, rco.grad) < 5e-4, maxrel(rc.grad, rco.grad)
-    for n in ("ipa.layers.0.to_q_scalar.weight", "ipa.layers.1.gamma", "ipa.layers.0.to_pair_bias.weight", "to_res_emb.0.weight",
-              "sequence_denoising.4.weight", "ipa.layers.1.to_out.weight", "ipa.layers.0.to_k_point.weight"):
-        got = dict(big.denoiser.named_parameters())[n].grad
-        assert maxrel(got, sdo["denoiser." + n].grad) < 5e-4, (n, maxrel(got, sdo["denoiser." + n].grad))
+    for Bb, Kb in ((1, 128), (2, 64)):  # both key-tile counts of the MFMA attention backward (NT = 8, 4); B = 2 crosses a patch boundary
+        bi = syn.patches(Bb, Kb, bd, seed=4, coord_sigma=6.0)
+        rc = bi["res_context_emb"].cuda().requires_grad_(True)
+        pcg = bi["pair_context_emb"].cuda().requires_grad_(True)  # exercises the d pair_ctx product of the backward stream kernel
+        t = torch.tensor([40] * Bb)
+        torch.manual_seed(0)
+        nz = big._add_noise(bi["seq_idx"].cuda(), bi["translations"].cuda(), bi["orientations"].cuda(), bi["generation_mask"].cuda(),
+                            t.cuda())
+        big.zero_grad()
+        ls = big.hotpath_train_losses(nz, rc, pcg, big.sched["beta"][t].cuda(), bi["orientations"].cuda(), bi["generation_mask"].cuda(),
+                                      bi["residue_mask"].cuda())
+        sum(ls).backward()
+        # oracle autograd on the same noised state
+        rco = bi["res_context_emb"].clone().requires_grad_(True)
+        pco = bi["pair_context_emb"].clone().requires_grad_(True)
+        sdo = {"denoiser." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        den = orc.denoiser(sdo, nz["seq_idx_t"].cpu(), nz["translations_t"].cpu(), nz["orientations_t"].cpu(), rco, pco, big.sched["beta"][t],
+                           bd["NL"], bd["H"])
+        lo = orc.hotpath_losses(den, nz["seq_posterior"].cpu(), nz["translations_eps"].cpu(), bi["orientations"], bi["generation_mask"],
+                                bi["residue_mask"])
+        sum(lo).backward()
+        np.testing.assert_allclose([float(x) for x in ls], [float(x) for x in lo], rtol=1e-4)
+        assert maxrel(rc.grad, rco.grad) < 5e-4, (Kb, maxrel(rc.grad, rco.grad))
+        assert maxrel(pcg.grad, pco.grad) < 5e-4, (Kb, maxrel(pcg.grad, pco.grad))
+        for n in ("ipa.layers.0.to_q_scalar.weight", "ipa.layers.1.gamma", "ipa.layers.0.gamma", "ipa.layers.0.to_pair_bias.weight",
+                  "ipa.layers.1.to_pair_bias.weight", "to_res_emb.0.weight", "sequence_denoising.4.weight", "ipa.layers.1.to_out.weight",
+                  "ipa.layers.0.to_k_point.weight", "ipa.layers.0.to_q_point.weight", "ipa.layers.1.to_v_point.weight",
+                  "ipa.layers.0.to_v_scalar.weight", "ipa.layers.1.to_k_scalar.weight"):
+            got = dict(big.denoiser.named_parameters())[n].grad
+            assert maxrel(got, sdo["denoiser." + n].grad) < 5e-4, (Kb, n, maxrel(got, sdo["denoiser." + n].grad))
 
 
 # ------------------------------------------------------------------ encode_context
