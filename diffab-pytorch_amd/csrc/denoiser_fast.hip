@@ -1032,16 +1032,24 @@ __global__ __launch_bounds__(512) void proj_frames_kernel(const float* __restric
 // (25 rows), so it becomes a bias table indexed by seq_t and the 2D-wide concatenation is never materialised
 // (reference diffab_pytorch.py:572-574).  Likewise cat[h, (beta, sin beta, cos beta)] W^T + b = h W[:, :D]^T + per-patch row
 // (diffab_pytorch.py:584-588) for each of the three heads.
-__global__ void fold_embed_table_kernel(const float* __restrict__ emb, const float* __restrict__ W0, const float* __restrict__ b0, int D,
-                                        int n_types, float* __restrict__ tab) {
-  // one block per residue type s; a wave per output n (strided), lanes along k so the weight row is read coalesced
-  const int s_ = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+__global__ __launch_bounds__(64) void fold_embed_table_kernel(const float* __restrict__ emb, const float* __restrict__ W0,
+                                                              const float* __restrict__ b0, int D, int n_types, float* __restrict__ tab) {
+  // one wave per (residue type s, 8 outputs n): lanes along k so the weight rows are read coalesced, the 8 rows' loads in flight
+  // together (a serial loop over n is a chain of exposed memory latencies: 20 us for a 25 x 128 table)
+  const int s_ = blockIdx.x, n0 = blockIdx.y * 8, lane = threadIdx.x;
   if (s_ >= n_types) return;
-  for (int n = wave; n < D; n += nwave) {
-    float acc = 0.f;
-    for (int k = lane; k < D; k += 64) acc += emb[s_ * D + k] * W0[n * 2 * D + D + k];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) tab[s_ * D + n] = acc + b0[n];
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = 0.f;
+    const int n = n0 + i;
+    if (n < D)
+      for (int k = lane; k < D; k += 64) acc[i] += emb[s_ * D + k] * W0[n * 2 * D + D + k];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+    if (lane == 0 && n0 + i < D) tab[s_ * D + n0 + i] = acc[i] + b0[n0 + i];
   }
 }
 __global__ void fold_beta_table_kernel(const float* __restrict__ beta, const float* __restrict__ Wa, const float* __restrict__ ba,
@@ -1057,7 +1065,7 @@ __global__ void fold_beta_table_kernel(const float* __restrict__ beta, const flo
 }
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
                        hipStream_t st) {
-  hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25), dim3(512), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
+  hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25, (d->D + 7) / 8), dim3(64), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
   DIFFAB_LAUNCH_CHECK();
   hipLaunchKernelGGL(fold_beta_table_kernel, dim3(d->B, 3), dim3(d->D), 0, st, beta, w->coord.w0, w->coord.b0, w->orient.w0, w->orient.b0,
                      w->seq.w0, w->seq.b0, d->D, d->B, beta_tab);
