@@ -5,15 +5,18 @@
 // flight for only half of a work-group's life and the key-side operands are re-staged by each of the 8 row tiles of a patch.
 // Here the phases are separate launches that exchange the (B, 8, K, K) logits / probabilities through HBM (+25 % bytes on top
 // of the pair stream, which is not the bound):
-//   A  ipa_logits_kernel       work-group = (patch, head, 64 query rows): k_s / k_pts of the head staged ONCE in LDS for the
+//   A  ipa_logits_kernel       work-group = (patch, head, 128 or 64 query rows): k_s / k_pts of the head staged ONCE in LDS for the
 //                              whole work-group, scalar logits on the MFMA, point logits as direct differences (packed fp32)
 //                              -> S[b][h][i][j] = 3^-1/2 (q.k / sqrt(ds) + coef_h |q_pts - k_pts|^2)
 //   B  ipa_pair_stream_kernel  wave = query rows, no barrier, no logits image in LDS: streams the pair row e[i] once
 //                              (non-temporal, 128 VGPRs), adds the pair bias (MFMA), softmax in registers, o_e on the MFMA,
 //                              writes the NORMALISED probabilities back in place of the logits and o_e to the feature row;
 //                              the next row's tiles are requested while the current row's are retired
-//   C  ipa_pv_kernel           work-group = (patch, head, 64 query rows): v_s / v_pts staged once in LDS, o_s and o_pts on the
-//                              MFMA with P as the A operand, global->local frames and norms -> feature row.
+//   C  ipa_pv_kernel           work-group = (patch, head, 128 or 64 query rows): v_s / v_pts staged once in LDS, o_s and o_pts on
+//                              the MFMA with P as the A operand, global->local frames and norms -> feature row.
+// Users: the opt-in DIFFAB_FLAG_SPLIT_ATTENTION forward; the training tape (the forward of a training step runs A, B, C and keeps P
+// and the squared point distances for the backward); the attention backward (B' = ipa_pair_stream_bwd_kernel below, and the
+// probability recompute when a tape has no slot for them).
 #include <type_traits>
 
 #include "common.h"
