@@ -439,7 +439,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #define DIFFAB_E_LAG 2
 #endif
   constexpr int E_LAG = MULTI ? DIFFAB_E_LAG : 0;    // the next row's tile loads trail the retiring tiles by this many (VGPRs)
-  constexpr int E_EARLY = MULTI ? DIFFAB_E_EARLY : 2;       // pair tiles of phase 2's first row started under the tail of phase 1
+#ifndef DIFFAB_E_EARLY_SINGLE
+#define DIFFAB_E_EARLY_SINGLE 2
+#endif
+  constexpr int E_EARLY = MULTI ? DIFFAB_E_EARLY : DIFFAB_E_EARLY_SINGLE;  // pair tiles of phase 2's first row started under the tail of phase 1
   float* scr = S + TI * IS + wv * SCR_FLOATS;
   float* st_fac = S + TI * IS + 8 * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
   float* st_inv = st_fac + TI * AH;              // [TI][AH] 1 / L after the last chunk (1 before)
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
       const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
       constexpr int SD = MULTI ? 3 : 4;  // register staging depth: SD - 1 key tiles of lookahead
+      static_assert(E_EARLY <= SD, "the early pair tiles are requested in the last E_EARLY iterations, which must not request key tiles any more");
       f32x4 st[SD][4];
       auto load_keys = [&](int sb, int jt) {
         const int64_t o = static_cast<int64_t>(jt) * 16 * ANP;
