@@ -234,6 +234,8 @@ def main():
         torch.cuda.synchronize()
 
     t_next = run_steps(args.warmup, model.T)
+    if dist is not None:  # untimed: RCCL sets up its channels / buffers on the first collective of each kind
+        gather_samples({"seq_idx": seq, "translations": x, "orientations": O}, dist)
     lib.diffab_kernel_timer_enable(1)
     barrier()
     t0 = time.perf_counter()
