@@ -320,6 +320,12 @@ def test_fast_path_key_chunks_vs_generic_and_oracle(hip, K):
     for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
         assert maxrel(fast[k], want[k]) < TOL, (K, k, maxrel(fast[k], want[k]))
         assert maxrel(fast[k], gen[k]) < TOL, (K, k, maxrel(fast[k], gen[k]))
+    # the opt-in attention variants (three launches / external logits) at this K: 4-tile instantiations for K = 64, and a silent
+    # fall-through to the fused kernel where they do not apply (K = 192, 256)
+    for fl in (_hip.FLAG_SPLIT_ATTENTION, _hip.FLAG_EXTERNAL_LOGITS):
+        alt = den(*[a.cuda() for a in args], beta.cuda(), None, None, return_logits=True, flags=fl)
+        for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
+            assert maxrel(alt[k], want[k]) < TOL, (K, fl, k, maxrel(alt[k], want[k]))
 
 
 def test_denoiser_translation_offset_robustness(hip):
