@@ -635,7 +635,9 @@ def test_training_step_runs_and_learns(hip):
     big = DiffAb(bd["D"], bd["C"], bd["NL"], bd["DS"], bd["PQ"], bd["PV"], bd["H"]).cuda()
     sd = syn.denoiser_state_dict(bd, seed=4, prefix="")
     big.denoiser.load_state_dict(sd)
-    for Bb, Kb in ((1, 128), (2, 64)):  # both key-tile counts of the MFMA attention backward (NT = 8, 4); B = 2 crosses a patch boundary
+    # (1, 128), (2, 64): both key-tile counts of the MFMA attention backward (NT = 8, 4), B = 2 crosses a patch boundary;
+    # (1, 256): chunked MFMA forward + the multi-row VALU backward (no MFMA backward / tape slots beyond one key chunk)
+    for Bb, Kb in ((1, 128), (2, 64), (1, 256)):
         bi = syn.patches(Bb, Kb, bd, seed=4, coord_sigma=6.0)
         rc = bi["res_context_emb"].cuda().requires_grad_(True)
         pcg = bi["pair_context_emb"].cuda().requires_grad_(True)  # exercises the d pair_ctx product of the backward stream kernel
