@@ -199,7 +199,13 @@ class _HotpathTrainStep(torch.autograd.Function):
         dims = ctx.dims
         B, K = seq.shape
         w = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, params)), ctx.denoiser.dims["NL"])
-        grads = [torch.zeros(p.shape, dtype=torch.float32, device=seq.device) for p in params]
+        # one zero-filled flat buffer, one view per parameter (256-byte aligned): a fill per parameter is 100+ tiny launches per step
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32, device=seq.device)
+        grads = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
         g = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, grads)), ctx.denoiser.dims["NL"])
         up = _hip.dev_f32(g_losses)
         d_rc = torch.empty(B, K, dims.D, dtype=torch.float32, device=seq.device)
