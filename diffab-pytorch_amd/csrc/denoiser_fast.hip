@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps,
-                                                            const float* __restrict__ Sg = nullptr) {
+                                                            const float* __restrict__ Sg = nullptr, int pf_slots = 0) {
   static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
@@ -620,15 +620,21 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           const float d2 = d2v[0] + d2v[1];
           S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
         }
+        if (c == 0 && jt == 0) stamp(6);
+        if (c == 0 && jt == 3) stamp(7);
       }
     }
     if (c == 0) stamp(1);
-
     // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
     {
       const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
+#ifndef DIFFAB_E_DEPTH0
+#define DIFFAB_E_DEPTH0 3  // tiles of the first row in flight before its bias loop starts; the rest follow one per consumed tile (all 8 at once:
+                           // 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it builds delays every other CU's loads)
+#endif
+      constexpr int E_DEPTH0 = DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT;
 #pragma unroll
-      for (int jt = E_EARLY; jt < NT; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
+      for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
       f32x4 wb[4];  // single-chunk kernel: bias B fragments in registers; multi-chunk: read from LDS per tile (VGPR pressure)
       if constexpr (!MULTI) {
 #pragma unroll
@@ -669,6 +675,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
               if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc2, 0, 0, 0);
               else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
             }
+          }
+          if (ii == 0 && jt + E_DEPTH0 < NT) {
+            load_e_tile(0, c, jt + E_DEPTH0);
+            MEM_FENCE();
           }
           const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
 #pragma unroll

@@ -75,23 +75,67 @@ __global__ void so3_scale_rot_kernel(const float* __restrict__ R, const float* _
 
 // ------------------------------------------------------------------ IGSO3 tables
 // pdf(theta; sigma) = (1 - cos theta)/pi * sum_l (2l+1) exp(-l(l+1) sigma^2) sin((l+1/2) theta)/sin(theta/2)
-// One thread per (sigma, bin); the series is summed in float64 and rounded once (the reference sums
-// 1024 float32 terms, so3.py:65-72; its result differs from this one by its own rounding error only).
+// One thread per (sigma, bin).
+//
+// FAITHFUL (the table DiffAb uses): the reference's table is NOT the exact density - it is the density plus the rounding noise of
+// its fp32 evaluation (so3.py:65-72), e.g. a = (1 - cos theta)/pi loses 2e-5 relative at the peak of row 1 to the rounding of
+// cos theta, and the clamp turns the +-1e-3 noise of the cancelling tail into ~1e-4 of spurious probability mass on the small-sigma
+// rows.  That noise is part of the distribution the reference samples from, so it is reproduced, operation by operation:
+//   * every arithmetic step rounded to fp32 in the reference's order: theta, a, b = (2l+1) * exp(fl(-(l(l+1))) * sigma^2),
+//     c = sin((l + 0.5) * theta) / sin(theta / 2), term = (a * b) * c;
+//   * cos / sin / exp correctly rounded (float64 evaluation, rounded once): torch's SLEEF kernels are correctly rounded on ~95 %
+//     of these arguments, so ~95 % of the evaluations are bit-identical and the rest differ by one ulp;
+//   * the sum over l in the order of torch's fp32 cascade sum for a reduction over the outer dimension (ATen SumKernel.cpp,
+//     multi_row_sum: 4 levels, level step max(16, 2^(ceil_log2(n)/4)) terms).
+// ACCURATE (opt-in): the whole series in float64, rounded once - the true density to fp32 accuracy.
+template <bool FAITHFUL>
 __global__ void igso3_pdf_kernel(const float* __restrict__ sigmas, int n_sigmas, int n_bins, int num_iters, float* __restrict__ pdf) {
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (gid >= static_cast<int64_t>(n_sigmas) * n_bins) return;
   const int s = static_cast<int>(gid / n_bins), m = static_cast<int>(gid % n_bins);
   const double width = kPiD / n_bins;
-  const double theta = static_cast<double>(static_cast<float>(m * width) + static_cast<float>(width / 2.0));
-  const double sg = static_cast<double>(sigmas[s]);
-  const double a = (1.0 - cos(theta)) / kPiD;
-  const double inv_sh = 1.0 / sin(theta / 2.0);
-  double acc = 0.0;
-  for (int l = 0; l < num_iters; ++l) {
-    const double ld = static_cast<double>(l);
-    acc += (2.0 * ld + 1.0) * exp(-ld * (ld + 1.0) * sg * sg) * sin((ld + 0.5) * theta) * inv_sh;
+  const float theta_f = static_cast<float>(m * width) + static_cast<float>(width / 2.0);  // arange(0, pi, w) + w / 2 (so3.py:57)
+  float v;
+  if (FAITHFUL) {
+    auto cr_cos = [](float x) { return static_cast<float>(cos(static_cast<double>(x))); };
+    auto cr_sin = [](float x) { return static_cast<float>(sin(static_cast<double>(x))); };
+    auto cr_exp = [](float x) { return static_cast<float>(exp(static_cast<double>(x))); };
+    const float sg2 = sigmas[s] * sigmas[s];
+    const float a = (1.0f - cr_cos(theta_f)) / kPiF;
+    const float sh = cr_sin(theta_f / 2.0f);
+    auto term = [&](int l) {
+      const float b = static_cast<float>(2 * l + 1) * cr_exp(static_cast<float>(-static_cast<int64_t>(l) * (l + 1)) * sg2);
+      const float c = cr_sin((static_cast<float>(l) + 0.5f) * theta_f) / sh;
+      return (a * b) * c;
+    };
+    int lg = 0;
+    while ((1 << lg) < num_iters) ++lg;  // ceil_log2
+    const int level_power = lg / 4 > 4 ? lg / 4 : 4, level_step = 1 << level_power, level_mask = level_step - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    while (i + level_step <= num_iters) {
+      for (int j = 0; j < level_step; ++j, ++i) acc[0] += term(i);
+      for (int j = 1; j < 4; ++j) {
+        acc[j] += acc[j - 1];
+        acc[j - 1] = 0.f;
+        if ((i & (level_mask << (j * level_power))) != 0) break;
+      }
+    }
+    for (; i < num_iters; ++i) acc[0] += term(i);
+    for (int j = 1; j < 4; ++j) acc[0] += acc[j];
+    v = acc[0];
+  } else {
+    const double theta = static_cast<double>(theta_f);
+    const double sg = static_cast<double>(sigmas[s]);
+    const double a = (1.0 - cos(theta)) / kPiD;
+    const double inv_sh = 1.0 / sin(theta / 2.0);
+    double acc = 0.0;
+    for (int l = 0; l < num_iters; ++l) {
+      const double ld = static_cast<double>(l);
+      acc += (2.0 * ld + 1.0) * exp(-ld * (ld + 1.0) * sg * sg) * sin((ld + 0.5) * theta) * inv_sh;
+    }
+    v = static_cast<float>(a * acc);
   }
-  float v = static_cast<float>(a * acc);
   if (!(v == v)) v = 0.0f;           // nan_to_num (so3.py:61)
   if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
   pdf[gid] = v < 0.0f ? 0.0f : v;    // clamp_min(0)
@@ -184,6 +228,15 @@ constexpr int kV = 21;  // diffusion.py:47
 __device__ inline float seq_prob(int v, int64_t centre, float w_keep, float w_noise, bool gen) {
   const float oh = (v == centre) ? 1.0f : 0.0f;
   return gen ? (w_keep * oh + w_noise * (1.0f / 21.0f)) : oh;
+}
+
+// w1[b] p1 + w2[b] p2 over the trailing (K, V) elements of patch b (diffusion.py:38-41; separate mul / add roundings, as ATen)
+__global__ void weighted_multinomial_kernel(const float* __restrict__ p1, const float* __restrict__ p2, const float* __restrict__ w1,
+                                            const float* __restrict__ w2, int64_t n, int64_t per_b, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = i / per_b;
+  out[i] = w1[b] * p1[i] + w2[b] * p2[i];
 }
 
 __global__ void seq_forward_prob_kernel(const float* __restrict__ beta, const float* __restrict__ alpha_bar, int T, int mode,
@@ -494,12 +547,22 @@ int diffab_so3_scale_rot(const float* R, const float* k, float* out, int64_t n, 
   ELEMENTWISE_ENTRY("so3_scale_rot", so3_scale_rot_kernel, R && k && out, n, R, k, out, n, per_k)
 }
 
-int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream) {
-  DIFFAB_REQUIRE(sigmas && pdf && n_sigmas > 0 && n_bins > 0 && num_iters > 0, DIFFAB_ERR_ARG, "igso3_table_build: bad argument");
+static int igso3_table(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, bool faithful, void* stream) {
+  DIFFAB_REQUIRE(sigmas && pdf && n_sigmas > 0 && n_bins > 0 && num_iters > 0 && num_iters <= 4096, DIFFAB_ERR_ARG,
+                 "igso3_table_build: bad argument");
   const int64_t n = static_cast<int64_t>(n_sigmas) * n_bins;
-  hipLaunchKernelGGL(igso3_pdf_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), sigmas, n_sigmas, n_bins, num_iters, pdf);
+  if (faithful)
+    hipLaunchKernelGGL(igso3_pdf_kernel<true>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), sigmas, n_sigmas, n_bins, num_iters, pdf);
+  else
+    hipLaunchKernelGGL(igso3_pdf_kernel<false>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), sigmas, n_sigmas, n_bins, num_iters, pdf);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
+}
+int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream) {
+  return igso3_table(sigmas, n_sigmas, n_bins, num_iters, pdf, true, stream);
+}
+int diffab_igso3_table_build_accurate(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream) {
+  return igso3_table(sigmas, n_sigmas, n_bins, num_iters, pdf, false, stream);
 }
 
 int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, float* cdf, void* stream) {
@@ -520,6 +583,12 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
                      tab->sigma_threshold, sigma_idx, B, K, axis_raw, u_bin, u_in, z, rotvec);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
+}
+
+int diffab_weighted_multinomial(const float* p1, const float* p2, const float* w1, const float* w2, int64_t n, int64_t per_b, float* out,
+                                void* stream) {
+  DIFFAB_REQUIRE(per_b > 0, DIFFAB_ERR_ARG, "weighted_multinomial: per_b must be positive");
+  ELEMENTWISE_ENTRY("weighted_multinomial", weighted_multinomial_kernel, p1 && p2 && w1 && w2 && out, n, p1, p2, w1, w2, n, per_b, out)
 }
 
 int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq, const int64_t* t, const uint8_t* mask, int32_t B,

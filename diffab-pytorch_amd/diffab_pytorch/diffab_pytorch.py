@@ -43,6 +43,27 @@ def _named(module: nn.Module) -> Dict[str, torch.Tensor]:
     return dict(module.named_parameters())
 
 
+_warned_detached = set()
+
+
+def _warn_if_grad_expected(who: str, module: Optional[nn.Module], *tensors) -> None:
+    """The per-module forwards are inference calls into the HIP library: their outputs carry no grad_fn.  A caller who builds a
+    loss of their own from them under autograd would silently get no gradients, so say so once per module type; the
+    differentiable path is DiffAb.training_step / DiffAb.hotpath_train_losses (one taped HIP forward + one HIP backward)."""
+    if not torch.is_grad_enabled() or who in _warned_detached:
+        return
+    needs = any(torch.is_tensor(t_) and t_.requires_grad for t_ in tensors)
+    if not needs and module is not None and module.training:
+        needs = any(p.requires_grad for p in module.parameters())
+    if needs:
+        _warned_detached.add(who)
+        import warnings
+
+        warnings.warn(f"{who}.forward runs the HIP inference path: its outputs are detached from autograd (no grad_fn).  Use "
+                      "DiffAb.training_step / DiffAb.hotpath_train_losses for gradients, or torch.no_grad() to silence this.",
+                      stacklevel=3)
+
+
 class InvariantPointAttentionLayer(nn.Module):
     """Reference IPA layer: no LayerNorm/residual/transition, raw gamma, unmasked (diffab_pytorch.py:339-465)."""
 
@@ -70,6 +91,7 @@ class InvariantPointAttentionLayer(nn.Module):
 
     def forward(self, x, e, r, t, *, flags: int = 0):
         lib = _hip.lib()
+        _warn_if_grad_expected("InvariantPointAttentionLayer", self, x, e)
         xd, ed, rd, td = (_hip.dev_f32(a) for a in (x, e, r, t))
         B, K = xd.shape[:2]
         d = self.dims
@@ -136,6 +158,7 @@ class Denoiser(nn.Module):
                 residue_mask=None, *, return_logits: bool = False, flags: int = 0) -> Dict[str, torch.Tensor]:
         # generation_mask / residue_mask are accepted and ignored, exactly like the reference (:566-567).
         lib = _hip.lib()
+        _warn_if_grad_expected("Denoiser", self, res_context_emb, pair_context_emb, translations_t)
         out_dev = translations_t.device
         seq = _hip.dev_i64(seq_idx_t)
         x, O, rc, pc, bt = (_hip.dev_f32(a) for a in (translations_t, orientations_t, res_context_emb, pair_context_emb, beta))
@@ -229,6 +252,7 @@ class OrientationLoss(nn.Module):
 
     def forward(self, pred_rotmat: torch.Tensor, target_rotmat: torch.Tensor) -> torch.Tensor:
         lib = _hip.lib()
+        _warn_if_grad_expected("OrientationLoss", None, pred_rotmat, target_rotmat)
         p, t = _hip.dev_f32(pred_rotmat), _hip.dev_f32(target_rotmat)
         n = p.numel() // 9
         elems = torch.empty_like(p) if self.reduction == "none" else None
@@ -426,8 +450,9 @@ class DiffAb(_ModuleBase):
         return losses[0].to(out_dev), losses[1].to(out_dev), losses[2].to(out_dev)
 
     def _shared_step(self, batch, batch_idx):
-        """t ~ U[1,T]; noise; denoise; three losses (diffab_pytorch.py:808-880).  Context embeddings are taken from
-        batch['res_context_emb'] / batch['pair_context_emb'] until encode_context lands on this path."""
+        """t ~ U[1,T]; noise; denoise; three losses (diffab_pytorch.py:808-880).  The contexts come from encode_context on
+        the reference's batch dict, or from batch['res_context_emb'] / batch['pair_context_emb'] when a caller
+        has them already (the hot-path benchmarks and gradient goldens, where contexts are leaf inputs)."""
         dev_in = batch["generation_mask"].device
         bsz = batch["generation_mask"].size(0)
         t = torch.randint(low=1, high=self.T + 1, size=(bsz,)).to(dev_in)
@@ -469,18 +494,39 @@ class DiffAb(_ModuleBase):
 
     # ------------------------------------------------------------------ reverse process (the reference has a stub, :770-776)
     @torch.no_grad()
-    def sample(self, seq_idx: torch.LongTensor, xyz: torch.FloatTensor, orientations: torch.FloatTensor, *, res_context_emb=None,
-               pair_context_emb=None, generation_mask=None, seed: Optional[int] = None, first_patch: int = 0, t_start: Optional[int] = None,
+    def sample(self, seq_idx: torch.LongTensor, xyz: torch.FloatTensor, orientations: torch.FloatTensor, *, generation_mask=None,
+               res_context_emb=None, pair_context_emb=None, residue_mask=None, backbone_dihedrals=None, pairwise_dihedrals=None,
+               distmat=None, atom_mask=None, chain_idx=None, residue_idx=None, generate_structure: bool = True,
+               generate_sequence: bool = True, seed: Optional[int] = None, first_patch: int = 0, t_start: Optional[int] = None,
                t_stop: int = 0, init: bool = True, flags: int = 0) -> Dict[str, torch.Tensor]:
-        """Reverse diffusion t_start .. t_stop+1 (default T .. 1) on the generated residues.
+        """Reverse diffusion t_start .. t_stop+1 (default T .. 1) on the generated residues (the reference's `sample` is a stub,
+        diffab_pytorch.py:770-776; the loop is build-defined).
 
         seq_idx (B,K), xyz (B,K,3) CA translations or (B,K,A,3) atoms, orientations (B,K,3,3): the ground-truth
         context; generated residues are re-initialised (x ~ N(0,I), O ~ U(SO3), s ~ U{0..19}) when ``init``.
+        Contexts: pass ``res_context_emb`` / ``pair_context_emb``, or the remaining fields of the reference's batch dict
+        (backbone_dihedrals, pairwise_dihedrals, atom_mask, chain_idx; residue_idx and residue_mask default to
+        arange(K) and all-true; distmat is taken from xyz on the device when absent) and `encode_context` runs first, once.
         Noise is Philox keyed by (seed, first_patch + b, residue, t): any sharding of a batch over ranks gives
         the same samples.  All T steps are enqueued on the current stream by ONE C-ABI call, no host sync."""
-        if res_context_emb is None or pair_context_emb is None or generation_mask is None:
-            raise NotImplementedError("sample() needs res_context_emb, pair_context_emb and generation_mask until encode_context "
-                                      "is on this path (SURVEY.md 8f-1)")
+        if generation_mask is None:
+            raise ValueError("sample() needs generation_mask: which residues to generate")
+        if res_context_emb is None or pair_context_emb is None:
+            need = {"backbone_dihedrals": backbone_dihedrals, "pairwise_dihedrals": pairwise_dihedrals, "atom_mask": atom_mask,
+                    "chain_idx": chain_idx}
+            missing = [k for k, v in need.items() if v is None]
+            if missing or xyz.dim() != 4:
+                raise ValueError("sample(): without res_context_emb / pair_context_emb the contexts are computed by encode_context, "
+                                 f"which needs all-atom xyz (B,K,A,3) and the batch fields {sorted(need)}; missing: "
+                                 f"{missing if missing else 'xyz is not (B,K,A,3)'}")
+            Bq, Kq = seq_idx.shape
+            if residue_mask is None:
+                residue_mask = torch.ones(Bq, Kq, dtype=torch.bool, device=seq_idx.device)
+            if residue_idx is None:
+                residue_idx = torch.arange(Kq, device=seq_idx.device).unsqueeze(0)  # data.py:91
+            res_context_emb, pair_context_emb = self.encode_context(seq_idx, xyz, orientations, backbone_dihedrals, distmat,
+                                                                    pairwise_dihedrals, atom_mask, chain_idx, residue_idx,
+                                                                    generation_mask, residue_mask, generate_structure, generate_sequence)
         lib = _hip.lib()
         out_dev = seq_idx.device
         seq = _hip.dev_i64(seq_idx).clone()

@@ -40,6 +40,25 @@ def cosine_variance_schedule(T: int, s: float = 8e-3, beta_max: float = 0.999) -
     }
 
 
+def weighted_multinomial(p1: torch.Tensor, p2: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """w1 * p1 + w2 * p2 with the (B,) weights broadcast over the trailing (K, V) dimensions (reference diffusion.py:38-41;
+    p1 may be an int64 one-hot, promoted to float32 as upstream)."""
+    a, b = _hip.dev_f32(p1), _hip.dev_f32(p2)
+    if a.shape != b.shape or a.dim() != 3:
+        a, b = torch.broadcast_tensors(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        if a.dim() != 3:
+            raise ValueError("weighted_multinomial expects (B, K, V) probabilities")
+    wa, wb = _hip.dev_f32(w1), _hip.dev_f32(w2)
+    B = a.shape[0]
+    if wa.shape != (B,) or wb.shape != (B,):
+        raise ValueError("weighted_multinomial expects (B,) weights")
+    out = torch.empty_like(a)
+    _hip.check(_hip.lib().diffab_weighted_multinomial(_hip.ptr(a), _hip.ptr(b), _hip.ptr(wa), _hip.ptr(wb), a.numel(),
+                                                      a.numel() // max(B, 1), _hip.ptr(out), _hip.stream_ptr()), "diffab_weighted_multinomial")
+    return out.to(p2.device if torch.is_tensor(p2) else out.device)
+
+
 class _Diffuser:
     def __init__(self, T, s, beta_max):
         self.sched = cosine_variance_schedule(T, s=s, beta_max=beta_max)

@@ -8,7 +8,8 @@ libdiffab_hip.so on the current HIP device and results come back on the caller's
 
 Differences from the reference, all documented in DESIGN.md:
   * the IGSO3 table is built on the GPU in milliseconds and never cached on disk
-    (``cache_prefix`` is accepted and ignored; the reference's cache key never hit anyway, so3.py:18);
+    (``cache_prefix`` is accepted and ignored; the reference's cache key never hit anyway, so3.py:18); it is the reference's
+    table (fp32 terms, see SO3.__init__), with the float64 series as the opt-in ``accurate=True``;
   * random draws come from a Philox stream seeded from torch's default generator
     (``torch.manual_seed`` still makes calls reproducible) - or from explicit noise tensors;
   * histogram bins are drawn by inverse CDF, i.e. WITH replacement across the residues of a patch
@@ -128,8 +129,13 @@ def uniform(*size) -> torch.Tensor:
 class SO3:
     """IGSO3 angle table + axis-angle sampler (so3.py:9-126)."""
 
-    def __init__(self, sigmas_to_consider, cache_prefix=".cache/so3_histograms", sigma_threshold=0.1, n_bins=8192, num_iters=1024):
+    def __init__(self, sigmas_to_consider, cache_prefix=".cache/so3_histograms", sigma_threshold=0.1, n_bins=8192, num_iters=1024, *,
+                 accurate: bool = False):
+        """``accurate=False`` (what DiffAb uses): the reference's table - every series term with the reference's own fp32
+        roundings, so its rectified rounding noise (~1e-4 of spurious tail mass on the small-sigma rows) is part of the table,
+        as it is part of what the reference samples from.  ``accurate=True``: the series in float64, i.e. the exact density."""
         lib = _hip.lib()
+        self.accurate = bool(accurate)
         self.n_bins = int(n_bins)
         self.num_iters = int(num_iters)
         self.sigma_threshold = float(sigma_threshold)
@@ -138,8 +144,9 @@ class SO3:
         n = int(self._sigmas.numel())
         self.histograms = torch.empty(n, self.n_bins, dtype=torch.float32, device=self._sigmas.device)
         self._cdf = torch.empty_like(self.histograms)
-        _hip.check(lib.diffab_igso3_table_build(_hip.ptr(self._sigmas), n, self.n_bins, self.num_iters, _hip.ptr(self.histograms),
-                                                _hip.stream_ptr()), "diffab_igso3_table_build")
+        build = lib.diffab_igso3_table_build_accurate if self.accurate else lib.diffab_igso3_table_build
+        _hip.check(build(_hip.ptr(self._sigmas), n, self.n_bins, self.num_iters, _hip.ptr(self.histograms), _hip.stream_ptr()),
+                   "diffab_igso3_table_build")
         _hip.check(lib.diffab_igso3_cdf_build(_hip.ptr(self.histograms), n, self.n_bins, _hip.ptr(self._cdf), _hip.stream_ptr()),
                    "diffab_igso3_cdf_build")
 

@@ -61,6 +61,9 @@ def parse_argument(argv: Optional[List[str]] = None) -> argparse.Namespace:
     parser.add_argument("--resume", default=None, help="Checkpoint to resume from")
     parser.add_argument("--log", default=None, help="JSON-lines log file (default: stdout on rank 0)")
     parser.add_argument("--max-steps", type=int, default=0, help="Stop after this many optimiser steps (0 = run all epochs)")
+    parser.add_argument("--cdr-mask-key", default="generation_mask",
+                        help="Key of the boolean (1, K) CDR mask inside each patch file.  preprocess_pdb.py:67-80 stores none (upstream "
+                             "derives it from the PDB numbering with protstruc, data.py:92), so patches must be augmented with one")
     return parser.parse_args(argv)
 
 
@@ -79,10 +82,17 @@ def load_patch(path: str, cdr_mask_key: str = "generation_mask") -> Dict[str, to
     if missing:
         raise KeyError(f"{path}: patch file lacks {missing} (expected the keys of reference preprocess_pdb.py:67-80)")
     out = {k: data[k] for k in PATCH_KEYS}
-    if cdr_mask_key in data:
-        out["generation_mask"] = data[cdr_mask_key]
-    else:  # preprocess_pdb.py does not store a CDR mask; fall back to "generate nothing" so the caller must supply one
-        out["generation_mask"] = torch.zeros_like(data["residue_mask"], dtype=torch.bool)
+    if cdr_mask_key not in data:
+        # preprocess_pdb.py:67-80 writes no CDR mask and it cannot be rebuilt from the patch (upstream takes it from the PDB
+        # numbering through protstruc, data.py:92: get_cdr_mask(subset=cdrs)).  An all-false mask would make every loss 0/0.
+        raise KeyError(f"{path}: no '{cdr_mask_key}' entry - add a boolean (1, K) mask of the residues to generate to the patch "
+                       f"file (or name its key with --cdr-mask-key); the reference's patch format has none")
+    mask = data[cdr_mask_key].bool()
+    if mask.shape != data["residue_mask"].shape:
+        raise ValueError(f"{path}: '{cdr_mask_key}' has shape {tuple(mask.shape)}, expected {tuple(data['residue_mask'].shape)}")
+    if not bool((mask & data["residue_mask"].bool()).any()):
+        raise ValueError(f"{path}: '{cdr_mask_key}' selects no valid residue (the three losses divide by the number of masked residues)")
+    out["generation_mask"] = mask
     return out
 
 
@@ -138,7 +148,7 @@ class PatchSource:
             lo, hi = self._shard(len(ids), self.rank, self.world)
             mine = ids[lo:hi]
             if self.args.patch_dir:
-                yield collate([load_patch(self.files[i]) for i in mine])
+                yield collate([load_patch(self.files[i], self.args.cdr_mask_key) for i in mine])
             else:
                 parts = [self._syn.context_batch(1, self.args.k, seed=self.args.seed + self.offset + i) for i in mine]
                 for p_ in parts:
@@ -187,6 +197,10 @@ def main(argv: Optional[List[str]] = None) -> int:
     if world > 1:  # identical parameters on every rank
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
+    # Timesteps and the forward-noise Philox seeds are drawn from torch's default generator: after the (identical) model
+    # construction give every rank its own stream, otherwise rank r's local patch b would get exactly the t, eps, categorical
+    # and IGSO3 draws of rank 0's local patch b (B / world distinct draws per global batch).
+    torch.manual_seed(args.seed + 7919 * (rank + 1) + 104729 * start["global_step"])
 
     train_src, val_src = PatchSource(args, rank, world, "train"), PatchSource(args, rank, world, "val")
     log_f = open(args.log, "a") if (args.log and rank == 0) else None
@@ -214,6 +228,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         for i, batch in enumerate(train_src.batches(epoch)):
             optimizer.zero_grad(set_to_none=False)
             loss = model.training_step(to_dev(batch), i)
+            if not bool(torch.isfinite(loss.detach())):
+                raise SystemExit(f"rank {rank}: non-finite loss {float(loss)} at epoch {epoch}, batch {i} (captured: {captured}) - aborting")
             loss.backward()
             D.allreduce_gradients(model.parameters(), dist if world > 1 else None)
             if args.gradient_clip_val:

@@ -140,8 +140,13 @@ int diffab_so3_rotvec_to_matrix(const float* v, float* R, int64_t n, void* strea
 int diffab_so3_scale_rot(const float* R, const float* k, float* out, int64_t n, int64_t per_k, void* stream);
 
 /* ---- IGSO3 ---------------------------------------------------------------- */
-/* so3.py:52-72  pdf[n_sigmas][n_bins] at the bin centres, series of num_iters terms, NaN->0, <0 -> 0 */
+/* so3.py:52-72  pdf[n_sigmas][n_bins] at the bin centres, series of num_iters terms, NaN->0, <0 -> 0.  The reference's table:
+ * every term formed with the reference's own fp32 roundings (its rounding noise, rectified by the clamp, is part of the
+ * distribution it samples from); the terms are added in float64 (torch's cascade sum has no fixed order to copy). */
 int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream);
+/* opt-in variant: the whole series in float64, rounded once - the exact density, NOT what the reference samples from */
+int diffab_igso3_table_build_accurate(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf,
+                                      void* stream);
 /* build-defined: cdf rows = normalised inclusive prefix sums (float64 accumulate) of the pdf rows */
 int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, float* cdf, void* stream);
 /* so3.py:98-126  rot-vectors (B,K,3) = normalize(axis_raw) * theta, theta from the histogram row
@@ -151,6 +156,9 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
                         const float* u_bin, const float* u_in, const float* z, float* rotvec, void* stream);
 
 /* ---- forward (noising) process, explicit noise ----------------------------- */
+/* diffusion.py:38-41  out[b, ...] = w1[b] p1[b, ...] + w2[b] p2[b, ...]; n elements in all, per_b of them per patch */
+int diffab_weighted_multinomial(const float* p1, const float* p2, const float* w1, const float* w2, int64_t n, int64_t per_b,
+                                float* out, void* stream);
 /* diffusion.py:49-79 (mode 0: q(s_t|s_{t-1}), beta_t), :105-135 (mode 1: q(s_t|s_0), alpha_bar_t) */
 int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq, const int64_t* t, const uint8_t* mask,
                             int32_t B, int32_t K, float* prob /* (B,K,21) */, void* stream);

@@ -69,6 +69,11 @@ def _onehot(idx: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     return torch.nn.functional.one_hot(idx, V_AA).to(dtype)
 
 
+def weighted_multinomial(p1, p2, w1, w2):
+    """w1 p1 + w2 p2, weights (B,) broadcast over (K, V).  (diffusion.py:38-41)"""
+    return w1[:, None, None] * p1 + w2[:, None, None] * p2
+
+
 def seq_forward_prob_single_step(seq, t, mask, sched, dtype=torch.float32):
     """q(s_t | s_{t-1}) = (1-beta_t) onehot + beta_t/21; exact one-hot where
     the residue is not generated.  (diffusion.py:49-79)"""

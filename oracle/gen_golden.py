@@ -169,6 +169,13 @@ def main():
     check("forward_prob_single_step", orc.seq_forward_prob_single_step(seqt, t, mask, osched), ref["single"], 1e-7)
     check("forward_prob_from_t0", orc.seq_forward_prob_from_t0(seq0, t, mask, osched), ref["from_t0"], 1e-7)
     check("posterior_single_step", orc.seq_posterior_single_step(seqt, seq0, t, mask, osched), ref["posterior"], 1e-6)
+    # weighted_multinomial (diffusion.py:38-41) with an int64 one-hot as p1, as its two call sites pass it
+    wm_p1 = torch.nn.functional.one_hot(seq0, 21)
+    rng_wm = np.random.Generator(np.random.PCG64([7, 2]))  # its own stream: the fixtures below keep their round-1 draws
+    wm_p2 = torch.from_numpy(rng_wm.random((Bs, Ls, 21)).astype(np.float32))
+    wm_w1, wm_w2 = torch.from_numpy(rng_wm.random(Bs).astype(np.float32)), torch.from_numpy(rng_wm.random(Bs).astype(np.float32))
+    ref.update(wm_p2=wm_p2, wm_w1=wm_w1, wm_w2=wm_w2, wm_out=rdiff.weighted_multinomial(wm_p1, wm_p2, wm_w1, wm_w2))
+    check("weighted_multinomial", orc.weighted_multinomial(wm_p1, wm_p2, wm_w1, wm_w2), ref["wm_out"], 0.0)
     np.savez_compressed(os.path.join(GOLD, "seqdiff.npz"), **{k: npf(x) for k, x in ref.items()})
 
     # ---------------------------------------------------------------- coordinate diffuser
@@ -326,6 +333,62 @@ def main():
     for n_, p_ in den.named_parameters():
         g["grad/" + n_] = npf(p_.grad)
     np.savez_compressed(os.path.join(GOLD, "losses_grads.npz"), **g)
+
+    # ---------------------------------------------------------------- hot-path gradients at the benchmark geometry (MFMA kernels)
+    # Autograd of the REAL reference at D=128, C=64, H=8, DS=32, P=8, K=128, NL=2, B=2.  The full gradients are 5 MB (pair context
+    # alone 8 MB), so the fixture holds, for every parameter and both contexts: the L2 norm, the max |g|, and a strided subsample
+    # (<= 512 elements, stride and offset stored), which a wrong kernel cannot match by accident.
+    print("hot-path gradients at the benchmark geometry (K=128, NL=2, B=2; reference autograd, ~1 min)")
+    dims = dict(syn.BENCH_DIMS, NL=2)
+    B, K, seed = 2, 128, 33
+    den, sd = build_ref_denoiser(dims, seed)
+    den.train()
+    inp = syn.patches(B, K, dims, seed=seed, coord_sigma=6.0)
+    tt = torch.tensor([12, 71])
+    beta = sched["beta"][tt]
+    gen, resm = inp["generation_mask"].clone(), inp["residue_mask"].clone()
+    resm[1, :2] = False
+    gen[1, :4] = True
+    torch.manual_seed(6)
+    seq_t, post = sdiff.diffuse_from_t0(inp["seq_idx"], tt, gen, return_posterior=True)
+    x_t, eps = cdiff.diffuse_from_t0(inp["translations"], tt, gen, return_eps=True)
+    O_t = odiff.diffuse_from_t0(inp["orientations"], gen, tt)
+    res_ctx = inp["res_context_emb"].clone().requires_grad_(True)
+    pair_ctx = inp["pair_context_emb"].clone().requires_grad_(True)
+    out = den(seq_t, x_t, O_t, res_ctx, pair_ctx, beta, gen, resm)
+    kl = nn.KLDivLoss(reduction="none")(out["seq_posterior"].log(), post)
+    mse = nn.MSELoss(reduction="none")(out["translations_eps"], eps)
+    ol = rmod.OrientationLoss(reduction="none")(out["orientations_t0"], inp["orientations"])
+    lm = gen & resm
+    denom = lm.sum()
+    l_seq = (kl * lm[..., None]).sum() / denom
+    l_x = (mse * lm[..., None]).sum() / denom
+    l_o = (ol * lm[..., None, None]).sum() / denom
+    (l_seq + l_x + l_o).backward()
+    mine = orc.denoiser(sd, seq_t, x_t, O_t, inp["res_context_emb"], inp["pair_context_emb"], beta, dims["NL"], dims["H"])
+    ml = orc.hotpath_losses(mine, post, eps, inp["orientations"], gen, resm)
+    check("bench-geometry loss seq", ml[0], l_seq.detach(), 2e-5)
+    check("bench-geometry loss translations", ml[1], l_x.detach(), 2e-5)
+    check("bench-geometry loss orientations", ml[2], l_o.detach(), 2e-5)
+    g = dict(
+        meta=np.array([B, K, seed, dims["D"], dims["C"], dims["NL"], dims["DS"], dims["H"], dims["PQ"], dims["PV"]]),
+        coord_sigma=np.array(6.0), t=npf(tt), beta=npf(beta), gen=npf(gen), resm=npf(resm), seq_t=npf(seq_t), post=npf(post),
+        x_t=npf(x_t), eps=npf(eps), O_t=npf(O_t), losses=np.array([float(l_seq), float(l_x), float(l_o)]),
+    )
+
+    def put_grad(name, gr):
+        flat = gr.detach().reshape(-1)
+        n = flat.numel()
+        stride = max(1, n // 512)
+        off = (7 * len(name)) % stride
+        g["sub/" + name] = npf(flat[off::stride][:512])
+        g["info/" + name] = np.array([n, stride, off, float(flat.double().norm()), float(flat.abs().max())])
+
+    put_grad("res_ctx", res_ctx.grad)
+    put_grad("pair_ctx", pair_ctx.grad)
+    for n_, p_ in den.named_parameters():
+        put_grad(n_, p_.grad)
+    np.savez_compressed(os.path.join(GOLD, "bench_grads.npz"), **g)
 
     # ---------------------------------------------------------------- encode_context through the real DiffAb
     print("encode_context (ResidueEmbedding + PairEmbedding), 4 flag combinations")

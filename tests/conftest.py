@@ -31,3 +31,17 @@ def maxrel(a, b):
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elemrel(a, b, floor=0.05):
+    """Element-wise relative error max |a-b|/|b| over the elements with |b| > floor * max|b| (north_star words its 1e-4 bar
+    per value; `maxrel` above is the tensor-global norm, this one checks that no significant element hides behind it).
+    The floor is where an element-wise 1e-4 is still above the reference's OWN fp32 noise: BASELINE.md section 2 measures
+    1e-7..1e-6 of the tensor maximum between its fp32 and fp64 runs (and between 1 and 8 threads), i.e. up to 1e-3 relative on an
+    element of 1e-3 max; at 5 % of the maximum that noise is 2e-5 of the element."""
+    import torch
+
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    big = b.abs() > floor * b.abs().max()
+    return float(((a - b).abs()[big] / b.abs()[big]).max())

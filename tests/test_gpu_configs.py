@@ -1,0 +1,137 @@
+"""BASELINE.json configs at their STATED sizes on one MI355X (the 8-GPU legs of configs 3 / 4 run their per-GPU share here):
+size-independent properties of the domain - finiteness, context preservation, orthonormal frames, determinism and bitwise
+invariance under sharding of the batch (what makes the N > 1 runs correct by construction) - on the MFMA path.
+
+  config 2: B = 256, K = 128, 100 reverse steps (T = 100)            -> test_config2_...
+  config 3: B = 2048 over 8 GPUs = 256 per GPU: config 2's shape; the shard test keys noise by the global patch id
+  config 4: training step, B = 1024 over 8 GPUs = 128 per GPU, NL = 6 -> test_config4_...
+  config 5: B = 512, K = 256, 200 reverse steps on the T = 200 schedule -> test_config5_...
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import diffab_oracle as orc
+from diffab_pytorch import _hip, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    lib = _hip.lib()
+    assert lib.diffab_device_ok() == 1
+    return lib
+
+
+def device_patches(B, K, dims, seed):
+    """Seeded synthetic patches of SURVEY 8(d)'s shapes, generated on the device (the 8.6 GB pair context of config 5 would take
+    minutes through the host generator): N(0,1) contexts, N(0,10^2) A translations, uniform rotations, one CDR-like segment
+    of 5..20 generated residues per patch."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    out = {
+        "res_context_emb": torch.randn(B, K, dims["D"], device="cuda", generator=g),
+        "pair_context_emb": torch.randn(B, K, K, dims["C"], device="cuda", generator=g),
+        "translations": 10 * torch.randn(B, K, 3, device="cuda", generator=g),
+        "seq_idx": torch.randint(0, 20, (B, K), device="cuda", generator=g),
+    }
+    q = torch.randn(B, K, 4, device="cuda", generator=g)
+    out["orientations"] = orc.uniform_rotation_from_normals(q.cpu()).cuda()
+    start = torch.randint(0, K - 20, (B, 1), device="cuda", generator=g)
+    length = torch.randint(5, 21, (B, 1), device="cuda", generator=g)
+    pos = torch.arange(K, device="cuda")[None]
+    out["generation_mask"] = (pos >= start) & (pos < start + length)
+    return out
+
+
+def bench_model(T_steps, NL=None):
+    from diffab_pytorch import DiffAb
+
+    d = dict(syn.BENCH_DIMS)
+    if NL is not None:
+        d["NL"] = NL
+    torch.manual_seed(0)
+    model = DiffAb(d["D"], d["C"], d["NL"], d["DS"], d["PQ"], d["PV"], d["H"], T=T_steps).cuda()
+    model.denoiser.load_state_dict(syn.denoiser_state_dict(d, seed=0, prefix=""))
+    return d, model
+
+
+def check_trajectory(model, inp, seed, shard, n_steps_expected):
+    """Full reverse trajectory + the properties listed in the module docstring; `shard` = (lo, hi) patches re-run alone."""
+    kw = lambda sl: dict(res_context_emb=inp["res_context_emb"][sl], pair_context_emb=inp["pair_context_emb"][sl],
+                         generation_mask=inp["generation_mask"][sl])
+    all_ = slice(None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    full = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], seed=seed, **kw(all_))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    B, K = inp["seq_idx"].shape
+    assert model.T == n_steps_expected
+    gm = inp["generation_mask"]
+    assert torch.isfinite(full["translations"]).all() and torch.isfinite(full["orientations"]).all()
+    assert torch.equal(full["translations"][~gm], inp["translations"][~gm])  # context residues are never touched
+    assert torch.equal(full["orientations"][~gm], inp["orientations"][~gm])
+    assert torch.equal(full["seq_idx"][~gm], inp["seq_idx"][~gm])
+    assert ((full["seq_idx"] >= 0) & (full["seq_idx"] < 21)).all()
+    assert not torch.equal(full["translations"][gm], inp["translations"][gm])
+    Og = full["orientations"][gm]
+    err = (Og.transpose(-1, -2) @ Og - torch.eye(3, device=Og.device)).abs().max()
+    assert err < 1e-3, float(err)  # every step re-derives O from exp maps: stays a rotation over the whole trajectory
+    lo, hi = shard
+    sl = slice(lo, hi)
+    part = model.sample(inp["seq_idx"][sl], inp["translations"][sl], inp["orientations"][sl], seed=seed, first_patch=lo, **kw(sl))
+    for k in full:  # bitwise: a rank that owns patches [lo, hi) of the global batch produces exactly these rows
+        assert torch.equal(part[k], full[k][sl]), k
+    again = model.sample(inp["seq_idx"][sl], inp["translations"][sl], inp["orientations"][sl], seed=seed, first_patch=lo, **kw(sl))
+    for k in full:
+        assert torch.equal(again[k], part[k]), k
+    other = model.sample(inp["seq_idx"][sl], inp["translations"][sl], inp["orientations"][sl], seed=seed + 1, first_patch=lo, **kw(sl))
+    assert not torch.equal(other["translations"], part["translations"])
+    return B * K * model.T / dt, dt
+
+
+def test_config2_b256_k128_100_steps(hip):
+    dims, model = bench_model(100)
+    inp = device_patches(256, 128, dims, seed=2)
+    rate, dt = check_trajectory(model, inp, seed=11, shard=(64, 72), n_steps_expected=100)
+    print(f"config 2: B=256 K=128 x 100 steps in {dt:.3f} s (incl. launch + sync) = {rate / 1e6:.2f} M residue-steps/s")
+
+
+def test_config5_b512_k256_200_steps_T200(hip):
+    dims, model = bench_model(200)
+    assert model.sched["beta"].numel() == 201 and model._reverse_so3().histograms.shape == (201, 8192)
+    inp = device_patches(512, 256, dims, seed=5)
+    rate, dt = check_trajectory(model, inp, seed=12, shard=(300, 304), n_steps_expected=200)
+    print(f"config 5: B=512 K=256 x 200 steps (T=200 schedule) in {dt:.3f} s = {rate / 1e6:.2f} M residue-steps/s")
+
+
+def test_config4_training_step_b128_nl6(hip):
+    """Per-GPU share of config 4 (1024 patches over 8 GPUs): noise + taped forward + 3 losses + HIP backward + Adam at
+    B = 128, K = 128, NL = 6.  Finite loss, a finite non-zero gradient on every denoiser parameter, parameters move."""
+    dims, model = bench_model(100)
+    inp = device_patches(128, 128, dims, seed=4)
+    batch = {"seq_idx": inp["seq_idx"], "xyz": inp["translations"], "orientations": inp["orientations"],
+             "generation_mask": inp["generation_mask"], "residue_mask": torch.ones_like(inp["generation_mask"]),
+             "res_context_emb": inp["res_context_emb"], "pair_context_emb": inp["pair_context_emb"]}
+    opt = model.configure_optimizers()
+    before = {n: p.detach().clone() for n, p in model.denoiser.named_parameters()}
+    times = []
+    for it in range(3):
+        torch.manual_seed(100 + it)
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = model.training_step(batch, it)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        assert torch.isfinite(loss)
+    for n, p in model.denoiser.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, n
+        assert not torch.equal(p.detach(), before[n]), n
+    print(f"config 4 (per-GPU share): B=128 K=128 NL=6 training step {1e3 * min(times):.2f} ms = "
+          f"{128 * 128 / min(times) / 1e6:.2f} M residue-steps/s")

@@ -54,6 +54,12 @@ def test_sequence_diffuser(golden):
     assert torch.allclose(post.sum(-1), torch.ones_like(post[..., 0]), atol=1e-6)
 
 
+def test_weighted_multinomial(golden):
+    g = golden("seqdiff")
+    p1 = torch.nn.functional.one_hot(T(g["seq0"]), 21)
+    assert np.array_equal(orc.weighted_multinomial(p1, T(g["wm_p2"]), T(g["wm_w1"]), T(g["wm_w2"])).numpy(), g["wm_out"])
+
+
 def test_coordinate_diffuser(golden):
     g = golden("coorddiff")
     s = orc.cosine_variance_schedule(100, s=0.01, beta_max=0.999)

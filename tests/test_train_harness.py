@@ -74,6 +74,18 @@ def test_patch_files_round_trip_and_distmat(tmp_path):
     with pytest.raises(KeyError, match="preprocess_pdb"):
         torch.save({"xyz": b["xyz"][:1]}, tmp_path / "bad.pt")
         T.load_patch(str(tmp_path / "bad.pt"))
+    # a patch exactly as the reference writes it has no CDR mask: refused loudly (an all-false mask would give 0/0 losses and
+    # zero gradients), as is a mask that selects nothing; --cdr-mask-key names another key
+    ref_fmt = torch.load(tmp_path / "patch0.pt")
+    mask = ref_fmt.pop("generation_mask")
+    torch.save(ref_fmt, tmp_path / "nomask.pt")
+    with pytest.raises(KeyError, match="generation_mask"):
+        T.load_patch(str(tmp_path / "nomask.pt"))
+    torch.save(dict(ref_fmt, h3=mask), tmp_path / "named.pt")
+    assert torch.equal(T.load_patch(str(tmp_path / "named.pt"), "h3")["generation_mask"], mask.bool())
+    torch.save(dict(ref_fmt, generation_mask=torch.zeros_like(mask)), tmp_path / "empty.pt")
+    with pytest.raises(ValueError, match="no valid residue"):
+        T.load_patch(str(tmp_path / "empty.pt"))
 
 
 def test_checkpoint_layout_round_trip(tmp_path):

@@ -40,5 +40,9 @@ print(f"B={B} K={K}: {nwg} work-groups; per-wave lifetime mean {tot.mean():.0f} 
 for k, n in enumerate(names):
     dlt = s[..., k + 1] - s[..., k]
     print(f"  {n:42s} mean {dlt.mean():9.0f}  min {dlt.min():9.0f}  max {dlt.max():9.0f}  ({100 * dlt.mean() / tot.mean():.1f} %)")
+if (s[..., 6] > 0).all():
+    for nm, a, b_ in (("  P1 start -> end of key tile 0", 0, 6), ("  P1 key tiles 1..3", 6, 7), ("  P1 key tiles 4..7", 7, 1)):
+        dlt = s[..., b_] - s[..., a]
+        print(f"{nm:44s} mean {dlt.mean():9.0f}  min {dlt.min():9.0f}  max {dlt.max():9.0f}")
 span = s[..., 5].max() - s[..., 0].min()
 print(f"  kernel span (first stamp to last stamp): {span:.0f} cycles; 100 MHz-based? memtime ticks are shader cycles")
