@@ -16,6 +16,7 @@
 //    row tiles of a patch, which the blockIdx map places on one XCD so the re-reads are L2 hits.
 //
 // Reference: InvariantPointAttentionLayer.forward, diffab_pytorch.py:389-465.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -1140,6 +1141,16 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   if (attn_mode == 1 && attention_split_supported(d)) {
     float* SP = feat + static_cast<size_t>(rows) * AF + 128;
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
+    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+  }
+  // K = 64 / 128: the key-tile pipeline of attention_flash.hip (DIFFAB_ATTN_FLASH=0 selects the three-phase kernel below, kept for
+  // every other K and for A/B timing)
+  static const bool use_flash = [] {
+    const char* v = getenv("DIFFAB_ATTN_FLASH");
+    return v == nullptr || atoi(v) != 0;
+  }();
+  if (attn_mode == 0 && use_flash && attention_flash_supported(d)) {
+    if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st)) return rc;
     return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
   }
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
