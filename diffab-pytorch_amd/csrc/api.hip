@@ -86,7 +86,7 @@ static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weigh
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
-    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : 0),
+    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : ((flags & DIFFAB_FLAG_FLASH_ATTENTION) ? 3 : 0)),
                           sp_keep, d2_keep);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }

@@ -1143,13 +1143,15 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
     return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
   }
-  // K = 64 / 128: the key-tile pipeline of attention_flash.hip (DIFFAB_ATTN_FLASH=0 selects the three-phase kernel below, kept for
-  // every other K and for A/B timing)
-  static const bool use_flash = [] {
+  // DIFFAB_FLAG_FLASH_ATTENTION (K = 64 / 128): the key-tile pipeline of attention_flash.hip - no logits image in LDS, the pair stream in
+  // flight from the first instruction.  Parity-tested on the same goldens; measured 0.380 ms against 0.357 ms for the three-phase
+  // kernel below at B = 256 (both leave the matrix pipe idle > 50 % of the time: DESIGN section 4.1), hence opt-in.
+  // DIFFAB_ATTN_FLASH=1 in the environment selects it for every default-mode call (A/B timing with bench.py).
+  static const bool env_flash = [] {
     const char* v = getenv("DIFFAB_ATTN_FLASH");
-    return v == nullptr || atoi(v) != 0;
+    return v != nullptr && atoi(v) != 0;
   }();
-  if (attn_mode == 0 && use_flash && attention_flash_supported(d)) {
+  if ((attn_mode == 3 || (attn_mode == 0 && env_flash)) && attention_flash_supported(d)) {
     if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st)) return rc;
     return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
   }

@@ -44,6 +44,9 @@ extern "C" {
 #define DIFFAB_FLAG_SPLIT_ATTENTION 2u /* K = 64 / 128: the attention of each layer as three launches (logits | pair stream | P x V)
                                           instead of the fused kernel; same results to rounding, see csrc/attention_split.hip */
 
+#define DIFFAB_FLAG_FLASH_ATTENTION 8u /* K = 64 / 128: the attention of each layer as a key-tile pipeline with an online softmax
+                                          (csrc/attention_flash.hip) instead of the three-phase kernel; same results to rounding */
+
 /* Model and batch geometry.  Reference ctor: diffab_pytorch.py:629-647. */
 typedef struct {
   int32_t B;  /* patches in this call */

@@ -35,14 +35,12 @@ lib.diffab_debug_set_attn_stamps(None)
 s = stamps.view(nwg, 8, 8).cpu().double()
 if os.environ.get("DIFFAB_ATTN_FLASH", "1") != "0" and K in (64, 128):
     # key-tile pipeline (attention_flash.hip): stamps 0 start | 1 prologue barrier | 2 step 0 | 3 step 1 | 4 step 4 | 6 step NT | 7 step NT+1 | 5 end
-    for role, sl in (("stream waves 0-3", slice(0, 4)), ("head waves 4-7", slice(4, 8))):
-        w = s[:, sl, :]
-        tot = w[..., 5] - w[..., 0]
-        print(f"{role}: lifetime mean {tot.mean():.0f} (min {tot.min():.0f}, max {tot.max():.0f})")
-        for nm, a, b_, div in (("prologue (to first barrier)", 0, 1, 1), ("step 0", 1, 2, 1), ("step 1", 2, 3, 1), ("steps 2..4 (per step)", 3, 4, 3),
-                               (f"steps 5..NT (per step)", 4, 6, K // 16 - 4), ("step NT+1", 6, 7, 1), ("epilogue", 7, 5, 1)):
-            dlt = (w[..., b_] - w[..., a]) / div
-            print(f"  {nm:32s} mean {dlt.mean():9.0f}  min {dlt.min():9.0f}  max {dlt.max():9.0f}")
+    tot = s[..., 5] - s[..., 0]
+    print(f"B={B} K={K}: {nwg} work-groups; per-wave lifetime mean {tot.mean():.0f} (min {tot.min():.0f}, max {tot.max():.0f})")
+    for nm, a, b_, div in (("prologue (to first barrier)", 0, 1, 1), ("step 0", 1, 2, 1), ("step 1", 2, 3, 1), ("steps 2..4 (per step)", 3, 4, 3),
+                           (f"steps 5..NT (per step)", 4, 6, K // 16 - 4), ("step NT+1", 6, 7, 1), ("epilogue", 7, 5, 1)):
+        dlt = (s[..., b_] - s[..., a]) / div
+        print(f"  {nm:32s} mean {dlt.mean():9.0f}  min {dlt.min():9.0f}  max {dlt.max():9.0f}")
     sys.exit(0)
 names = ["phase1 (S: q.k MFMA + point VALU)", "phase2 prologue + barrier", "phase2 (bias, softmax, o_e)", "phase3 prologue + barrier",
          "phase3 (o_s, o_p, epilogue)"]
