@@ -144,6 +144,110 @@ __global__ void pair_mask_kernel(float* __restrict__ out, const float* __restric
   out[gid] *= amask[(b * K + i) * A + kCA] * amask[(b * K + j) * A + kCA];
 }
 
+// ------------------------------------------------------------------ backward (training through encode_context)
+// The reference cannot back-propagate through PairEmbedding: `distmat = torch.exp(...)` is multiplied IN PLACE by the structure
+// mask after the distance MLP has saved it (diffab_pytorch.py:295-301), which autograd rejects.  The fix-forward is an
+// out-of-place product and nothing else (its result is unused, so the forward is unchanged); gradients are pinned against autograd
+// of the oracle restatement, and ResidueEmbedding's against the real reference.  Nothing is taped: the backward recomputes the
+// forward of its chunk (the row buffers of a K = 128 patch are 27 MB; keeping them for a batch would cost more than the recompute).
+
+// d aa_emb[s] += dfeat[:, 0:D]; d chain_emb[chain] += dfeat_chain (padding_idx = 0 takes no gradient, nn.Embedding(10, D, padding_idx=0) :65)
+__global__ void residue_embed_bwd_kernel(const float* __restrict__ d_aa, const float* __restrict__ d_ch, const int64_t* __restrict__ seq,
+                                         const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ chain, int D, int64_t rows,
+                                         float* __restrict__ g_aa, float* __restrict__ g_chain) {
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  int64_t s = seq[r];
+  if (seq_m && !seq_m[r]) s = kUNK;
+  const int64_t c = chain[r];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    atomicAdd(g_aa + s * D + d, d_aa[r * D + d]);
+    if (c != 0) atomicAdd(g_chain + c * D + d, d_ch[r * D + d]);
+  }
+}
+
+// dO[row][:] = d_out[row][:] * atom_mask_i[CA] * atom_mask_j[CA]   (backward of pair_mask_kernel)
+__global__ void pair_mask_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ amask, int K, int A, int C, int64_t row0,
+                                     int64_t rows, float* __restrict__ dO) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (gid >= rows * C) return;
+  const int64_t row = row0 + gid / C;
+  const int64_t b = row / (static_cast<int64_t>(K) * K);
+  const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+  dO[gid] = d_out[row * C + gid % C] * (amask[(b * K + i) * A + kCA] * amask[(b * K + j) * A + kCA]);
+}
+
+// backward of pair_cat_kernel: d aa_pair_emb[si*21+sj] += dcat[:, 0:C]; d relpos_emb[rel] += dcat[:, C:2C] * same;
+// ddf[row][c] = dcat[:, 2C + c] * (df > 0)   (distance_embedding ends with a ReLU, :212-217); the dihedral columns carry no parameter
+__global__ void pair_cat_bwd_kernel(const float* __restrict__ dcat, int ldc, const float* __restrict__ df, const int64_t* __restrict__ seq,
+                                    const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid, int resid_bstride,
+                                    const int64_t* __restrict__ chain, int K, int C, int max_dist, int64_t row0,
+                                    float* __restrict__ g_pair, float* __restrict__ g_rel, float* __restrict__ ddf) {
+  const int64_t lr = blockIdx.x, row = row0 + lr;
+  const int64_t b = row / (static_cast<int64_t>(K) * K);
+  const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+  const int64_t ri = b * K + i, rj = b * K + j;
+  const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+  int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
+  rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
+  const float same = static_cast<float>(chain[ri] * chain[rj]);
+  const float* g = dcat + lr * ldc;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    atomicAdd(g_pair + (si * kAA + sj) * C + c, g[c]);
+    if (same != 0.0f) atomicAdd(g_rel + (rel + max_dist) * C + c, g[C + c] * same);
+    ddf[lr * C + c] = df[lr * C + c] > 0.0f ? g[2 * C + c] : 0.0f;
+  }
+}
+
+// d softplus(coef)[si*21+sj][p] += ddin[row][p] * d din / d c,  din = exp(-c d^2) mask  =>  d din / d c = -d^2 din
+__global__ void pair_dist_bwd_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const float* __restrict__ distmat,
+                                     const float* __restrict__ xyz, const float* __restrict__ din, const float* __restrict__ ddin, int K,
+                                     int A, int64_t row0, int64_t nrows, int ld, float* __restrict__ g_coef_sp) {
+  const int AA2 = A * A;
+  constexpr int RPB = 8;
+  for (int rr = 0; rr < RPB; ++rr) {
+    const int64_t lr = static_cast<int64_t>(blockIdx.x) * RPB + rr;
+    if (lr >= nrows) return;
+    const int64_t row = row0 + lr;
+    const int64_t b = row / (static_cast<int64_t>(K) * K);
+    const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+    const int64_t ri = b * K + i, rj = b * K + j;
+    const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+    float* grow = g_coef_sp + (si * kAA + sj) * AA2;
+    for (int p = threadIdx.x; p < AA2; p += blockDim.x) {
+      const float v = din[lr * ld + p];
+      if (v == 0.0f) continue;  // masked atom pair (or underflow): no gradient
+      const int a1 = p / A, a2 = p % A;
+      float d;
+      if (distmat) {
+        d = distmat[row * AA2 + p];
+      } else {
+        const float* pa = xyz + (ri * A + a1) * 3;
+        const float* pb = xyz + (rj * A + a2) * 3;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        d = sqrtf((dx * dx + dy * dy) + dz * dz);
+      }
+      atomicAdd(grow + p, ddin[lr * ld + p] * (-(d * d) * v));
+    }
+  }
+}
+
+// g_coef[n] += g_coef_sp[n] * softplus'(coef[n])   (sigmoid; 1 beyond F.softplus's threshold of 20)
+__global__ void softplus_bwd_kernel(const float* __restrict__ coefw, const float* __restrict__ g_sp, int n, float* __restrict__ g_coef) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const float x = coefw[gid];
+  g_coef[gid] += g_sp[gid] * (x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)));
+}
+
+// g[r][0:n] += gpad[r][0:n]   (weight gradients of the padded first layers back to the parameter's own row stride)
+__global__ void unpad_add_kernel(const float* __restrict__ gpad, int ld, int n, int rows, float* __restrict__ g) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * n) return;
+  const int r = gid / n, c = gid % n;
+  g[gid] += gpad[r * ld + c];
+}
+
 }  // namespace diffab
 
 using namespace diffab;
@@ -270,6 +374,168 @@ int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
   DIFFAB_REQUIRE(distmat != nullptr, DIFFAB_ERR_ARG, "pair_embedding_fwd: distmat is null");
   return pair_embedding_impl(d, w, seq_idx, distmat, nullptr, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
                              sequence_context_mask, out, workspace, workspace_bytes, stream);
+}
+
+// ---- backward of ResidueEmbedding: parameter gradients accumulate (+=) into `g` (same layout as the weights; caller zero-fills)
+size_t diffab_residue_embedding_bwd_workspace_bytes(const diffab_ctx_dims* d) {
+  if (check_ctx(d, "residue_embedding_bwd_workspace_bytes")) return 0;
+  const size_t rows = static_cast<size_t>(d->B) * d->K, Din = 2 * d->D + kAA * d->A * 3 + 39;
+  // forward row buffers (feat, h1, h2, h3) + dh3, dh2 (D each), dh1 (2D), d_aa, d_chain (D each)
+  return (rows * (Din + 2 * d->D + d->D + d->D) + rows * (2 * d->D + 2 * d->D + 2 * d->D) + 64) * sizeof(float);
+}
+
+int diffab_residue_embedding_bwd(const diffab_ctx_dims* d, const diffab_residue_emb_weights* w, const diffab_residue_emb_weights* g,
+                                 const int64_t* seq_idx, const float* xyz, const float* orientations, const float* dihedrals,
+                                 const int64_t* chain_idx, const float* atom_mask, const uint8_t* structure_context_mask,
+                                 const uint8_t* sequence_context_mask, const float* d_out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (int rc = check_ctx(d, "residue_embedding_bwd")) return rc;
+  DIFFAB_REQUIRE(w && w->aa_emb && w->chain_emb && w->w0 && w->b0 && w->w2 && w->b2 && w->w4 && w->b4 && w->w6 && w->b6, DIFFAB_ERR_ARG,
+                 "residue_embedding_bwd: null weight");
+  DIFFAB_REQUIRE(g && g->aa_emb && g->chain_emb && g->w0 && g->b0 && g->w2 && g->b2 && g->w4 && g->b4 && g->w6 && g->b6, DIFFAB_ERR_ARG,
+                 "residue_embedding_bwd: null gradient buffer");
+  DIFFAB_REQUIRE(seq_idx && xyz && orientations && dihedrals && chain_idx && atom_mask && d_out && workspace, DIFFAB_ERR_ARG,
+                 "residue_embedding_bwd: null pointer");
+  DIFFAB_REQUIRE(workspace_bytes >= diffab_residue_embedding_bwd_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "residue_embedding_bwd: workspace");
+  hipStream_t st = as_stream(stream);
+  const int rows = d->B * d->K, D = d->D, Din = 2 * D + kAA * d->A * 3 + 39;
+  float* feat = static_cast<float*>(workspace);
+  float* h1 = feat + static_cast<size_t>(rows) * Din;
+  float* h2 = h1 + static_cast<size_t>(rows) * 2 * D;
+  float* h3 = h2 + static_cast<size_t>(rows) * D;
+  float* dh3 = h3 + static_cast<size_t>(rows) * D;
+  float* dh2 = dh3 + static_cast<size_t>(rows) * D;
+  float* dh1 = dh2 + static_cast<size_t>(rows) * D;
+  float* d_aa = dh1 + static_cast<size_t>(rows) * 2 * D;
+  float* d_ch = d_aa + static_cast<size_t>(rows) * D;
+  auto mut = [](const float* p) { return const_cast<float*>(p); };
+  // forward recompute (same launches as diffab_residue_embedding_fwd up to the last hidden layer)
+  hipLaunchKernelGGL(residue_feat_kernel, dim3(rows), dim3(128), 0, st, seq_idx, xyz, orientations, dihedrals, chain_idx, atom_mask,
+                     structure_context_mask, sequence_context_mask, w->aa_emb, w->chain_emb, d->K, d->A, D, feat);
+  DIFFAB_LAUNCH_CHECK();
+  if (int rc = launch_linear(feat, Din, w->w0, w->b0, h1, 2 * D, rows, 2 * D, Din, true, st)) return rc;
+  if (int rc = launch_linear(h1, 2 * D, w->w2, w->b2, h2, D, rows, D, 2 * D, true, st)) return rc;
+  if (int rc = launch_linear(h2, D, w->w4, w->b4, h3, D, rows, D, D, true, st)) return rc;
+  // backward chain
+  if (int rc = bwd_linear(d_out, D, h3, D, w->w6, mut(g->w6), mut(g->b6), dh3, D, rows, D, D, false, st)) return rc;
+  if (int rc = bwd_relu_mask(dh3, h3, static_cast<int64_t>(rows) * D, st)) return rc;
+  if (int rc = bwd_linear(dh3, D, h2, D, w->w4, mut(g->w4), mut(g->b4), dh2, D, rows, D, D, false, st)) return rc;
+  if (int rc = bwd_relu_mask(dh2, h2, static_cast<int64_t>(rows) * D, st)) return rc;
+  if (int rc = bwd_linear(dh2, D, h1, 2 * D, w->w2, mut(g->w2), mut(g->b2), dh1, 2 * D, rows, D, 2 * D, false, st)) return rc;
+  if (int rc = bwd_relu_mask(dh1, h1, static_cast<int64_t>(rows) * 2 * D, st)) return rc;
+  if (int rc = bwd_linear(dh1, 2 * D, feat, Din, w->w0, mut(g->w0), mut(g->b0), nullptr, 0, rows, 2 * D, Din, false, st)) return rc;
+  // only the two embedding slices of d feat are needed: columns [0, D) and [Din - D, Din) of dh1 W0
+  if (int rc = bwd_gemm_nn(dh1, 2 * D, w->w0, Din, d_aa, D, rows, D, 2 * D, false, st)) return rc;
+  if (int rc = bwd_gemm_nn(dh1, 2 * D, w->w0 + (Din - D), Din, d_ch, D, rows, D, 2 * D, false, st)) return rc;
+  hipLaunchKernelGGL(residue_embed_bwd_kernel, dim3(rows), dim3(128), 0, st, d_aa, d_ch, seq_idx, sequence_context_mask, chain_idx, D,
+                     static_cast<int64_t>(rows), mut(g->aa_emb), mut(g->chain_emb));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// ---- backward of PairEmbedding
+static int pair_bwd_chunk_patches(const diffab_ctx_dims* d) {
+  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (2 * round4(d->A * d->A) + 9 * d->C + 2 * round4(3 * d->C + 18)) * sizeof(float);
+  const size_t budget = static_cast<size_t>(1024) << 20;
+  const size_t n = budget / per_patch;
+  return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
+}
+
+size_t diffab_pair_embedding_bwd_workspace_bytes(const diffab_ctx_dims* d) {
+  if (check_ctx(d, "pair_embedding_bwd_workspace_bytes")) return 0;
+  const size_t rows = static_cast<size_t>(pair_bwd_chunk_patches(d)) * d->K * d->K;
+  const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
+  const size_t wpad = 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + 2 * static_cast<size_t>(kAA) * kAA * d->A * d->A;
+  return (rows * (2 * AA2p + 9 * d->C + 2 * Wp) + wpad + 64) * sizeof(float);
+}
+
+int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
+                              const int64_t* seq_idx, const float* distmat, const float* xyz, const float* pairwise_dihedrals,
+                              const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                              const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (int rc = check_ctx(d, "pair_embedding_bwd")) return rc;
+  DIFFAB_REQUIRE(w && w->aa_pair_emb && w->relpos_emb && w->pair2distcoef && w->dw0 && w->db0 && w->dw2 && w->db2 && w->mw0 && w->mb0 &&
+                     w->mw2 && w->mb2 && w->mw4 && w->mb4,
+                 DIFFAB_ERR_ARG, "pair_embedding_bwd: null weight");
+  DIFFAB_REQUIRE(g && g->aa_pair_emb && g->relpos_emb && g->pair2distcoef && g->dw0 && g->db0 && g->dw2 && g->db2 && g->mw0 && g->mb0 &&
+                     g->mw2 && g->mb2 && g->mw4 && g->mb4,
+                 DIFFAB_ERR_ARG, "pair_embedding_bwd: null gradient buffer");
+  DIFFAB_REQUIRE(seq_idx && (distmat || xyz) && pairwise_dihedrals && residue_idx && chain_idx && atom_mask && d_out && workspace,
+                 DIFFAB_ERR_ARG, "pair_embedding_bwd: null pointer");
+  DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_bwd_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_bwd: workspace");
+  hipStream_t st = as_stream(stream);
+  const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18, AA2p = round4(AA2), Wp = round4(W);
+  const int bc = pair_bwd_chunk_patches(d);
+  const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
+  const size_t R = static_cast<size_t>(bc) * per_patch;
+  float* din = static_cast<float*>(workspace);  // forward: [R][AA2p]
+  float* h1 = din + R * AA2p;                   // [R][C]
+  float* df = h1 + R * C;
+  float* cat = df + R * C;                      // [R][Wp]
+  float* m1 = cat + R * Wp;
+  float* m2 = m1 + R * C;
+  float* dA = m2 + R * C;                       // backward ping-pong [R][C] x 2
+  float* dB = dA + R * C;
+  float* dcat = dB + R * C;                     // [R][Wp]
+  float* ddf = dcat + R * Wp;                   // [R][C]
+  float* dh1 = ddf + R * C;                     // [R][C]
+  float* ddin = dh1 + R * C;                    // [R][AA2p]
+  float* dw0p = ddin + R * AA2p;                // padded first-layer weights and their gradients
+  float* mw0p = dw0p + static_cast<size_t>(C) * AA2p;
+  float* gdw0p = mw0p + static_cast<size_t>(C) * Wp;
+  float* gmw0p = gdw0p + static_cast<size_t>(C) * AA2p;
+  float* coef_sp = gmw0p + static_cast<size_t>(C) * Wp;  // [441][AA2]
+  float* g_sp = coef_sp + static_cast<size_t>(kAA) * kAA * AA2;
+  auto mut = [](const float* p) { return const_cast<float*>(p); };
+  hipLaunchKernelGGL(softplus_table_kernel, dim3((kAA * kAA * AA2 + 255) / 256), dim3(256), 0, st, w->pair2distcoef, kAA * kAA * AA2, coef_sp);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((C * AA2p + 255) / 256), dim3(256), 0, st, w->dw0, AA2, C, dw0p, AA2p);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((C * Wp + 255) / 256), dim3(256), 0, st, w->mw0, W, C, mw0p, Wp);
+  DIFFAB_LAUNCH_CHECK();
+  DIFFAB_HIP_CHECK(hipMemsetAsync(gdw0p, 0, sizeof(float) * (static_cast<size_t>(C) * (AA2p + Wp) + 0), st));  // gdw0p and gmw0p are adjacent
+  DIFFAB_HIP_CHECK(hipMemsetAsync(g_sp, 0, sizeof(float) * static_cast<size_t>(kAA) * kAA * AA2, st));
+  for (int b0 = 0; b0 < d->B; b0 += bc) {
+    const int nb = (d->B - b0) < bc ? (d->B - b0) : bc;
+    const int64_t row0 = b0 * per_patch, nrows = nb * per_patch;
+    const int rows = static_cast<int>(nrows);
+    // ---- forward recompute of this chunk (the launches of pair_embedding_impl, last layer excepted)
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq_idx, sequence_context_mask, distmat, xyz,
+                       atom_mask, coef_sp, d->K, d->A, row0, nrows, din, AA2p);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_linear(din, AA2p, dw0p, w->db0, h1, C, rows, C, AA2p, true, st)) return rc;
+    if (int rc = launch_linear(h1, C, w->dw2, w->db2, df, C, rows, C, C, true, st)) return rc;
+    hipLaunchKernelGGL(pair_cat_kernel, dim3(static_cast<unsigned>(nrows)), dim3(64), 0, st, seq_idx, sequence_context_mask, residue_idx,
+                       residue_idx_batch_stride, chain_idx, pairwise_dihedrals, df, w->aa_pair_emb, w->relpos_emb, d->K, C, d->max_dist,
+                       row0, cat, Wp);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_linear(cat, Wp, mw0p, w->mb0, m1, C, rows, C, Wp, true, st)) return rc;
+    if (int rc = launch_linear(m1, C, w->mw2, w->mb2, m2, C, rows, C, C, true, st)) return rc;
+    // ---- backward
+    hipLaunchKernelGGL(pair_mask_bwd_kernel, dim3(static_cast<unsigned>((nrows * C + 255) / 256)), dim3(256), 0, st, d_out, atom_mask, d->K,
+                       d->A, C, row0, nrows, dA);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = bwd_linear(dA, C, m2, C, w->mw4, mut(g->mw4), mut(g->mb4), dB, C, rows, C, C, false, st)) return rc;
+    if (int rc = bwd_relu_mask(dB, m2, nrows * C, st)) return rc;
+    if (int rc = bwd_linear(dB, C, m1, C, w->mw2, mut(g->mw2), mut(g->mb2), dA, C, rows, C, C, false, st)) return rc;
+    if (int rc = bwd_relu_mask(dA, m1, nrows * C, st)) return rc;
+    if (int rc = bwd_linear(dA, C, cat, Wp, mw0p, gmw0p, mut(g->mb0), dcat, Wp, rows, C, Wp, false, st)) return rc;
+    hipLaunchKernelGGL(pair_cat_bwd_kernel, dim3(static_cast<unsigned>(nrows)), dim3(64), 0, st, dcat, Wp, df, seq_idx, sequence_context_mask,
+                       residue_idx, residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, mut(g->aa_pair_emb),
+                       mut(g->relpos_emb), ddf);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = bwd_linear(ddf, C, h1, C, w->dw2, mut(g->dw2), mut(g->db2), dh1, C, rows, C, C, false, st)) return rc;
+    if (int rc = bwd_relu_mask(dh1, h1, nrows * C, st)) return rc;
+    if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
+    hipLaunchKernelGGL(pair_dist_bwd_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq_idx, sequence_context_mask,
+                       distmat, xyz, din, ddin, d->K, d->A, row0, nrows, AA2p, g_sp);
+    DIFFAB_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(unpad_add_kernel, dim3((C * AA2 + 255) / 256), dim3(256), 0, st, gdw0p, AA2p, AA2, C, mut(g->dw0));
+  hipLaunchKernelGGL(unpad_add_kernel, dim3((C * W + 255) / 256), dim3(256), 0, st, gmw0p, Wp, W, C, mut(g->mw0));
+  hipLaunchKernelGGL(softplus_bwd_kernel, dim3((kAA * kAA * AA2 + 255) / 256), dim3(256), 0, st, w->pair2distcoef, g_sp, kAA * kAA * AA2,
+                     mut(g->pair2distcoef));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
 }
 
 int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* xyz,

@@ -288,6 +288,16 @@ static int linear_bwd(const float* dY, int ldy, const float* X, int ldx, const f
   return DIFFAB_OK;
 }
 
+// shared with context_kernels.hip (the encode_context backward is the same chain of linear / ReLU backward steps)
+int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M, int N,
+               int Kd, bool acc_dx, hipStream_t st) {
+  return linear_bwd(dY, ldy, X, ldx, W, dW, db, dX, lddx, M, N, Kd, acc_dx, st);
+}
+int bwd_relu_mask(float* dY, const float* act, int64_t n, hipStream_t st) { return relu_mask(dY, act, n, st); }
+int bwd_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st) {
+  return gemm_nn(A, lda, B, ldb, C, ldc, M, N, K, acc, st);
+}
+
 // ------------------------------------------------------------------ loss backward (per residue)
 // upstream scalars g = (g_seq, g_x, g_o); N = #masked residues (device scalar computed here by one block)
 __global__ void count_mask_kernel(const uint8_t* __restrict__ gm, const uint8_t* __restrict__ rm, int64_t n, float* __restrict__ out) {

@@ -73,6 +73,12 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
                    const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
                    const uint8_t* gm, const uint8_t* rm, const float* upstream3, float* d_res_ctx, float* d_pair_ctx, float* ws,
                    hipStream_t st);
+// Y = act(X W^T + b) backward: dW += dY^T X (W is N x Kd, row-major), db += colsum dY (nullable), dX (+)= dY W (nullable).
+// dY must already carry the activation mask (bwd_relu_mask: dY *= act > 0, in place).  bwd_gemm_nn: C (+)= A[M,K] B[K,N].
+int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M, int N,
+               int Kd, bool acc_dx, hipStream_t st);
+int bwd_relu_mask(float* dY, const float* act, int64_t n, hipStream_t st);
+int bwd_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st);
 int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const float* te, const float* pO, const float* tO, const uint8_t* gm,
                       const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st);
 

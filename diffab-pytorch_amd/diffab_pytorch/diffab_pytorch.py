@@ -8,7 +8,9 @@ reference loads unchanged and callers need no edits.  The ``nn.Module`` objects 
 parameters; every forward is one C-ABI call into the HIP library - there is no ATen fallback.
 
 The context encoders ResidueEmbedding / PairEmbedding (the step just before the hot path) also run
-on HIP (forward only: the reference itself cannot back-propagate through PairEmbedding, diffab_pytorch.py:295-301).
+on HIP, forward and backward (the reference itself cannot back-propagate through PairEmbedding: in-place product at
+diffab_pytorch.py:295-301; the backward here is the gradient of the same forward with that product out of place), so
+DiffAb.training_step on a reference batch dict trains all 2 538 468 parameters.
 """
 from __future__ import annotations
 
@@ -272,9 +274,100 @@ def _opt_mask(m):
     return None if m is None else _hip.dev_mask(m)
 
 
+_RES_KEYS = ("amino_acid_type_embedding.weight", "chain_embedding.weight", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
+             "mlp.4.weight", "mlp.4.bias", "mlp.6.weight", "mlp.6.bias")
+_PAIR_KEYS = ("aa_pair_type_embedding.weight", "relpos_embedding.weight", "pair2distcoef.weight", "distance_embedding.0.weight",
+              "distance_embedding.0.bias", "distance_embedding.2.weight", "distance_embedding.2.bias", "mlp.0.weight", "mlp.0.bias",
+              "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias")
+
+
+def _zero_grads_like(params):
+    """One zero-filled flat buffer with a (256-byte aligned) view per parameter: the HIP backward accumulates into it."""
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + 63) // 64 * 64
+    flat = torch.zeros(total, dtype=torch.float32, device=_hip.device())
+    return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+
+
+class _ResidueEmbeddingFn(torch.autograd.Function):
+    """ResidueEmbedding forward / backward as two C-ABI calls (the backward recomputes the forward: nothing is taped)."""
+
+    @staticmethod
+    def forward(ctx, dims, seq, x, O, dh, ch, am, sm, qm, *params):
+        lib = _hip.lib()
+        ts = [_hip.dev_f32(p) for p in params]
+        w = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in ts])
+        ws = _hip.workspace(lib.diffab_residue_embedding_workspace_bytes(C.byref(dims)))
+        out = torch.empty(dims.B, dims.K, dims.D, dtype=torch.float32, device=seq.device)
+        _hip.check(lib.diffab_residue_embedding_fwd(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(dh),
+                                                    _hip.ptr(ch), _hip.ptr(am), _hip.ptr(sm), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws),
+                                                    ws.numel(), _hip.stream_ptr()), "diffab_residue_embedding_fwd")
+        ctx.dims, ctx.masks = dims, (sm, qm)
+        ctx.p_devs = [p.device for p in params]
+        ctx.save_for_backward(seq, x, O, dh, ch, am, *ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _hip.lib()
+        seq, x, O, dh, ch, am = ctx.saved_tensors[:6]
+        ts = list(ctx.saved_tensors[6:])
+        sm, qm = ctx.masks
+        dims = ctx.dims
+        grads = _zero_grads_like(ts)
+        w = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in ts])
+        g = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in grads])
+        ws = _hip.workspace(lib.diffab_residue_embedding_bwd_workspace_bytes(C.byref(dims)))
+        do = _hip.dev_f32(d_out)
+        _hip.check(lib.diffab_residue_embedding_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O),
+                                                    _hip.ptr(dh), _hip.ptr(ch), _hip.ptr(am), _hip.ptr(sm), _hip.ptr(qm), _hip.ptr(do),
+                                                    _hip.ptr(ws), ws.numel(), _hip.stream_ptr()), "diffab_residue_embedding_bwd")
+        return (None,) * 9 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
+
+
+class _PairEmbeddingFn(torch.autograd.Function):
+    """PairEmbedding forward / backward as two C-ABI calls.  The backward is the gradient of the reference's forward with its
+    in-place mask product (diffab_pytorch.py:295-301, which makes the reference's own autograd fail) taken out of place."""
+
+    @staticmethod
+    def forward(ctx, dims, from_xyz, seq, dm, dh, ri, ri_stride, ch, am, qm, *params):
+        lib = _hip.lib()
+        ts = [_hip.dev_f32(p) for p in params]
+        w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
+        ws = _hip.workspace(lib.diffab_pair_embedding_workspace_bytes(C.byref(dims)))
+        out = torch.empty(dims.B, dims.K, dims.K, dims.C, dtype=torch.float32, device=seq.device)
+        entry = lib.diffab_pair_embedding_xyz_fwd if from_xyz else lib.diffab_pair_embedding_fwd
+        _hip.check(entry(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri), ri_stride, _hip.ptr(ch),
+                         _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
+                   "diffab_pair_embedding_xyz_fwd" if from_xyz else "diffab_pair_embedding_fwd")
+        ctx.dims, ctx.from_xyz, ctx.ri_stride, ctx.qm = dims, from_xyz, ri_stride, qm
+        ctx.p_devs = [p.device for p in params]
+        ctx.save_for_backward(seq, dm, dh, ri, ch, am, *ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _hip.lib()
+        seq, dm, dh, ri, ch, am = ctx.saved_tensors[:6]
+        ts = list(ctx.saved_tensors[6:])
+        dims = ctx.dims
+        grads = _zero_grads_like(ts)
+        w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
+        g = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in grads])
+        ws = _hip.workspace(lib.diffab_pair_embedding_bwd_workspace_bytes(C.byref(dims)))
+        do = _hip.dev_f32(d_out)
+        _hip.check(lib.diffab_pair_embedding_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(seq), _hip.ptr(None if ctx.from_xyz else dm),
+                                                 _hip.ptr(dm if ctx.from_xyz else None), _hip.ptr(dh), _hip.ptr(ri), ctx.ri_stride, _hip.ptr(ch),
+                                                 _hip.ptr(am), _hip.ptr(ctx.qm), _hip.ptr(do), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
+                   "diffab_pair_embedding_bwd")
+        return (None,) * 10 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
+
+
 class ResidueEmbedding(nn.Module):
     """Per-residue context embedding (reference diffab_pytorch.py:57-183): same parameters, creation order and forward
-    signature; the forward is one C-ABI call (feature gather kernel + four MFMA linears)."""
+    signature; forward and backward are one C-ABI call each (feature gather kernel + four MFMA linears; the backward recomputes them)."""
 
     def __init__(self, max_n_atoms_per_residue, d_feat):
         super().__init__()
@@ -297,19 +390,12 @@ class ResidueEmbedding(nn.Module):
         B, K = seq.shape
         dims = _hip.CtxDims(B, K, self.max_n_atoms_per_residue, self.d_feat, 1, 32)
         p = _named(self)
-        ts = [_hip.dev_f32(p[k]) for k in ("amino_acid_type_embedding.weight", "chain_embedding.weight", "mlp.0.weight", "mlp.0.bias",
-                                           "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias", "mlp.6.weight", "mlp.6.bias")]
-        w = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in ts])
-        ws = _hip.workspace(lib.diffab_residue_embedding_workspace_bytes(C.byref(dims)))
-        out = torch.empty(B, K, self.d_feat, dtype=torch.float32, device=seq.device)
-        _hip.check(lib.diffab_residue_embedding_fwd(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(dh),
-                                                    _hip.ptr(ch), _hip.ptr(am), _hip.ptr(sm), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws),
-                                                    ws.numel(), _hip.stream_ptr()), "diffab_residue_embedding_fwd")
+        out = _ResidueEmbeddingFn.apply(dims, seq, x, O, dh, ch, am, sm, qm, *[p[k] for k in _RES_KEYS])
         return out.to(out_dev)
 
 
 class PairEmbedding(nn.Module):
-    """Residue-pair context embedding (reference diffab_pytorch.py:186-312), forward on HIP.  Reference quirks kept: the
+    """Residue-pair context embedding (reference diffab_pytorch.py:186-312), forward and backward on HIP.  Reference quirks kept: the
     same-chain mask is a product of chain ids (:279) and the structure-context mask never reaches the output (:292-301)."""
 
     def __init__(self, max_n_atoms_per_residue, d_feat, max_dist_to_consider=32):
@@ -343,20 +429,9 @@ class PairEmbedding(nn.Module):
         A = self.max_n_atoms_per_residue
         dims = _hip.CtxDims(B, K, A, 1, self.d_feat, self.max_dist_to_consider)
         p = _named(self)
-        ts = [_hip.dev_f32(p[k]) for k in ("aa_pair_type_embedding.weight", "relpos_embedding.weight", "pair2distcoef.weight",
-                                           "distance_embedding.0.weight", "distance_embedding.0.bias", "distance_embedding.2.weight",
-                                           "distance_embedding.2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
-                                           "mlp.4.weight", "mlp.4.bias")]
-        w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
-        ws = _hip.workspace(lib.diffab_pair_embedding_workspace_bytes(C.byref(dims)))
-        out = torch.empty(B, K, K, self.d_feat, dtype=torch.float32, device=seq.device)
-        stride = K if ri.shape[0] == B and B > 1 or ri.shape[0] == B else 0
         if ri.shape[0] not in (1, B):
             raise ValueError("residue_idx must be (1, K) or (B, K)")
-        entry = lib.diffab_pair_embedding_xyz_fwd if from_xyz else lib.diffab_pair_embedding_fwd
-        _hip.check(entry(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri),
-                         stride if ri.shape[0] == B else 0, _hip.ptr(ch), _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws), ws.numel(),
-                         _hip.stream_ptr()), "diffab_pair_embedding_xyz_fwd" if from_xyz else "diffab_pair_embedding_fwd")
+        out = _PairEmbeddingFn.apply(dims, from_xyz, seq, dm, dh, ri, K if ri.shape[0] == B else 0, ch, am, qm, *[p[k] for k in _PAIR_KEYS])
         return out.to(out_dev)
 
 

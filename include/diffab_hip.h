@@ -274,6 +274,25 @@ int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_em
                                   const float* atom_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
                                   size_t workspace_bytes, void* stream);
 
+/* Backward of the two context encoders (training through encode_context, diffab_pytorch.py:843-854 under autograd).
+ * d_out is the gradient w.r.t. the module output; parameter gradients ACCUMULATE (+=) into the buffers of `g`, which has the
+ * layout of the weight struct (the caller zero-fills them).  Inputs other than parameters take no gradient.  Nothing is taped:
+ * the backward recomputes the forward of each chunk.  PairEmbedding: the reference's own autograd fails on an in-place product
+ * (:295-301); this is the gradient of the same forward with that product out of place (it does not reach the output). */
+size_t diffab_residue_embedding_bwd_workspace_bytes(const diffab_ctx_dims* d);
+int diffab_residue_embedding_bwd(const diffab_ctx_dims* d, const diffab_residue_emb_weights* w, const diffab_residue_emb_weights* g,
+                                 const int64_t* seq_idx, const float* xyz, const float* orientations, const float* dihedrals,
+                                 const int64_t* chain_idx, const float* atom_mask, const uint8_t* structure_context_mask,
+                                 const uint8_t* sequence_context_mask, const float* d_out /* (B,K,D) */, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+size_t diffab_pair_embedding_bwd_workspace_bytes(const diffab_ctx_dims* d);
+/* exactly one of distmat (B,K,K,A,A) / xyz (B,K,A,3) is non-null, as in the two forward entries */
+int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
+                              const int64_t* seq_idx, const float* distmat, const float* xyz, const float* pairwise_dihedrals,
+                              const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                              const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out /* (B,K,K,C) */,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- reverse process (build-defined; reference stub diffab_pytorch.py:770-776) -- */
 /* One update t -> t-1 from denoiser outputs with explicit noise (z (B,K,3), rotvec (B,K,3), u_seq (B,K)),
  * in place on (seq, x, O), only where gen_mask is set. */

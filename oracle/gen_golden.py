@@ -413,6 +413,41 @@ def main():
             g[f"pair_{int(gs)}{int(gq)}"] = npf(pair_ref)
     np.savez_compressed(os.path.join(GOLD, "encode_context.npz"), **g)
 
+    # ---------------------------------------------------------------- encode_context gradients (training through the encoders)
+    # loss = <res_ctx, G1> + <pair_ctx, G2> with fixed upstream gradients.  ResidueEmbedding: autograd of the REAL reference.
+    # PairEmbedding: the reference's own backward raises (in-place product on a tensor saved for backward, diffab_pytorch.py:295-301 -
+    # checked below), so its gradients come from autograd of the oracle restatement, whose forward equals the reference's (above).
+    print("encode_context gradients (residue: reference autograd; pair: oracle autograd, the reference's raises)")
+    rng_g = np.random.Generator(np.random.PCG64([7, 3]))
+    G1 = torch.from_numpy(rng_g.standard_normal((Bc, Kc, D_)).astype(np.float32))
+    G2 = torch.from_numpy(rng_g.standard_normal((Bc, Kc, Kc, C_)).astype(np.float32))
+    ctx_mask = cb["residue_mask"].bool() & (~cb["generation_mask"].bool())
+    ref_model.train()
+    ref_model.zero_grad()
+    res_ref = ref_model.residue_context_embedding(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], cb["chain_idx"],
+                                                  cb["atom_mask"], ctx_mask, ctx_mask)
+    (res_ref * G1).sum().backward()
+    gg = {"G1": npf(G1), "G2": npf(G2), "meta": np.array([Bc, Kc, A_, D_, C_, 41])}
+    for n_, p_ in ref_model.residue_context_embedding.named_parameters():
+        gg["grad/residue_context_embedding." + n_] = npf(p_.grad)
+    raised = False
+    try:
+        pr = ref_model.pair_context_embedding(cb["seq_idx"], cb["distmat"].clone(), cb["pairwise_dihedrals"], cb["residue_idx"],
+                                              cb["chain_idx"], cb["atom_mask"], ctx_mask, ctx_mask)
+        (pr * G2).sum().backward()
+    except RuntimeError as err:
+        raised = "inplace" in str(err) or "in-place" in str(err)
+    assert raised, "the reference's PairEmbedding backward was expected to fail on its in-place product"
+    sdo = {k_: v_.clone().requires_grad_(v_.is_floating_point()) for k_, v_ in csd.items()}
+    res_o, pair_o = orc.encode_context(sdo, cb, True, True)
+    ((res_o * G1).sum() + (pair_o * G2).sum()).backward()
+    for n_, p_ in ref_model.residue_context_embedding.named_parameters():
+        check("grad residue_context_embedding." + n_, sdo["residue_context_embedding." + n_].grad, p_.grad, 2e-5)
+    for k_, v_ in sdo.items():
+        if k_.startswith("pair_context_embedding."):
+            gg["grad/" + k_] = npf(v_.grad)
+    np.savez_compressed(os.path.join(GOLD, "encode_context_grads.npz"), **gg)
+
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print(f"wrote {len(os.listdir(GOLD))} fixtures, {tot/1024:.0f} KiB, under {GOLD}")
 

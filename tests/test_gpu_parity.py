@@ -786,6 +786,69 @@ def test_encode_context_vs_reference_goldens(hip, golden):
             assert maxrel(pair_x, g[f"pair_{int(gs)}{int(gq)}"]) < 1e-5, (gs, gq, maxrel(pair_x, g[f"pair_{int(gs)}{int(gq)}"]))
 
 
+def test_encode_context_gradients_vs_goldens(hip, golden):
+    """Training through encode_context: every residue_context_embedding.* gradient against autograd of the REAL reference, every
+    pair_context_embedding.* gradient against autograd of the oracle restatement (the reference's own PairEmbedding backward
+    raises on its in-place product, diffab_pytorch.py:295-301 - asserted when the fixture is generated), for the materialised
+    distance tensor and for distances taken from xyz."""
+    from diffab_pytorch import DiffAb
+
+    g = golden("encode_context_grads")
+    Bc, Kc, A_, D_, C_, seed = [int(v) for v in g["meta"]]
+    model = DiffAb(D_, C_, 1, 12, 4, 4, 8).cuda()
+    model.load_state_dict(syn.context_state_dict(D_, C_, A_, 32, seed=seed), strict=False)
+    cb = {k: v.cuda() for k, v in syn.context_batch(Bc, Kc, A_, seed=seed).items()}
+    G1, G2 = T(g["G1"]).cuda(), T(g["G2"]).cuda()
+    names = [k[5:] for k in g if k.startswith("grad/")]
+    assert len(names) == 23 and {n.split(".")[0] for n in names} == {"residue_context_embedding", "pair_context_embedding"}
+    params = dict(model.named_parameters())
+    for distmat in (cb["distmat"], None):
+        model.zero_grad()
+        res, pair = model.encode_context(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], distmat,
+                                         cb["pairwise_dihedrals"], cb["atom_mask"], cb["chain_idx"], cb["residue_idx"],
+                                         cb["generation_mask"], cb["residue_mask"])
+        assert res.requires_grad and pair.requires_grad
+        ((res * G1).sum() + (pair * G2).sum()).backward()
+        worst = ("", 0.0)
+        for n in names:
+            want = g["grad/" + n]
+            got = params[n].grad
+            assert got is not None and got.shape == want.shape, n
+            r = maxrel(got, want)
+            worst = max(worst, (n, r), key=lambda t_: t_[1])
+            assert r < 2e-4, (n, r, "xyz" if distmat is None else "distmat")
+        print("encode_context worst parameter-gradient max-rel (%s):" % ("xyz" if distmat is None else "distmat"), worst)
+    # padding_idx of the chain embedding takes no gradient (nn.Embedding(10, D, padding_idx=0), reference :65)
+    assert float(params["residue_context_embedding.chain_embedding.weight"].grad[0].abs().max()) == 0.0
+
+
+def test_full_training_step_updates_every_parameter(hip):
+    """DiffAb.training_step on the reference's batch dict (no precomputed contexts): encode_context is part of the graph, so one
+    Adam step moves all parameters - the 559 641 of the two context encoders included."""
+    from diffab_pytorch import DiffAb
+
+    d = syn.BENCH_DIMS
+    torch.manual_seed(0)
+    model = DiffAb(d["D"], d["C"], 2, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    model.load_state_dict(syn.context_state_dict(d["D"], d["C"], 15, 32, seed=3), strict=False)
+    batch = {k: v.cuda() for k, v in syn.context_batch(2, 32, 15, seed=3).items()}
+    batch.pop("distmat")
+    n_params = sum(p.numel() for p in model.parameters())
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = model.configure_optimizers()
+    torch.manual_seed(1)
+    loss = model.training_step(batch, 0)
+    assert loss.requires_grad and torch.isfinite(loss)
+    loss.backward()
+    opt.step()
+    # pair2distcoef is zero-initialised upstream and takes a gradient all the same; relpos rows never indexed stay put
+    moved = {n: not torch.equal(p.detach(), before[n]) for n, p in model.named_parameters()}
+    still = [n for n, m in moved.items() if not m]
+    assert not still, still
+    enc = sum(p.numel() for n, p in model.named_parameters() if n.startswith(("residue_context_embedding", "pair_context_embedding")))
+    print(f"full training step: {n_params} parameters, {enc} of them in the context encoders, all moved")
+
+
 def test_encode_context_benchmark_dims_and_end_to_end(hip):
     """Benchmark model (D=128, C=64, A=15), K=64, vs the oracle; then the whole chain on the device: encode_context ->
     _shared_step (no precomputed contexts) -> sample."""

@@ -118,6 +118,14 @@ def test_two_synthetic_steps_train_and_resume(tmp_path):
         assert np.isfinite(r["train/loss"])
     ck = torch.load(tmp_path / "ck" / "last.ckpt")
     assert ck["global_step"] == 2 and any(k.startswith("denoiser.ipa.layers.0.") for k in ck["state_dict"])
+    # the context encoders are trained too (encode_context has a HIP backward): their weights differ from the seeded initialisation
+    from diffab_pytorch import DiffAb
+
+    torch.manual_seed(42)  # the harness's default --seed
+    fresh = DiffAb(*T.MODEL_HPARAMS.values()).state_dict()
+    for k in ("residue_context_embedding.mlp.0.weight", "residue_context_embedding.amino_acid_type_embedding.weight",
+              "pair_context_embedding.mlp.4.weight", "pair_context_embedding.pair2distcoef.weight", "denoiser.ipa.layers.5.to_out.weight"):
+        assert not torch.equal(ck["state_dict"][k].cpu(), fresh[k].cpu()), k
     # resume: one more epoch continues the step count from the checkpoint
     rc = T.main(["--synthetic", "6", "--k", "16", "-b", "3", "-e", "2", "--val-pct", "0.34", "--resume", str(tmp_path / "ck" / "last.ckpt"),
                  "--log", str(log)])
