@@ -9,6 +9,7 @@ all-gather of the sampled structures at the end of the timed region.
 
     python bench.py --gpus 1 --steps 100 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    ... bench.py --train [--gpus N]        BASELINE config 4 (training step, 128 patches per GPU, gradient all-reduce) instead
 
 Prints ONE JSON line on rank 0 (contract: task prompt section 4).
 """
@@ -39,59 +40,98 @@ def algorithmic_bytes_per_residue_step(K, D, C, NL, V=21):
     return per_patch / K
 
 
-def cpu_baseline(dims, sd, K, n_patches, n_steps, seed):
-    """The oracle (torch-CPU restatement of the reference's formulation, checked against the reference by the golden
-    vectors) timed on this host's cores on a bounded sample of the same workload: n_patches x K x n_steps."""
+def cpu_baseline(dims, sd, K, seed, budget_s=30.0):
+    """The oracle (torch-CPU restatement of the reference's formulation incl. the materialised point-difference tensor, checked
+    against the real reference by the golden vectors) timed on this host's cores, as SURVEY 8(d) / BASELINE.md section 3 specify:
+    B = 1 and B = 8 patches of K residues; (i) reverse-sampling steps, (ii) the hot-path training step (forward + backward);
+    all cores and one thread.  A bounded sample: each case runs one warm-up and as many timed iterations (1..5) as fit its share of
+    `budget_s`.  `value` is the best all-core sampling case; every case is listed under `cases`."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import numpy as np
 
     import diffab_oracle as orc
     from diffab_pytorch import synthetic as syn
 
-    inp = syn.patches(n_patches, K, dims, seed=seed, coord_sigma=10.0)
     sched = orc.cosine_variance_schedule(100, s=0.01, beta_max=0.999)
     sdo = {"denoiser." + k: v for k, v in sd.items()}
-    seq, x, O = inp["seq_idx"], inp["translations"], inp["orientations"]
-    gm = inp["generation_mask"]
-    patch = np.arange(n_patches)[:, None] + np.zeros((n_patches, K), dtype=np.int64)
-    res = np.zeros((n_patches, K), dtype=np.int64) + np.arange(K)[None, :]
-
-    def step(t, seq, x, O):
-        den = orc.denoiser(sdo, seq, x, O, inp["res_context_emb"], inp["pair_context_emb"], sched["beta"][t].expand(n_patches),
-                           dims["NL"], dims["H"])
-        z = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, 1)[:3], -1))
-        rv = 0.1 * torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, 2)[:3], -1))
-        u = torch.from_numpy(orc.philox_uniform4(seed, patch, res, t, 0)[0])
-        return orc.reverse_update(t, seq, x, O, den, gm, sched, z, rv, u)
-
-    # torch's default thread count (all physical cores) oversubscribes a box whose CPU share is smaller than the
-    # machine: probe the default and a 16-thread run (the 1-GPU box's share) for 3 steps each, then time the faster
-    # configuration on the full sample (~10-30 s of CPU work).
     default_threads = torch.get_num_threads()
+    thread_sets = sorted({default_threads, min(16, default_threads)}, reverse=True)  # the 1-GPU box's CPU share is 16 of the host's cores
 
-    def run(threads, steps):
+    def make(B):
+        inp = syn.patches(B, K, dims, seed=seed, coord_sigma=10.0)
+        patch = np.arange(B)[:, None] + np.zeros((B, K), dtype=np.int64)
+        res = np.zeros((B, K), dtype=np.int64) + np.arange(K)[None, :]
+        return inp, patch, res
+
+    def sampling_case(B):
+        inp, patch, res = make(B)
+        state = [inp["seq_idx"], inp["translations"], inp["orientations"]]
+
+        def it(i):
+            t = 100 - (i % 100)
+            with torch.no_grad():
+                den = orc.denoiser(sdo, state[0], state[1], state[2], inp["res_context_emb"], inp["pair_context_emb"],
+                                   sched["beta"][t].expand(B), dims["NL"], dims["H"])
+                z = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, 1)[:3], -1))
+                rv = 0.1 * torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, 2)[:3], -1))
+                u = torch.from_numpy(orc.philox_uniform4(seed, patch, res, t, 0)[0])
+                state[0], state[1], state[2] = orc.reverse_update(t, state[0], state[1], state[2], den, inp["generation_mask"], sched, z, rv, u)
+        return it
+
+    def training_case(B):
+        inp, patch, res = make(B)
+        params = {k: v.clone().requires_grad_(True) for k, v in sdo.items()}
+        t = torch.full((B,), 40)
+        eps = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, 40, 1)[:3], -1))
+        x_t = orc.coord_diffuse_from_t0(inp["translations"], t, inp["generation_mask"], eps, sched)
+        post = orc.seq_posterior_single_step(inp["seq_idx"], inp["seq_idx"], t, inp["generation_mask"], sched)
+
+        def it(i):
+            for p in params.values():
+                p.grad = None
+            den = orc.denoiser(params, inp["seq_idx"], x_t, inp["orientations"], inp["res_context_emb"], inp["pair_context_emb"],
+                               sched["beta"][t], dims["NL"], dims["H"])
+            ls = orc.hotpath_losses(den, post, eps, inp["orientations"], inp["generation_mask"], inp["residue_mask"])
+            (ls[0] + ls[1] + ls[2]).backward()
+        return it
+
+    plan = []  # (name, B, threads, factory): all-core cases first so the single-thread ones take what is left of the budget
+    for threads in thread_sets + [1]:
+        for B in (1, 8):
+            plan.append(("sampling", B, threads, sampling_case))
+            plan.append(("training", B, threads, training_case))
+    cases, t_start = [], time.perf_counter()
+    for idx, (name, B, threads, factory) in enumerate(plan):
+        left = budget_s - (time.perf_counter() - t_start)
+        if left <= 0.5:
+            cases.append({"what": name, "patches": B, "threads": threads, "skipped": "budget spent"})
+            continue
+        share = left / (len(plan) - idx) * (2.0 if threads == 1 else 1.0)
         torch.set_num_threads(threads)
-        s0, x0, O0 = seq, x, O
-        with torch.no_grad():
-            s0, x0, O0 = step(100, s0, x0, O0)  # warm-up
-            t0 = time.perf_counter()
-            for i in range(steps):
-                s0, x0, O0 = step(100 - (i % 100), s0, x0, O0)
-            return time.perf_counter() - t0
-
-    probes = {threads: run(threads, 3) for threads in sorted({default_threads, min(16, default_threads)})}
-    threads = min(probes, key=probes.get)
-    best = (run(threads, n_steps), threads)
+        it = factory(B)
+        t0 = time.perf_counter()
+        it(0)  # warm-up (its time bounds how many timed iterations fit)
+        warm = time.perf_counter() - t0
+        n = int(max(1, min(5, share / max(warm, 1e-3) - 1)))
+        t0 = time.perf_counter()
+        for i in range(n):
+            it(1 + i)
+        dt = (time.perf_counter() - t0) / n
+        cases.append({"what": name, "patches": B, "threads": threads, "iters": n, "ms_per_step": dt * 1e3,
+                      "residue_steps_per_s": B * K / dt})
     torch.set_num_threads(default_threads)
-    dt, threads = best
+    best = max((c for c in cases if c["what"] == "sampling" and c["threads"] > 1 and "ms_per_step" in c),
+               key=lambda c: c["residue_steps_per_s"])
     return {
-        "value": n_patches * K * n_steps / dt,
+        "value": best["residue_steps_per_s"],
         "unit": "residue-steps/s",
-        "cores": threads,
+        "cores": best["threads"],
         "kind": "port",
-        "sample": f"{n_patches} patches x K={K} x {n_steps} reverse steps, oracle/diffab_oracle.py (torch CPU fp32, "
-                  f"reference formulation), {dt:.1f} s on {threads} threads (best of default {default_threads} and 16) of "
-                  f"{os.cpu_count()} logical CPUs",
+        "sample": f"oracle/diffab_oracle.py (torch CPU fp32, reference formulation) on {os.cpu_count()} logical CPUs: B = 1 and 8 patches x "
+                  f"K={K}; reverse-sampling steps and hot-path training steps (forward + backward); {thread_sets} threads and 1 thread; one "
+                  f"warm-up + 1..5 timed iterations per case, {time.perf_counter() - t_start:.0f} s in all; value = sampling, "
+                  f"B={best['patches']}, {best['threads']} threads",
+        "cases": cases,
     }
 
 
@@ -162,6 +202,66 @@ def other_configs(model, dims, flags):
     return res
 
 
+def train_bench(args, model, dims, rank, world, dist):
+    """BASELINE config 4: B patches per GPU (1024 = 8 x 128), one training step = forward noise + taped denoise forward + three
+    losses + HIP backward + all-reduce of the gradient buckets (in place, RCCL) + Adam.  Contexts are leaf inputs, as in the
+    gradient goldens (the hot-path definition of SURVEY 8d: 107 MB of algorithmic traffic per patch-step)."""
+    from diffab_pytorch import distributed as D, synthetic as syn
+
+    B, K = args.batch, args.k
+    inp = syn.patches(B, K, dims, seed=2, first_patch=rank * B)
+    batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
+             "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),
+             "res_context_emb": inp["res_context_emb"].cuda(), "pair_context_emb": inp["pair_context_emb"].cuda()}
+    torch.manual_seed(1000 + rank)  # per-rank noise / timestep stream (the parameters above are identical on every rank)
+    opt = model.configure_optimizers()
+    loss = None
+
+    def step(i):
+        nonlocal loss
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, i)
+        loss.backward()
+        D.allreduce_gradients(model.parameters(), dist, flats=model.gradient_buckets())
+        opt.step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    in_place = all(p.grad is None or any(f is not None and p.grad.untyped_storage().data_ptr() == f.untyped_storage().data_ptr()
+                                         for f in model.gradient_buckets()) for p in model.denoiser.parameters())
+    if rank == 0:
+        value = world * B * K * args.steps / elapsed
+        train_bytes_per_patch = 107e6  # SURVEY 8(d): NL K^2 C 4 x (fwd read + bwd read + grad-e read-modify-write) + saved activations
+        achieved = value / world / K * train_bytes_per_patch / 1e9
+        print(json.dumps({
+            "metric": "CDR-residue training-steps/sec (K=128 patch, forward + backward + Adam)", "value": value, "unit": "residue-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: training step, batch={B}/GPU synthetic K={K} patches, benchmark model NL=6; noise + taped "
+                                   "forward + 3 losses + HIP backward + gradient all-reduce (RCCL, in-place buckets) + Adam; contexts given",
+                       "patches_per_gpu": B, "K": K, "global_batch": world * B, "parallelism": f"data-parallel x{world}"},
+            "roofline": {"kernel": "whole training step (no single dominant kernel: profiles/r02_train_kernel_stats.csv)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_patch_step": train_bytes_per_patch},
+            "loss_finite": bool(torch.isfinite(loss.detach()).item()), "gradients_reduced_in_place": bool(in_place),
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,12 +270,17 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="patches per GPU")
     ap.add_argument("--k", type=int, default=128, help="residues per patch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=300)
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU baseline cases")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
     ap.add_argument("--split-attention", action="store_true", help="attention as three launches (csrc/attention_split.hip) instead of fused")
     ap.add_argument("--external-logits", action="store_true", help="logits in their own launch, fused kernel for the rest")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short BASELINE config 4 / 5 measurements (N=1 only)")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 4 instead of the sampling headline: training steps (noise + taped forward + 3 losses + HIP "
+                         "backward + gradient all-reduce over RCCL + Adam), 128 patches per GPU unless --batch is given")
     args = ap.parse_args()
+    if args.train and "--batch" not in sys.argv:
+        args.batch = 128
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,6 +303,11 @@ def main():
     torch.manual_seed(0)  # default init of the boundary module, identical on every rank
     model = DiffAb(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"]).cuda()
     first_patch = rank * B  # global patch ids: rank r owns [r*B, (r+1)*B)
+    if args.train:
+        train_bench(args, model, dims, rank, world, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     t_gen = time.perf_counter()
     inp = syn.patches(B, K, dims, seed=0, coord_sigma=10.0, first_patch=first_patch)  # CPU-generated, then copied
     dev = {k: v.cuda() for k, v in inp.items()}
@@ -311,7 +421,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             torch.manual_seed(0)
             sd = {k: v.detach().cpu() for k, v in model.denoiser.state_dict().items()}
-            out["cpu_baseline"] = cpu_baseline(dims, sd, K, n_patches=2, n_steps=args.cpu_steps, seed=seed)
+            out["cpu_baseline"] = cpu_baseline(dims, sd, K, seed=seed, budget_s=args.cpu_budget)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -102,7 +102,7 @@ static int mlp3(const diffab_dims* d, const diffab_mlp3_weights* w, const float*
 
 static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
                         const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
-                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st) {
+                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool emb_tab_ready = false) {
   const StepBuffers b = carve_step(d, ws);
   const int rows = d->B * d->K, D = d->D;
   // Folded concatenations (MFMA path): the sequence-embedding half of to_res_emb[0] and the beta-embedding columns of the three
@@ -111,7 +111,7 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   if (fold) {
     DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0, DIFFAB_ERR_ARG,
                    "denoiser head: null weight pointer");
-    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st)) return rc;
+    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, emb_tab_ready)) return rc;
     if (int rc = launch_rowgemm128(res_ctx, D, w->res_w0, 2 * D, b.emb_tab, seq_t, 0, b.h1, D, rows, D, true, st)) return rc;
   } else {
     if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, b.cat2, st)) return rc;
@@ -298,7 +298,8 @@ int diffab_train_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w
   const TrainTape tp = carve_tape(d, static_cast<float*>(tape));
   hipStream_t st = as_stream(stream);
   if (int rc = denoise_step_taped(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, tp, flags, st)) return rc;
-  return launch_losses_fwd(out_posterior, true_post, out_eps, true_eps, out_O0, true_O0, gen_mask, res_mask, d->B, d->K, d->V, losses3, st);
+  return launch_losses_fwd(out_posterior, true_post, out_eps, true_eps, out_O0, true_O0, gen_mask, res_mask, d->B, d->K, d->V, losses3, st,
+                           tp.scratch);
 }
 
 int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
@@ -335,9 +336,15 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
   const SampleBuffers sb = carve_sample(d, workspace);
   DIFFAB_REQUIRE(workspace_bytes >= sb.bytes, DIFFAB_ERR_WORKSPACE, "sample_loop: workspace %zu < %zu bytes", workspace_bytes, sb.bytes);
   hipStream_t st = as_stream(stream);
+  // the folded sequence-embedding table depends on the weights only: once per call, not once per step (same condition as denoise_step)
+  const StepBuffers b0 = carve_step(d, sb.step);
+  const bool fold = !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d) &&
+                    rowgemm128_ok(res_ctx, d->D, b0.h1, d->D, d->B * d->K, d->D);
+  if (fold)
+    if (int rc = launch_fold_tables(d, w, nullptr, b0.emb_tab, nullptr, st)) return rc;
   for (int t = t_start; t > t_stop; --t) {
     if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st)) return rc;
-    if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st))
+    if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold))
       return rc;
     if (int rc = launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K,
                                               d->V, st))

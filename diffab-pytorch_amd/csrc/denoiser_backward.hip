@@ -1287,6 +1287,7 @@ TrainTape carve_tape(const diffab_dims* d, float* base) {
   for (int hd = 0; hd < 3; ++hd) { t.t1[hd] = take(rows * D); t.t2[hd] = take(rows * D); }
   t.vbuf = take(rows * 3);
   t.logits = take(rows * d->V);
+  t.scratch = take(1024);  // (the +1024 of train_tape_floats)
   return t;
 }
 

@@ -1079,9 +1079,12 @@ __global__ void fold_beta_table_kernel(const float* __restrict__ beta, const flo
   tab[(static_cast<int64_t>(hd) * B + b) * D + n] = ((be * wr[0] + sinf(be) * wr[1]) + cosf(be) * wr[2]) + bias[n];
 }
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
-                       hipStream_t st) {
-  hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25, (d->D + 7) / 8), dim3(64), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
-  DIFFAB_LAUNCH_CHECK();
+                       hipStream_t st, bool emb_tab_ready) {
+  if (!emb_tab_ready) {  // weights only: the reverse sampler builds it once per trajectory, not once per step
+    hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25, (d->D + 7) / 8), dim3(64), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
+    DIFFAB_LAUNCH_CHECK();
+  }
+  if (beta == nullptr) return DIFFAB_OK;
   hipLaunchKernelGGL(fold_beta_table_kernel, dim3(d->B, 3), dim3(d->D), 0, st, beta, w->coord.w0, w->coord.b0, w->orient.w0, w->orient.b0,
                      w->seq.w0, w->seq.b0, d->D, d->B, beta_tab);
   DIFFAB_LAUNCH_CHECK();

@@ -31,7 +31,7 @@ int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const fl
                       int ldy, int M, int Kd, bool relu, hipStream_t st);
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
-                       hipStream_t st);
+                       hipStream_t st, bool emb_tab_ready = false);  // beta == nullptr: the weights-only embedding table alone
 
 // attention_split.hip: the attention of one IPA layer as three launches (logits | pair stream | P x V) exchanging the
 // (B, 8, K, K) logits / probabilities through SP; single key chunk only (K = 64, 128)
@@ -61,6 +61,7 @@ void timer_end(hipStream_t st);
 constexpr int kMaxLayers = 16;
 struct TrainTape {
   float *cat2, *h1, *x[kMaxLayers + 1], *ipa_ws[kMaxLayers], *cat3, *t1[3], *t2[3], *vbuf, *logits;
+  float* scratch;  // 1024 floats: partial sums of the loss reduction
   // per layer, benchmark geometry with K = 64 / 128 only (else null): the attention probabilities and the squared point distances
   // [b][h][i][j], saved by the three-launch forward so that the backward does not recompute them
   float *sp[kMaxLayers], *d2[kMaxLayers];
@@ -80,7 +81,8 @@ int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W
 int bwd_relu_mask(float* dY, const float* act, int64_t n, hipStream_t st);
 int bwd_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st);
 int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const float* te, const float* pO, const float* tO, const uint8_t* gm,
-                      const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st);
+                      const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st,
+                      float* scratch = nullptr);  // scratch: 1024 floats -> the multi-work-group two-stage reduction
 
 // diffusion_kernels.hip
 int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,

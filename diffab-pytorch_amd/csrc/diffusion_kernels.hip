@@ -376,6 +376,63 @@ __global__ void losses_kernel(const float* __restrict__ pp, const float* __restr
   if (threadIdx.x < 3) out3[threadIdx.x] = red[threadIdx.x][0] / red[3][0];
 }
 
+// Two-stage form for the training step (B K = 16 k rows, ~21 logf per row: one work-group serialises 0.2 ms of it): kLossBlocks
+// work-groups reduce contiguous row chunks to partial[block][4] (fixed tree order inside a block), one work-group adds the partials
+// in block order - deterministic, and independent of how rows are spread over compute units.
+constexpr int kLossBlocks = 256;
+__global__ __launch_bounds__(256) void losses_partial_kernel(const float* __restrict__ pp, const float* __restrict__ tp,
+                                                             const float* __restrict__ pe, const float* __restrict__ te,
+                                                             const float* __restrict__ pO, const float* __restrict__ tO,
+                                                             const uint8_t* __restrict__ gm, const uint8_t* __restrict__ rm, int64_t n, int V,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4][256];
+  const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  float a_kl = 0.f, a_mse = 0.f, a_o = 0.f, a_n = 0.f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    if (!(gm[i] && rm[i])) continue;
+    a_n += 1.0f;
+    for (int v = 0; v < V; ++v) {
+      const float q = tp[i * V + v];
+      if (q > 0.0f) a_kl += q * logf(q) - q * logf(pp[i * V + v]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = pe[i * 3 + c] - te[i * 3 + c];
+      a_mse += d * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) d += pO[i * 9 + r * 3 + j] * tO[i * 9 + r * 3 + k];
+        d -= (j == k) ? 1.0f : 0.0f;
+        a_o += d * d;
+      }
+  }
+  red[0][threadIdx.x] = a_kl; red[1][threadIdx.x] = a_mse; red[2][threadIdx.x] = a_o; red[3][threadIdx.x] = a_n;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s)
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ __launch_bounds__(256) void losses_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out3) {
+  __shared__ float red[4][256];
+  for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = static_cast<int>(threadIdx.x) < nblocks ? partial[threadIdx.x * 4 + q] : 0.0f;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s)
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out3[threadIdx.x] = red[threadIdx.x][0] / red[3][0];
+}
+
 // (pred^T target - I)^2 element-wise (+ optional total), diffab_pytorch.py:610-625.  One block, fixed-order reduction.
 __global__ void orientation_loss_kernel(const float* __restrict__ pO, const float* __restrict__ tO, int64_t n, float* __restrict__ elems,
                                         float* __restrict__ sum1) {
@@ -499,7 +556,14 @@ int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab,
 }
 
 int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const float* te, const float* pO, const float* tO, const uint8_t* gm,
-                      const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st) {
+                      const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st, float* scratch) {
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (scratch != nullptr && n >= 4096) {  // scratch: 4 kLossBlocks floats (the training tape has them)
+    hipLaunchKernelGGL(losses_partial_kernel, dim3(kLossBlocks), dim3(256), 0, st, pp, tp, pe, te, pO, tO, gm, rm, n, V, scratch);
+    hipLaunchKernelGGL(losses_final_kernel, dim3(1), dim3(256), 0, st, scratch, kLossBlocks, out3);
+    DIFFAB_LAUNCH_CHECK();
+    return DIFFAB_OK;
+  }
   hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(1024), 0, st, pp, tp, pe, te, pO, tO, gm, rm, static_cast<int64_t>(B) * K, V, out3);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;

@@ -224,13 +224,9 @@ class _HotpathTrainStep(torch.autograd.Function):
         dims = ctx.dims
         B, K = seq.shape
         w = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, params)), ctx.denoiser.dims["NL"])
-        # one zero-filled flat buffer, one view per parameter (256-byte aligned): a fill per parameter is 100+ tiny launches per step
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
-            total += (p.numel() + 63) // 64 * 64
-        flat = torch.zeros(total, dtype=torch.float32, device=seq.device)
-        grads = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+        # one zero-filled flat buffer, one view per parameter (256-byte aligned): a fill per parameter is 100+ tiny launches per step;
+        # kept on the module so that the data-parallel all-reduce can run on the bucket itself (DiffAb.gradient_buckets)
+        grads, ctx.denoiser._flat_grad = _zero_grads_like(params)
         g = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, grads)), ctx.denoiser.dims["NL"])
         up = _hip.dev_f32(g_losses)
         d_rc = torch.empty(B, K, dims.D, dtype=torch.float32, device=seq.device)
@@ -288,15 +284,16 @@ def _zero_grads_like(params):
         offs.append(total)
         total += (p.numel() + 63) // 64 * 64
     flat = torch.zeros(total, dtype=torch.float32, device=_hip.device())
-    return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+    return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)], flat
 
 
 class _ResidueEmbeddingFn(torch.autograd.Function):
     """ResidueEmbedding forward / backward as two C-ABI calls (the backward recomputes the forward: nothing is taped)."""
 
     @staticmethod
-    def forward(ctx, dims, seq, x, O, dh, ch, am, sm, qm, *params):
+    def forward(ctx, owner, dims, seq, x, O, dh, ch, am, sm, qm, *params):
         lib = _hip.lib()
+        ctx.owner = owner
         ts = [_hip.dev_f32(p) for p in params]
         w = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in ts])
         ws = _hip.workspace(lib.diffab_residue_embedding_workspace_bytes(C.byref(dims)))
@@ -316,7 +313,7 @@ class _ResidueEmbeddingFn(torch.autograd.Function):
         ts = list(ctx.saved_tensors[6:])
         sm, qm = ctx.masks
         dims = ctx.dims
-        grads = _zero_grads_like(ts)
+        grads, ctx.owner._flat_grad = _zero_grads_like(ts)
         w = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in ts])
         g = _hip.ResidueEmbWeights(*[_hip.ptr(t_) for t_ in grads])
         ws = _hip.workspace(lib.diffab_residue_embedding_bwd_workspace_bytes(C.byref(dims)))
@@ -324,7 +321,7 @@ class _ResidueEmbeddingFn(torch.autograd.Function):
         _hip.check(lib.diffab_residue_embedding_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O),
                                                     _hip.ptr(dh), _hip.ptr(ch), _hip.ptr(am), _hip.ptr(sm), _hip.ptr(qm), _hip.ptr(do),
                                                     _hip.ptr(ws), ws.numel(), _hip.stream_ptr()), "diffab_residue_embedding_bwd")
-        return (None,) * 9 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
+        return (None,) * 10 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
 
 
 class _PairEmbeddingFn(torch.autograd.Function):
@@ -332,8 +329,9 @@ class _PairEmbeddingFn(torch.autograd.Function):
     in-place mask product (diffab_pytorch.py:295-301, which makes the reference's own autograd fail) taken out of place."""
 
     @staticmethod
-    def forward(ctx, dims, from_xyz, seq, dm, dh, ri, ri_stride, ch, am, qm, *params):
+    def forward(ctx, owner, dims, from_xyz, seq, dm, dh, ri, ri_stride, ch, am, qm, *params):
         lib = _hip.lib()
+        ctx.owner = owner
         ts = [_hip.dev_f32(p) for p in params]
         w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
         ws = _hip.workspace(lib.diffab_pair_embedding_workspace_bytes(C.byref(dims)))
@@ -353,7 +351,7 @@ class _PairEmbeddingFn(torch.autograd.Function):
         seq, dm, dh, ri, ch, am = ctx.saved_tensors[:6]
         ts = list(ctx.saved_tensors[6:])
         dims = ctx.dims
-        grads = _zero_grads_like(ts)
+        grads, ctx.owner._flat_grad = _zero_grads_like(ts)
         w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
         g = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in grads])
         ws = _hip.workspace(lib.diffab_pair_embedding_bwd_workspace_bytes(C.byref(dims)))
@@ -362,7 +360,7 @@ class _PairEmbeddingFn(torch.autograd.Function):
                                                  _hip.ptr(dm if ctx.from_xyz else None), _hip.ptr(dh), _hip.ptr(ri), ctx.ri_stride, _hip.ptr(ch),
                                                  _hip.ptr(am), _hip.ptr(ctx.qm), _hip.ptr(do), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
                    "diffab_pair_embedding_bwd")
-        return (None,) * 10 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
+        return (None,) * 11 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
 
 
 class ResidueEmbedding(nn.Module):
@@ -390,7 +388,7 @@ class ResidueEmbedding(nn.Module):
         B, K = seq.shape
         dims = _hip.CtxDims(B, K, self.max_n_atoms_per_residue, self.d_feat, 1, 32)
         p = _named(self)
-        out = _ResidueEmbeddingFn.apply(dims, seq, x, O, dh, ch, am, sm, qm, *[p[k] for k in _RES_KEYS])
+        out = _ResidueEmbeddingFn.apply(self, dims, seq, x, O, dh, ch, am, sm, qm, *[p[k] for k in _RES_KEYS])
         return out.to(out_dev)
 
 
@@ -431,7 +429,8 @@ class PairEmbedding(nn.Module):
         p = _named(self)
         if ri.shape[0] not in (1, B):
             raise ValueError("residue_idx must be (1, K) or (B, K)")
-        out = _PairEmbeddingFn.apply(dims, from_xyz, seq, dm, dh, ri, K if ri.shape[0] == B else 0, ch, am, qm, *[p[k] for k in _PAIR_KEYS])
+        out = _PairEmbeddingFn.apply(self, dims, from_xyz, seq, dm, dh, ri, K if ri.shape[0] == B else 0, ch, am, qm,
+                                     *[p[k] for k in _PAIR_KEYS])
         return out.to(out_dev)
 
 
@@ -563,6 +562,12 @@ class DiffAb(_ModuleBase):
         self.log_dict({"val/seq_loss": seq_loss, "val/translations_loss": translations_loss, "val/orientations_loss": orientations_loss,
                        "val/loss": loss}, on_step=False, on_epoch=True, prog_bar=False, logger=True)
         return loss
+
+    def gradient_buckets(self):
+        """The flat fp32 buffers the last HIP backward wrote the parameter gradients into (denoiser, residue encoder, pair encoder):
+        after zero_grad(set_to_none=True) + backward every p.grad is a view of one of them.  distributed.allreduce_gradients
+        reduces them in place."""
+        return [getattr(m, "_flat_grad", None) for m in (self.denoiser, self.residue_context_embedding, self.pair_context_embedding)]
 
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay, betas=self.betas)

@@ -56,20 +56,43 @@ def gather_samples(local: Dict[str, torch.Tensor], dist=None, sizes: Optional[li
     return unpack_samples(torch.cat(parts))
 
 
-def allreduce_gradients(params, dist=None, average: bool = True) -> None:
-    """Data-parallel gradient exchange for the training step: ONE all-reduce (sum) of a flat fp32 bucket holding
-    every gradient (7.9 MB for the benchmark denoiser), then / world.  Each rank normalises its losses by its own number of
-    masked residues (reference diffab_pytorch.py:868-878 on the local shard), so this is the usual DDP mean of per-rank means.
-    On the 8-GPU xGMI mesh RCCL moves the single bucket over all 7 links of each GPU; no per-tensor collectives."""
+def allreduce_gradients(params, dist=None, average: bool = True, flats=None) -> None:
+    """Data-parallel gradient exchange for the training step: all-reduce (sum) of flat fp32 gradient buckets, then
+    / world.  Each rank normalises its losses by its own number of masked residues (reference diffab_pytorch.py:868-878 on the
+    local shard), so this is the usual DDP mean of per-rank means.
+
+    `flats`: the flat buffers the HIP backward passes wrote their gradients into (one per module: DiffAb.gradient_buckets()).
+    After `zero_grad(set_to_none=True)` every `p.grad` is a view of one of them, so they are reduced IN PLACE - three collectives
+    (7.9 MB denoiser + 1.5 MB + 0.7 MB encoders), no gather / scatter copies.  Gradients that are not views of a bucket (another
+    producer, accumulated grads) go through one packed bucket as before.  On the 8-GPU xGMI mesh RCCL moves each bucket over all 7
+    links of a GPU; no per-tensor collectives."""
     params = [p for p in params if p.grad is not None]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or not params:
         return
-    flat = torch.cat([p.grad.reshape(-1).float() for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    world = dist.get_world_size()
+    covered = set()
+    for flat in (flats or []):
+        if flat is None:
+            continue
+        base = flat.untyped_storage().data_ptr()
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        mine = [p for p in params if p.grad.untyped_storage().data_ptr() == base and lo <= p.grad.data_ptr() and
+                p.grad.data_ptr() + p.grad.numel() * p.grad.element_size() <= hi and p.grad.is_contiguous()]
+        if not mine:
+            continue
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= world
+        covered.update(id(p) for p in mine)
+    rest = [p for p in params if id(p) not in covered]
+    if not rest:
+        return
+    packed = torch.cat([p.grad.reshape(-1).float() for p in rest])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     if average:
-        flat /= dist.get_world_size()
+        packed /= world
     off = 0
-    for p in params:
+    for p in rest:
         n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        p.grad.copy_(packed[off:off + n].view_as(p.grad))
         off += n

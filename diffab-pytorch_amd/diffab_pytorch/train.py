@@ -15,9 +15,9 @@ Same command-line flags and the same model / optimiser construction as the refer
   parameter names of SURVEY Appendix B.3, so a reference checkpoint loads here and vice versa.
 
 Multi-GPU: one process per GPU under ``python -m torch.distributed.run`` (backend "nccl" = RCCL).  Patches are independent, so
-every rank runs forward + backward on its contiguous shard of each batch and the only exchange is ONE all-reduce of the flat
-gradient bucket per step (``distributed.allreduce_gradients``); parameters stay identical because every rank applies the same
-averaged gradient with the same optimiser state.
+every rank runs forward + backward on its contiguous shard of each batch and the only exchange is the all-reduce of the flat
+gradient buckets the HIP backward wrote (denoiser + the two encoders, reduced in place: ``distributed.allreduce_gradients``);
+parameters stay identical because every rank applies the same averaged gradient with the same optimiser state.
 """
 from __future__ import annotations
 
@@ -226,12 +226,12 @@ def main(argv: Optional[List[str]] = None) -> int:
         model.train()
         t0 = time.perf_counter()
         for i, batch in enumerate(train_src.batches(epoch)):
-            optimizer.zero_grad(set_to_none=False)
+            optimizer.zero_grad(set_to_none=True)  # the backward hands out views of its flat buckets as p.grad
             loss = model.training_step(to_dev(batch), i)
             if not bool(torch.isfinite(loss.detach())):
                 raise SystemExit(f"rank {rank}: non-finite loss {float(loss)} at epoch {epoch}, batch {i} (captured: {captured}) - aborting")
             loss.backward()
-            D.allreduce_gradients(model.parameters(), dist if world > 1 else None)
+            D.allreduce_gradients(model.parameters(), dist if world > 1 else None, flats=model.gradient_buckets())
             if args.gradient_clip_val:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), args.gradient_clip_val)
             optimizer.step()

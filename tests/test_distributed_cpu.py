@@ -95,6 +95,23 @@ def _grad_worker(rank, world, port, q):
                 acc += vals[i]
             want.append(acc / world)
         ok = all(torch.allclose(p.grad, w_, atol=1e-6) for p, w_ in zip(ps[:2], want)) and ps[2].grad is None
+        # flat buckets (what the HIP backward hands out): gradients that are views of a bucket are reduced IN PLACE, on the bucket,
+        # with no packed copy; a gradient outside every bucket still goes through the packed path in the same call
+        g = torch.Generator().manual_seed(200 + rank)
+        flat = torch.randn(64 + 64 + 64, generator=g)          # 3 aligned slots, the last one unused padding
+        loose = torch.randn(4, generator=g)
+        qs = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(4))]
+        qs[0].grad, qs[1].grad, qs[2].grad = flat[0:15].view(5, 3), flat[64:71], loose.clone()
+        ptrs = [p_.grad.data_ptr() for p_ in qs]
+        allreduce_gradients(qs, dist, flats=[flat, None])
+        tot_flat, tot_loose = torch.zeros(192), torch.zeros(4)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(200 + r)
+            tot_flat += torch.randn(192, generator=gr)
+            tot_loose += torch.randn(4, generator=gr)
+        ok = ok and torch.allclose(flat, tot_flat / world, atol=1e-6) and torch.allclose(qs[2].grad, tot_loose / world, atol=1e-6)
+        ok = ok and torch.allclose(qs[0].grad, (tot_flat / world)[0:15].view(5, 3), atol=1e-6)
+        ok = ok and ptrs == [p_.grad.data_ptr() for p_ in qs] and qs[0].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
