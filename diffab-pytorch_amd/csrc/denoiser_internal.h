@@ -56,6 +56,7 @@ void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime s
 // api.hip: opt-in hipEvent bracket around the dominant (attention) kernel
 void timer_begin(hipStream_t st);
 void timer_end(hipStream_t st);
+bool kernel_timer_enabled();
 
 // denoiser_backward.hip: saved activations of one training forward (every buffer written by the forward kernels themselves)
 constexpr int kMaxLayers = 16;
@@ -87,7 +88,10 @@ int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const f
 // diffusion_kernels.hip
 int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
                                  const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,
-                                 int64_t first_patch, int B, int K, int V, hipStream_t st);
-int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st);
+                                 int64_t first_patch, int B, int K, int V, hipStream_t st,
+                                 const int* t_dev = nullptr);  // t_dev: read the timestep from device memory (graph replay)
+int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st, const int* t_dev = nullptr);
+int launch_set_int(int* p, int v, hipStream_t st);
+int launch_dec_int(int* p, hipStream_t st);
 
 }  // namespace diffab

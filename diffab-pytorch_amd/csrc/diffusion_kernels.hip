@@ -505,9 +505,10 @@ __global__ void reverse_update_philox_kernel(const float* __restrict__ beta, con
                                              float thr, int64_t* __restrict__ seq, float* __restrict__ x, float* __restrict__ O,
                                              const float* __restrict__ eps_hat, const float* __restrict__ O0_hat,
                                              const float* __restrict__ post, const uint8_t* __restrict__ gm, uint64_t seed,
-                                             int64_t first_patch, int B, int K, int V) {
+                                             int64_t first_patch, int B, int K, int V, const int* __restrict__ t_dev) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= static_cast<int64_t>(B) * K || !gm[i]) return;
+  if (t_dev != nullptr) t = *t_dev;  // graph replay: the timestep lives in device memory (one captured step serves every t)
   const uint32_t patch = static_cast<uint32_t>(first_patch + i / K), res = static_cast<uint32_t>(i % K), st = static_cast<uint32_t>(t);
   const f32x4 zt = philox_normal4(seed, patch, res, st, STREAM_TRANS);
   f32x4 ax = philox_normal4(seed, patch, res, st, STREAM_AXIS);
@@ -538,19 +539,22 @@ __global__ void sample_init_kernel(int64_t* __restrict__ seq, float* __restrict_
   seq[i] = min(static_cast<int>(us.x * 20.0f), 19);
 }
 
-__global__ void fill_beta_kernel(const float* __restrict__ beta, int t, int B, float* __restrict__ out) {
+__global__ void fill_beta_kernel(const float* __restrict__ beta, int t, int B, float* __restrict__ out, const int* __restrict__ t_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t_dev != nullptr) t = *t_dev;
   if (i < B) out[i] = beta[t];
 }
+__global__ void set_int_kernel(int* __restrict__ p, int v) { *p = v; }
+__global__ void dec_int_kernel(int* __restrict__ p) { *p -= 1; }
 
 // launchers used by api.hip (sample loop)
 int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
                                  const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,
-                                 int64_t first_patch, int B, int K, int V, hipStream_t st) {
+                                 int64_t first_patch, int B, int K, int V, hipStream_t st, const int* t_dev) {
   const int64_t n = static_cast<int64_t>(B) * K;
   hipLaunchKernelGGL(reverse_update_philox_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, st, s->beta, s->alpha,
                      s->one_minus_alpha_bar_sqrt, t, tab->sigmas, tab->cdf, tab->n_bins, tab->sigma_threshold, seq, x, O, eps_hat, O0_hat,
-                     post, gm, seed, first_patch, B, K, V);
+                     post, gm, seed, first_patch, B, K, V, t_dev);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -569,8 +573,18 @@ int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const f
   return DIFFAB_OK;
 }
 
-int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(fill_beta_kernel, dim3((B + 255) / 256), dim3(256), 0, st, s->beta, t, B, out);
+int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st, const int* t_dev) {
+  hipLaunchKernelGGL(fill_beta_kernel, dim3((B + 255) / 256), dim3(256), 0, st, s->beta, t, B, out, t_dev);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+int launch_set_int(int* p, int v, hipStream_t st) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, p, v);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+int launch_dec_int(int* p, hipStream_t st) {
+  hipLaunchKernelGGL(dec_int_kernel, dim3(1), dim3(1), 0, st, p);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

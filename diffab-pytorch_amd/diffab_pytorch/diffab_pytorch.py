@@ -578,7 +578,7 @@ class DiffAb(_ModuleBase):
                res_context_emb=None, pair_context_emb=None, residue_mask=None, backbone_dihedrals=None, pairwise_dihedrals=None,
                distmat=None, atom_mask=None, chain_idx=None, residue_idx=None, generate_structure: bool = True,
                generate_sequence: bool = True, seed: Optional[int] = None, first_patch: int = 0, t_start: Optional[int] = None,
-               t_stop: int = 0, init: bool = True, flags: int = 0) -> Dict[str, torch.Tensor]:
+               t_stop: int = 0, init: bool = True, flags: int = 0, graph: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """Reverse diffusion t_start .. t_stop+1 (default T .. 1) on the generated residues (the reference's `sample` is a stub,
         diffab_pytorch.py:770-776; the loop is build-defined).
 
@@ -588,7 +588,11 @@ class DiffAb(_ModuleBase):
         (backbone_dihedrals, pairwise_dihedrals, atom_mask, chain_idx; residue_idx and residue_mask default to
         arange(K) and all-true; distmat is taken from xyz on the device when absent) and `encode_context` runs first, once.
         Noise is Philox keyed by (seed, first_patch + b, residue, t): any sharding of a batch over ranks gives
-        the same samples.  All T steps are enqueued on the current stream by ONE C-ABI call, no host sync."""
+        the same samples.  All T steps are enqueued on the current stream by ONE C-ABI call, no host sync.
+        ``graph=True``: replay one captured step as a hipGraph instead of ~45 launches per step (same kernels, bitwise the same
+        result; the call then waits for the trajectory).  Off by default: measured at BASELINE config 1 (B = 1, K = 128, 100 steps)
+        it changes nothing - 145 ms eager, 146 ms replayed - because the host already runs ahead of the device there; a step is a
+        chain of ~45 dependent kernels on 8-work-group grids (1.45 ms), not 45 launch overheads."""
         if generation_mask is None:
             raise ValueError("sample() needs generation_mask: which residues to generate")
         if res_context_emb is None or pair_context_emb is None:
@@ -621,6 +625,8 @@ class DiffAb(_ModuleBase):
         sd = self._sched_on_device()
         tab = self._reverse_so3().struct()
         ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(dims)))
+        if graph:
+            flags |= _hip.FLAG_GRAPH_SAMPLER
         if init:
             _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, self.T,
                                               _hip.stream_ptr()), "diffab_sample_init")

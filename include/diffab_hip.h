@@ -47,6 +47,12 @@ extern "C" {
 #define DIFFAB_FLAG_FLASH_ATTENTION 8u /* K = 64 / 128: the attention of each layer as a key-tile pipeline with an online softmax
                                           (csrc/attention_flash.hip) instead of the three-phase kernel; same results to rounding */
 
+#define DIFFAB_FLAG_GRAPH_SAMPLER 16u /* diffab_sample_loop: capture one reverse step into a hipGraph (timestep read from device memory)
+                                         and replay it for the remaining steps - one host call per step instead of ~45.  Bitwise the
+                                         eager trajectory.  The call drains its private replay stream before it returns (the graph
+                                         must outlive its launches).  Measured at B = 1, K = 128: no gain (the host already runs
+                                         ahead of the device; a step is 45 dependent small-grid kernels), hence opt-in. */
+
 /* Model and batch geometry.  Reference ctor: diffab_pytorch.py:629-647. */
 typedef struct {
   int32_t B;  /* patches in this call */

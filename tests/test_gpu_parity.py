@@ -548,6 +548,41 @@ def test_sample_loop_shard_invariance_and_determinism(hip):
     assert not torch.equal(other["translations"], full["translations"])
 
 
+def test_graph_sampler_is_bitwise_the_eager_sampler(hip):
+    """DIFFAB_FLAG_GRAPH_SAMPLER: one captured reverse step (timestep in device memory) replayed as a hipGraph = the eager loop, bit
+    for bit, on the generic path (unit dims) and on the MFMA path at BASELINE config 1's shape (B = 1, K = 128, 100 steps)."""
+    from diffab_pytorch import DiffAb
+
+    dims, model, _ = _unit_model()
+    inp = syn.patches(3, 16, dims, seed=21, coord_sigma=5.0)
+    kw = dict(res_context_emb=inp["res_context_emb"], pair_context_emb=inp["pair_context_emb"], generation_mask=inp["generation_mask"], seed=77)
+    eager = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], graph=False, **kw)
+    graph = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], graph=True, **kw)
+    for k in eager:
+        assert torch.equal(eager[k], graph[k]), k
+    part = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], graph=True, t_start=60, t_stop=55, init=False, **kw)
+    want = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], graph=False, t_start=60, t_stop=55, init=False, **kw)
+    for k in part:
+        assert torch.equal(part[k], want[k]), k
+    bd = dict(syn.BENCH_DIMS)
+    torch.manual_seed(0)
+    big = DiffAb(bd["D"], bd["C"], bd["NL"], bd["DS"], bd["PQ"], bd["PV"], bd["H"]).cuda()
+    bi = {k: v.cuda() for k, v in syn.patches(1, 128, bd, seed=22).items()}
+    kw = dict(res_context_emb=bi["res_context_emb"], pair_context_emb=bi["pair_context_emb"], generation_mask=bi["generation_mask"], seed=5)
+    import time
+    res = {}
+    for mode in (False, True, False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = big.sample(bi["seq_idx"], bi["translations"], bi["orientations"], graph=mode, **kw)
+        torch.cuda.synchronize()
+        res[mode] = (out, time.perf_counter() - t0)
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert torch.isfinite(res[True][0]["translations"]).all()
+    print("config 1 (B=1, K=128, 100 steps): eager %.1f ms, graph replay %.1f ms" % (1e3 * res[False][1], 1e3 * res[True][1]))
+
+
 def test_shared_step_and_add_noise(hip):
     dims, model, sd = _unit_model()
     B, K = 4, 16
