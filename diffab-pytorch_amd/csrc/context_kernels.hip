@@ -144,6 +144,93 @@ __global__ void pair_mask_kernel(float* __restrict__ out, const float* __restric
   out[gid] *= amask[(b * K + i) * A + kCA] * amask[(b * K + j) * A + kCA];
 }
 
+// ------------------------------------------------------------------ featurisation from coordinates
+// What the reference's data layer computes with protstruc before a batch reaches the model (data.py:75-82, preprocess_pdb.py:60-65):
+// backbone orientations, backbone dihedrals (+ mask) and the pairwise phi / psi dihedrals.  protstruc is not in the reference tree, so
+// these follow the geometric definitions (stated at each kernel) and parity with protstruc is UNPINNED; the oracle restates the same
+// definitions in float64.  Atom slots: N = 0, CA = 1, C = 2 (protstruc.general.ATOM).
+__device__ inline void v3_load(const float* p, float* o) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+__device__ inline void v3_sub(const float* a, const float* b, float* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+__device__ inline float v3_dot(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ inline void v3_cross(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// IUPAC dihedral of four points: angle between the planes (p0,p1,p2) and (p1,p2,p3), atan2(|b1| b0.(b1 x b2), (b0 x b1).(b1 x b2)),
+// b_k = p_{k+1} - p_k; in (-pi, pi], 0 for cis, pi for trans
+__device__ inline float dihedral4(const float* p0, const float* p1, const float* p2, const float* p3) {
+  float b0[3], b1[3], b2[3], n1[3], n2[3];
+  v3_sub(p1, p0, b0);
+  v3_sub(p2, p1, b1);
+  v3_sub(p3, p2, b2);
+  v3_cross(b0, b1, n1);
+  v3_cross(b1, b2, n2);
+  const float y = sqrtf(v3_dot(b1, b1)) * v3_dot(b0, n2);
+  const float x = v3_dot(n1, n2);
+  return atan2f(y, x);
+}
+
+// one thread per residue: frame with origin CA, rows of R = local axes in global coordinates (x along CA->C, y in the N-CA-C plane
+// towards N, z = x cross y: the Gram-Schmidt frame of io.frames_from_backbone, `global = local @ R + t` as the hot path uses it);
+// backbone dihedrals (phi, psi, omega) with their validity mask: phi_i = (C_{i-1}, N_i, CA_i, C_i), psi_i = (N_i, CA_i, C_i, N_{i+1}),
+// omega_i = (CA_i, C_i, N_{i+1}, CA_{i+1}); a dihedral is valid when both residues exist, are in the same chain and are consecutive
+// in the patch (angle 0 where invalid)
+__global__ void featurize_residue_kernel(const float* __restrict__ xyz, const int64_t* __restrict__ chain, const uint8_t* __restrict__ rmask,
+                                         int K, int A, int64_t rows, float* __restrict__ R, float* __restrict__ dih,
+                                         uint8_t* __restrict__ dih_mask) {
+  const int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (r >= rows) return;
+  const float* at = xyz + r * A * 3;
+  float n[3], ca[3], c[3];
+  v3_load(at, n);
+  v3_load(at + 3, ca);
+  v3_load(at + 6, c);
+  if (R != nullptr) {
+    float e1[3], u[3], e2[3], e3[3];
+    v3_sub(c, ca, e1);
+    float inv = 1.0f / fmaxf(sqrtf(v3_dot(e1, e1)), 1e-12f);
+    for (int k = 0; k < 3; ++k) e1[k] *= inv;
+    v3_sub(n, ca, u);
+    const float pr = v3_dot(e1, u);
+    for (int k = 0; k < 3; ++k) u[k] -= pr * e1[k];
+    inv = 1.0f / fmaxf(sqrtf(v3_dot(u, u)), 1e-12f);
+    for (int k = 0; k < 3; ++k) e2[k] = u[k] * inv;
+    v3_cross(e1, e2, e3);
+    float* o = R + r * 9;
+    for (int k = 0; k < 3; ++k) { o[k] = e1[k]; o[3 + k] = e2[k]; o[6 + k] = e3[k]; }
+  }
+  if (dih != nullptr) {
+    const int l = static_cast<int>(r % K);
+    const bool me = rmask ? rmask[r] != 0 : true;
+    const bool prev_ok = me && l > 0 && (rmask ? rmask[r - 1] != 0 : true) && (chain ? chain[r - 1] == chain[r] : true);
+    const bool next_ok = me && l + 1 < K && (rmask ? rmask[r + 1] != 0 : true) && (chain ? chain[r + 1] == chain[r] : true);
+    float phi = 0.f, psi = 0.f, omg = 0.f;
+    if (prev_ok) phi = dihedral4(at - A * 3 + 6, n, ca, c);
+    if (next_ok) {
+      psi = dihedral4(n, ca, c, at + A * 3);
+      omg = dihedral4(ca, c, at + A * 3, at + A * 3 + 3);
+    }
+    dih[r * 3 + 0] = phi; dih[r * 3 + 1] = psi; dih[r * 3 + 2] = omg;
+    if (dih_mask) { dih_mask[r * 3 + 0] = prev_ok; dih_mask[r * 3 + 1] = next_ok; dih_mask[r * 3 + 2] = next_ok; }
+  }
+}
+
+// one thread per residue pair (i, j): phi_ij = (C_i, N_j, CA_j, C_j), psi_ij = (N_i, CA_i, C_i, N_j)   (data.py:78-80:
+// pairwise_dihedrals(atoms_i=["C"], atoms_j=["N","CA","C"]) and (atoms_i=["N","CA","C"], atoms_j=["N"]))
+__global__ void featurize_pair_kernel(const float* __restrict__ xyz, int K, int A, int64_t pairs, float* __restrict__ out) {
+  const int64_t g = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (g >= pairs) return;
+  const int64_t b = g / (static_cast<int64_t>(K) * K);
+  const int i = static_cast<int>((g / K) % K), j = static_cast<int>(g % K);
+  const float* ai = xyz + (b * K + i) * A * 3;
+  const float* aj = xyz + (b * K + j) * A * 3;
+  float2 o;
+  o.x = dihedral4(ai + 6, aj, aj + 3, aj + 6);
+  o.y = dihedral4(ai, ai + 3, ai + 6, aj);
+  reinterpret_cast<float2*>(out)[g] = o;
+}
+
 // ------------------------------------------------------------------ backward (training through encode_context)
 // The reference cannot back-propagate through PairEmbedding: `distmat = torch.exp(...)` is multiplied IN PLACE by the structure
 // mask after the distance MLP has saved it (diffab_pytorch.py:295-301), which autograd rejects.  The fix-forward is an
@@ -535,6 +622,27 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
   hipLaunchKernelGGL(softplus_bwd_kernel, dim3((kAA * kAA * AA2 + 255) / 256), dim3(256), 0, st, w->pair2distcoef, g_sp, kAA * kAA * AA2,
                      mut(g->pair2distcoef));
   DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_featurize_xyz(const float* xyz, const int64_t* chain_idx, const uint8_t* residue_mask, int32_t B, int32_t K, int32_t A,
+                         float* orientations, float* backbone_dihedrals, uint8_t* backbone_dihedrals_mask, float* pairwise_dihedrals,
+                         void* stream) {
+  DIFFAB_REQUIRE(xyz && B > 0 && K > 0 && A >= 3, DIFFAB_ERR_ARG, "featurize_xyz: bad argument (needs the N, CA, C slots: A >= 3)");
+  DIFFAB_REQUIRE(orientations || backbone_dihedrals || pairwise_dihedrals, DIFFAB_ERR_ARG, "featurize_xyz: no output requested");
+  hipStream_t st = as_stream(stream);
+  const int64_t rows = static_cast<int64_t>(B) * K;
+  if (orientations || backbone_dihedrals) {
+    hipLaunchKernelGGL(featurize_residue_kernel, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, st, xyz, chain_idx,
+                       residue_mask, K, A, rows, orientations, backbone_dihedrals, backbone_dihedrals_mask);
+    DIFFAB_LAUNCH_CHECK();
+  }
+  if (pairwise_dihedrals) {
+    const int64_t pairs = rows * K;
+    hipLaunchKernelGGL(featurize_pair_kernel, dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, st, xyz, K, A, pairs,
+                       pairwise_dihedrals);
+    DIFFAB_LAUNCH_CHECK();
+  }
   return DIFFAB_OK;
 }
 

@@ -126,6 +126,7 @@ SYMBOLS = {
     "diffab_pair_embedding_bwd_workspace_bytes": (_sz, [C.POINTER(CtxDims)]),
     "diffab_pair_embedding_bwd": (C.c_int, [C.POINTER(CtxDims), C.POINTER(PairEmbWeights), C.POINTER(PairEmbWeights), _fp, _fp, _fp, _fp, _fp,
                                             _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "diffab_featurize_xyz": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
     "diffab_orientation_loss": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp]),
     "diffab_reverse_update": (C.c_int, [_PS, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "diffab_sample_loop": (C.c_int, [_PD, C.POINTER(DenoiserWeights), _PS, _PI, _fp, _fp, _fp, _fp, _fp, _fp, _u64, _i64, _i32,

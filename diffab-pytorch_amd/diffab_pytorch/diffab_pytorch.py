@@ -23,6 +23,7 @@ import torch.nn as nn
 from . import _hip
 from .diffusion import CoordinateDiffuser, OrientationDiffuser, SequenceDiffuser, cosine_variance_schedule
 from . import so3 as _so3
+from . import features as _features
 
 try:  # LightningModule hooks when Lightning is installed; a plain nn.Module otherwise
     import pytorch_lightning as pl
@@ -532,11 +533,17 @@ class DiffAb(_ModuleBase):
         t = torch.randint(low=1, high=self.T + 1, size=(bsz,)).to(dev_in)
         beta = self.sched["beta"][t.cpu()].to(dev_in)
         xyz_t0 = batch["xyz"]
+        if "orientations" not in batch and xyz_t0.dim() == 4:  # frames from the backbone atoms
+            batch = dict(batch, **_features.featurize(xyz_t0, orientations=True, backbone_dihedrals=False, pairwise_dihedrals=False))
         translations_t0 = xyz_t0[:, :, CA_IDX] if xyz_t0.dim() == 4 else xyz_t0
         noised = self._add_noise(batch["seq_idx"], translations_t0, batch["orientations"], batch["generation_mask"], t)
         if "res_context_emb" in batch and "pair_context_emb" in batch:
             res_ctx, pair_ctx = batch["res_context_emb"], batch["pair_context_emb"]
         else:
+            if "backbone_dihedrals" not in batch or "pairwise_dihedrals" not in batch:  # from xyz, on the device
+                batch = dict(batch, **_features.featurize(xyz_t0, batch["chain_idx"], batch["residue_mask"], orientations=False,
+                                                          backbone_dihedrals="backbone_dihedrals" not in batch,
+                                                          pairwise_dihedrals="pairwise_dihedrals" not in batch))
             res_ctx, pair_ctx = self.encode_context(batch["seq_idx"], xyz_t0, batch["orientations"], batch["backbone_dihedrals"],
                                                     batch.get("distmat"), batch["pairwise_dihedrals"], batch["atom_mask"], batch["chain_idx"],
                                                     batch["residue_idx"], batch["generation_mask"], batch["residue_mask"])
@@ -585,8 +592,8 @@ class DiffAb(_ModuleBase):
         seq_idx (B,K), xyz (B,K,3) CA translations or (B,K,A,3) atoms, orientations (B,K,3,3): the ground-truth
         context; generated residues are re-initialised (x ~ N(0,I), O ~ U(SO3), s ~ U{0..19}) when ``init``.
         Contexts: pass ``res_context_emb`` / ``pair_context_emb``, or the remaining fields of the reference's batch dict
-        (backbone_dihedrals, pairwise_dihedrals, atom_mask, chain_idx; residue_idx and residue_mask default to
-        arange(K) and all-true; distmat is taken from xyz on the device when absent) and `encode_context` runs first, once.
+        (SURVEY B.2): atom_mask and chain_idx; residue_idx and residue_mask default to arange(K) and all-true; distmat and the two
+        dihedral features are taken from xyz on the device when absent (features.featurize) - and `encode_context` runs first, once.
         Noise is Philox keyed by (seed, first_patch + b, residue, t): any sharding of a batch over ranks gives
         the same samples.  All T steps are enqueued on the current stream by ONE C-ABI call, no host sync.
         ``graph=True``: replay one captured step as a hipGraph instead of ~45 launches per step (same kernels, bitwise the same
@@ -596,8 +603,7 @@ class DiffAb(_ModuleBase):
         if generation_mask is None:
             raise ValueError("sample() needs generation_mask: which residues to generate")
         if res_context_emb is None or pair_context_emb is None:
-            need = {"backbone_dihedrals": backbone_dihedrals, "pairwise_dihedrals": pairwise_dihedrals, "atom_mask": atom_mask,
-                    "chain_idx": chain_idx}
+            need = {"atom_mask": atom_mask, "chain_idx": chain_idx}
             missing = [k for k, v in need.items() if v is None]
             if missing or xyz.dim() != 4:
                 raise ValueError("sample(): without res_context_emb / pair_context_emb the contexts are computed by encode_context, "
@@ -606,6 +612,11 @@ class DiffAb(_ModuleBase):
             Bq, Kq = seq_idx.shape
             if residue_mask is None:
                 residue_mask = torch.ones(Bq, Kq, dtype=torch.bool, device=seq_idx.device)
+            if backbone_dihedrals is None or pairwise_dihedrals is None:  # dihedral features from the coordinates, on the device
+                feats = _features.featurize(xyz, chain_idx, residue_mask, orientations=False, backbone_dihedrals=backbone_dihedrals is None,
+                                            pairwise_dihedrals=pairwise_dihedrals is None)
+                backbone_dihedrals = feats.get("backbone_dihedrals", backbone_dihedrals)
+                pairwise_dihedrals = feats.get("pairwise_dihedrals", pairwise_dihedrals)
             if residue_idx is None:
                 residue_idx = torch.arange(Kq, device=seq_idx.device).unsqueeze(0)  # data.py:91
             res_context_emb, pair_context_emb = self.encode_context(seq_idx, xyz, orientations, backbone_dihedrals, distmat,

@@ -280,6 +280,16 @@ int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_em
                                   const float* atom_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
                                   size_t workspace_bytes, void* stream);
 
+/* Featurisation from coordinates (what the reference's data layer computes with protstruc: data.py:75-82, preprocess_pdb.py:60-65):
+ * backbone orientations (B,K,3,3) (rows = the residue's local axes: x along CA->C, y in the N-CA-C plane towards N; `global = local @ R
+ * + t`), backbone dihedrals (B,K,3) = (phi, psi, omega) with their validity mask (B,K,3), and pairwise dihedrals (B,K,K,2):
+ * phi_ij = (C_i, N_j, CA_j, C_j), psi_ij = (N_i, CA_i, C_i, N_j), IUPAC sign.  Any output may be NULL; chain_idx / residue_mask
+ * may be NULL (one chain, every residue present).  xyz is (B,K,A,3) with atoms N, CA, C in slots 0, 1, 2.
+ * protstruc is not part of the reference tree: these are the geometric definitions, parity with protstruc is unpinned. */
+int diffab_featurize_xyz(const float* xyz, const int64_t* chain_idx, const uint8_t* residue_mask, int32_t B, int32_t K, int32_t A,
+                         float* orientations, float* backbone_dihedrals, uint8_t* backbone_dihedrals_mask,
+                         float* pairwise_dihedrals, void* stream);
+
 /* Backward of the two context encoders (training through encode_context, diffab_pytorch.py:843-854 under autograd).
  * d_out is the gradient w.r.t. the module output; parameter gradients ACCUMULATE (+=) into the buffers of `g`, which has the
  * layout of the weight struct (the caller zero-fills them).  Inputs other than parameters take no gradient.  Nothing is taped:

@@ -575,3 +575,48 @@ def encode_context(sd, batch, generate_structure=True, generate_sequence=True, m
     pair = pair_embedding(sd, batch["seq_idx"], batch["distmat"], batch["pairwise_dihedrals"], batch["residue_idx"], batch["chain_idx"],
                           batch["atom_mask"], sm, qm, max_dist)
     return res, pair
+
+
+# --------------------------------------------------------------------------
+# featurisation from coordinates        reference: data.py:75-82, preprocess_pdb.py:60-65 (protstruc calls)
+# --------------------------------------------------------------------------
+# protstruc is not in the reference tree: these are the geometric definitions the HIP kernels implement (include/diffab_hip.h,
+# diffab_featurize_xyz), restated in float64.  PARITY UNPINNED against protstruc's own conventions.
+
+def dihedral(p0, p1, p2, p3):
+    """IUPAC dihedral of four points (..., 3): atan2(|b1| b0.(b1 x b2), (b0 x b1).(b1 x b2))."""
+    b0, b1, b2 = p1 - p0, p2 - p1, p3 - p2
+    n1, n2 = torch.cross(b0, b1, dim=-1), torch.cross(b1, b2, dim=-1)
+    y = b1.norm(dim=-1) * (b0 * n2).sum(-1)
+    x = (n1 * n2).sum(-1)
+    return torch.atan2(y, x)
+
+
+def featurize_xyz(xyz, chain_idx=None, residue_mask=None):
+    """xyz (B,K,A,3), atoms N, CA, C in slots 0..2 -> orientations (rows = local axes, Gram-Schmidt on CA->C then CA->N), backbone
+    (phi, psi, omega) + mask, pairwise (phi_ij, psi_ij) = ((C_i,N_j,CA_j,C_j), (N_i,CA_i,C_i,N_j))."""
+    x = xyz.double()
+    B, K = x.shape[:2]
+    n, ca, c = x[:, :, 0], x[:, :, 1], x[:, :, 2]
+    e1 = torch.nn.functional.normalize(c - ca, dim=-1)
+    u = (n - ca) - ((n - ca) * e1).sum(-1, keepdim=True) * e1
+    e2 = torch.nn.functional.normalize(u, dim=-1)
+    e3 = torch.cross(e1, e2, dim=-1)
+    O = torch.stack([e1, e2, e3], dim=-2)
+    rm = torch.ones(B, K, dtype=torch.bool) if residue_mask is None else residue_mask.bool()
+    ch = torch.zeros(B, K, dtype=torch.long) if chain_idx is None else chain_idx
+    link = rm[:, :-1] & rm[:, 1:] & (ch[:, :-1] == ch[:, 1:])  # residues l and l+1 are consecutive members of one chain
+    prev_ok = torch.cat([torch.zeros(B, 1, dtype=torch.bool), link], 1)
+    next_ok = torch.cat([link, torch.zeros(B, 1, dtype=torch.bool)], 1)
+    z3 = torch.zeros(B, 1, 3, dtype=x.dtype)
+    c_prev = torch.cat([z3, c[:, :-1]], 1)
+    n_next = torch.cat([n[:, 1:], z3], 1)
+    ca_next = torch.cat([ca[:, 1:], z3], 1)
+    phi = torch.where(prev_ok, dihedral(c_prev, n, ca, c), torch.zeros(B, K, dtype=x.dtype))
+    psi = torch.where(next_ok, dihedral(n, ca, c, n_next), torch.zeros(B, K, dtype=x.dtype))
+    omg = torch.where(next_ok, dihedral(ca, c, n_next, ca_next), torch.zeros(B, K, dtype=x.dtype))
+    pphi = dihedral(c[:, :, None], n[:, None, :], ca[:, None, :], c[:, None, :])
+    ppsi = dihedral(n[:, :, None], ca[:, :, None], c[:, :, None], n[:, None, :])
+    return {"orientations": O, "backbone_dihedrals": torch.stack([phi, psi, omg], -1),
+            "backbone_dihedrals_mask": torch.stack([prev_ok, next_ok, next_ok], -1),
+            "pairwise_dihedrals": torch.stack([pphi.expand(B, K, K), ppsi.expand(B, K, K)], -1)}

@@ -884,6 +884,45 @@ def test_full_training_step_updates_every_parameter(hip):
     print(f"full training step: {n_params} parameters, {enc} of them in the context encoders, all moved")
 
 
+def test_featurize_xyz_vs_oracle_and_minimal_batch(hip):
+    """orientations, backbone dihedrals (+ mask) and pairwise dihedrals from xyz on the device against the oracle's
+    float64 statement of the same definitions (parity with protstruc itself is unpinned: it is not in the reference tree); then a
+    training step and a sampling call on a batch that carries nothing but coordinates, sequence, masks and chain ids."""
+    from diffab_pytorch import DiffAb, features, io
+
+    cb = syn.context_batch(3, 64, 15, seed=11)
+    rmask = cb["residue_mask"].clone()
+    rmask[0, 10] = False
+    f = features.featurize(cb["xyz"].cuda(), cb["chain_idx"].cuda(), rmask.cuda())
+    want = orc.featurize_xyz(cb["xyz"], cb["chain_idx"], rmask)
+    # fp32 differences of coordinates tens of Angstrom from the origin carry ~3e-6 relative error before the Gram-Schmidt step
+    assert f["orientations"].is_cuda and maxrel(f["orientations"], want["orientations"]) < 5e-5
+    Rd = f["orientations"].double().cpu()
+    orth = (Rd @ Rd.transpose(-1, -2) - torch.eye(3, dtype=torch.float64)).abs().flatten(-2).max(-1).values
+    # (the synthetic atoms are scattered at random: a few N-CA-C triples are nearly collinear, where Gram-Schmidt in fp32 loses digits)
+    assert float(orth.median()) < 1e-6 and float(orth.max()) < 2e-4, (float(orth.median()), float(orth.max()))
+    assert torch.equal(f["backbone_dihedrals_mask"].cpu(), want["backbone_dihedrals_mask"])
+    for k in ("backbone_dihedrals", "pairwise_dihedrals"):  # compare on the circle: +-pi are the same angle
+        d = (f[k].cpu().double() - want[k]).abs()
+        d = torch.minimum(d, 2 * np.pi - d)
+        assert float(d.max()) < 2e-4, (k, float(d.max()))  # fp32 atan2 of fp32 cross products: near-planar quadruples lose a few digits
+        assert float(d.median()) < 1e-6, (k, float(d.median()))
+    # frames are the exact inverse of the output side's reconstruction
+    back = io.backbone_from_frames(cb["xyz"][:, :, 1].cuda(), f["orientations"], atoms=("N", "CA", "C"))
+    n_ca = (cb["xyz"][:, :, 0] - cb["xyz"][:, :, 1]).norm(dim=-1).cuda()
+    assert torch.allclose((back[:, :, 2] - back[:, :, 1]).norm(dim=-1), torch.full_like(n_ca, 1.526), atol=1e-4)
+    # minimal batch: no orientations, no dihedral features, no distance tensor
+    d = syn.BENCH_DIMS
+    torch.manual_seed(0)
+    model = DiffAb(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    batch = {k: cb[k].cuda() for k in ("seq_idx", "xyz", "atom_mask", "chain_idx", "residue_idx", "residue_mask", "generation_mask")}
+    loss = model.training_step(batch, 0)
+    assert torch.isfinite(loss) and loss.requires_grad
+    out = model.sample(batch["seq_idx"], batch["xyz"], f["orientations"], generation_mask=batch["generation_mask"],
+                       atom_mask=batch["atom_mask"], chain_idx=batch["chain_idx"], residue_mask=batch["residue_mask"], seed=3, t_start=100, t_stop=96)
+    assert torch.isfinite(out["translations"]).all()
+
+
 def test_encode_context_benchmark_dims_and_end_to_end(hip):
     """Benchmark model (D=128, C=64, A=15), K=64, vs the oracle; then the whole chain on the device: encode_context ->
     _shared_step (no precomputed contexts) -> sample."""

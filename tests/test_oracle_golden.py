@@ -171,3 +171,37 @@ def test_encode_context_oracle_vs_golden(golden):
     # the flags matter (sequence masking changes both outputs, structure masking only the residue embedding)
     assert not np.allclose(g["res_11"], g["res_01"]) and not np.allclose(g["res_11"], g["res_10"])
     assert not np.allclose(g["pair_11"], g["pair_10"]) and np.array_equal(g["pair_11"], g["pair_01"])
+
+
+def test_featurize_xyz_definitions():
+    """SURVEY 8 row f2 (parity with protstruc UNPINNED): the oracle's geometric definitions against known answers - frames are
+    the exact inverse of io.backbone_from_frames, a trans / cis / +90 degree dihedral, and the chain-break mask."""
+    from diffab_pytorch import io
+
+    g = torch.Generator().manual_seed(4)
+    B, K = 2, 7
+    t = 10 * torch.randn(B, K, 3, generator=g, dtype=torch.float64)
+    O = orc.uniform_rotation_from_normals(torch.randn(B, K, 4, generator=g)).double()
+    xyz = io.backbone_from_frames(t, O)  # (B,K,5,3): N, CA, C, O, CB
+    chain = torch.tensor([[1, 1, 1, 2, 2, 2, 2], [1, 1, 1, 1, 1, 1, 1]])
+    rmask = torch.ones(B, K, dtype=torch.bool)
+    rmask[1, 4] = False
+    f = orc.featurize_xyz(xyz, chain, rmask)
+    assert torch.allclose(f["orientations"], O, atol=1e-6)  # (O itself is orthonormal to fp32 only) exact inverse of the reconstruction used on the output side
+    m = f["backbone_dihedrals_mask"]
+    assert m[0, :, 0].tolist() == [False, True, True, False, True, True, True]   # phi needs residue l-1 in the same chain
+    assert m[0, :, 1].tolist() == [True, True, False, True, True, True, False]   # psi / omega need residue l+1
+    assert m[1, :, 1].tolist() == [True, True, True, False, False, True, False]  # a missing residue breaks both neighbours
+    assert torch.equal(m[..., 1], m[..., 2]) and (f["backbone_dihedrals"][~m] == 0).all()
+    p = lambda *v: torch.tensor(v, dtype=torch.float64)
+    assert abs(float(orc.dihedral(p(1, 1, 0), p(0, 1, 0), p(0, 0, 0), p(-1, 0, 0))) - np.pi) < 1e-12  # trans
+    assert abs(float(orc.dihedral(p(1, 1, 0), p(0, 1, 0), p(0, 0, 0), p(1, 0, 0)))) < 1e-12          # cis
+    assert abs(abs(float(orc.dihedral(p(1, 1, 0), p(0, 1, 0), p(0, 0, 0), p(0, 0, 1)))) - np.pi / 2) < 1e-12
+    # pairwise: the (i, i+1) psi entry is the backbone psi, the (i-1, i) phi entry the backbone phi (same four atoms)
+    pd, bd = f["pairwise_dihedrals"], f["backbone_dihedrals"]
+    for l in range(K - 1):
+        assert abs(float(pd[1, l, l + 1, 1]) - float(orc.dihedral(xyz[1, l, 0], xyz[1, l, 1], xyz[1, l, 2], xyz[1, l + 1, 0]))) < 1e-12
+        if m[1, l, 1]:
+            assert abs(float(pd[1, l, l + 1, 1]) - float(bd[1, l, 1])) < 1e-12
+        if m[1, l + 1, 0]:
+            assert abs(float(pd[1, l, l + 1, 0]) - float(bd[1, l + 1, 0])) < 1e-12
