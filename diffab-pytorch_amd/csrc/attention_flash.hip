@@ -26,6 +26,7 @@
 //
 // Numerics: online softmax = the reference's softmax up to fp32 rounding (running maximum instead of the row maximum; every
 // partial sum rescaled by exp(m_old - m_new)); deterministic (no atomics), independent of the batch composition.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -452,6 +453,399 @@ __global__ __launch_bounds__(512) void ipa_attn_flash_kernel(const float* __rest
   stamp(5);
 }
 
+// Sixteen-wave form of the same pipeline: waves 0-7 run B only (two rows each), waves 8-15 run A and C only (one head each), 128
+// registers per wave, four waves per SIMD - twice as many instruction streams for the scheduler to interleave as in the eight-wave
+// form above, where matrix, vector and LDS work of the two co-resident waves was measured to add up rather than overlap.
+template <int NT>
+__global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __restrict__ proj, const float* __restrict__ e,
+                                                                const float* __restrict__ R, const float* __restrict__ t,
+                                                                const float* __restrict__ Wb, const float* __restrict__ gamma,
+                                                                float* __restrict__ feat, int B, unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = NT * 16;
+  constexpr int ntile = K / TI;
+  constexpr int NRS = 2 * NT;  // row-steps of a wave: (key tile jt, row ii) = rs = 2 jt + ii
+  // XCD-aware map (blocks b and b + 8 share an XCD): all row tiles of a patch on one XCD, so the K/V side is an L2 hit for 7 of 8
+  int b, tile;
+  if ((B & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    b = (slot / ntile) * 8 + xcd;
+    tile = slot % ntile;
+  } else {
+    b = blockIdx.x / ntile;
+    tile = blockIdx.x % ntile;
+  }
+  const int i0 = tile * TI;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t prow0 = static_cast<int64_t>(b) * K;
+  const float scale_t = 0.57735026918962576f;  // 3^-1/2   (diffab_pytorch.py:387, :439)
+  const float scale_s = 0.17677669529663687f;  // 32^-1/2  (:353)
+  auto stamp = [&](int k) {  // diagnostics (stamps == nullptr in production)
+    if (stamps != nullptr) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long tnow = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && (wv < 4 || wv >= 12)) stamps[(static_cast<size_t>(blockIdx.x) * 8 + (wv & 7)) * 8 + k] = tnow;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stamp(0);
+
+  const int wv_role = wv;
+  if (wv_role < 8) {
+    const int wv = wv_role;  // row pair of this B wave
+    // ======================================================================================= B: pair stream of rows 2 wv, 2 wv + 1
+    const int hl = l15 & 7;  // lanes l15 >= 8 duplicate head l15 - 8 (their MFMA columns are the padding half of the 16-wide tile)
+    // addresses as (wave-uniform pointer, 32-bit lane offset): one VGPR per stream instead of a 64-bit pointer per load
+    const float* ebase = e + ((prow0 + i0 + 2 * wv) * K) * AC;  // + ii K AC + jt 16 AC (uniform)
+    const int eoff = (4 * q) * AC + 4 * l15;                    // + r AC
+    f32x4 ev[ERING][4];
+    auto load_rs = [&](int rs) {  // -> ring slot rs % ERING
+      const float* eu = ebase + (rs & 1) * (K * AC) + (rs >> 1) * (16 * AC);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ev[rs % ERING][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(eu + eoff + r * AC));
+    };
+#pragma unroll
+    for (int rs = 0; rs < ERING && rs < NRS; ++rs) load_rs(rs);  // the stream starts with the kernel
+    MEM_FENCE();
+    // B fragments of the bias product, Wb[h][16 sg + 4 q + s], per lane: kept in LDS [sg][lane] (the same for every wave; 16 VGPRs
+    // that the pipeline needs more), read back beside the pair tile in front()
+    if (wv == 0) {
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg)
+        *reinterpret_cast<f32x4*>(lds + L_WB + (sg * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(Wb + hl * AC + 16 * sg + 4 * q);
+    }
+    float* escr = lds + L_SE + wv * (16 * ELD);
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x4 oe[2][4];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A row-step in two halves, software-pipelined by hand (an in-order wave overlaps nothing by itself):
+    //   front(rs): pair tile -> bias orientation through LDS, 16 bias MFMAs in four independent chains   (needs only the pair tile:
+    //                                                                              runs a row-step early, across the step barrier too)
+    //   back(rs):  + S, running max / sum, P~ -> LDS, rescale, 16 o_e MFMAs, refill  (needs S of the tile: after the step barrier)
+    // No lane-divergent branch inside (they end a scheduling region): lanes l15 >= 8 and the four quarters store duplicates.
+    f32x4 acc_n;
+    auto front = [&](int rs) {
+      const int sl = rs % ERING;
+      float* t_ = escr + 4 * q * ELD + 4 * l15;  // write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[sl][r];
+      // (128-register budget: one 16-channel group of the tile and of Wb at a time, two accumulator chains)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(escr + l15 * ELD + 16 * sg + 4 * q);  // e[i][key l15][16 sg + 4 q + s]
+        const f32x4 wbv = *reinterpret_cast<const f32x4*>(lds + L_WB + (sg * 64 + lane) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbv[s], acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbv[s], acc, 0, 0, 0);
+        }
+      }
+      acc_n = acc + acc2;  // D: column = head l15, rows = keys 4 q + r of this tile
+    };
+    // Reductions over the four quarters (lanes l, l^16, l^32, l^48) with the gfx950 row swaps instead of LDS round trips:
+    // v_permlane32_swap exchanges lanes 32-63 of its first register with lanes 0-31 of its second, v_permlane16_swap the odd rows
+    // of the first with the even rows of the second; fed two COPIES of x they leave (x of the lower half / even row, x of the upper
+    // half / odd row) in every lane.  Written in assembly: the builtin, given the same value twice, is folded to "both results = its
+    // first" by hipcc (ROCm 7.2; tools/permlane_probe.hip shows it), which silently drops the other half.  s_nop 1 = the two wait
+    // states a VALU write of an operand needs before the swap reads it (the compiler pads nothing inside an asm statement).
+    // Not volatile: a pure function of its operands, free to be scheduled.
+    struct F2 { float a, b; };
+    auto swap32 = [](float x) {
+      F2 r{x, x};
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+      return r;
+    };
+    auto swap16 = [](float x) {
+      F2 r{x, x};
+      asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r.a), "+v"(r.b));
+      return r;
+    };
+    auto xq_max = [&](float x) {
+      F2 r = swap32(x);
+      r = swap16(fmaxf(r.a, r.b));
+      return fmaxf(r.a, r.b);
+    };
+    auto xq_sum = [&](float x) {
+      F2 r = swap32(x);
+      r = swap16(r.a + r.b);
+      return r.a + r.b;
+    };
+    auto back = [&](int rs, const f32x4 acc) {
+      const int jt = rs >> 1, ii = rs & 1, sl = rs % ERING, il = 2 * wv + ii;
+      const float* Sk = lds + L_S + (jt & 1) * RING;
+      float* Pk = lds + L_P + (jt & 1) * RING;
+      float* Ak = lds + L_AL + (jt & 1) * (AH * TI);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(Sk + il * RS + hl * HS + 4 * q);
+      float s_[4], mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_[r] = sv[r] + scale_t * acc[r];
+        mt = fmaxf(mt, s_[r]);
+      }
+#ifdef FLASH_ABL_NOSOFTMAX
+      const float m_new = mt, alpha = 0.5f;
+      f32x4 pv = {s_[0], s_[1], s_[2], s_[3]};
+      float ls = s_[0];
+#else
+      mt = xq_max(mt);
+      const float m_new = fmaxf(m_run[ii], mt);
+      const float alpha = FAST_EXP(m_run[ii] - m_new);  // 0 on the first tile (m_run = -inf)
+      f32x4 pv;
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = FAST_EXP(s_[r] - m_new);
+        ls += pv[r];
+      }
+#endif
+      *reinterpret_cast<f32x4*>(Pk + il * RS + hl * HS + 4 * q) = pv;  // (lanes l15 and l15 + 8 store the same values)
+      Ak[hl * TI + il] = alpha;                                         // (so do the four quarters)
+      // o_e[head n = l15][channel 4 m + ct] += sum_keys e[key][4 m + ct] P~[n][key]:  A = e (m = l15, k = q), B = P~ (n = l15, k = q)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oe[ii][ct][r] *= alpha;
+#ifdef FLASH_ABL_NOOE
+      for (int ct = 0; ct < 4; ++ct) oe[ii][ct] += ev[sl][ct] * pv[ct];
+#else
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[sl][r][ct], pv[r], oe[ii][ct], 0, 0, 0);
+#endif
+#ifndef FLASH_ABL_NOSOFTMAX
+      ls = xq_sum(ls);
+#endif
+      l_run[ii] = l_run[ii] * alpha + ls;
+      m_run[ii] = m_new;
+      asm("" : "+v"(l_run[ii]));  // keep the running sum a running sum: the scheduler otherwise defers the whole chain to the end of
+                                  // the kernel and spills every tile's (alpha, partial sum) pair until then
+#ifdef FLASH_ABL_NOLOAD
+      if (false) {
+#else
+      if (rs + ERING < NRS) {  // the slot is free: request the row-tile ERING row-steps ahead
+#endif
+        load_rs(rs + ERING);
+        MEM_FENCE();
+      }
+      if (jt == NT - 1) {  // last key tile of this row: normalise and store o_e, publish 1 / l for the head products
+        const float inv = 1.0f / l_run[ii];
+        int le = lane;  // opaque copy: otherwise the store addresses are computed at the top of the kernel and spilled
+        asm volatile("" : "+v"(le));
+        const int he = le & 7, qe = le >> 4;
+        lds[L_LI + he * TI + il] = inv;
+        if ((le & 15) < 8) {
+          float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + he * AC + 16 * qe;  // D rows m = 4 q + r' <-> channels 16 q + 4 r' + ct
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 v = {oe[ii][0][r] * inv, oe[ii][1][r] * inv, oe[ii][2][r] * inv, oe[ii][3][r] * inv};
+            *reinterpret_cast<f32x4*>(fo + 4 * r) = v;
+          }
+        }
+      }
+    };
+    MEM_FENCE();
+    __syncthreads();  // prologue barrier
+    stamp(1);
+    front(0);
+#pragma unroll
+    for (int k = 0; k < NT + 2; ++k) {
+      if (k >= 1 && k <= NT) {  // ---- B(k - 1): this wave's two rows
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int rs = 2 * (k - 1) + ii;
+          const f32x4 a0 = acc_n;
+#ifndef FLASH_ABL_NOB
+          if (rs + 1 < NRS) front(rs + 1);
+          back(rs, a0);
+#endif
+        }
+      }
+      __syncthreads();
+      if (k == 0) stamp(2);
+      if (k == 1) stamp(3);
+      if (k == 4) stamp(4);
+      if (k == NT) stamp(6);
+      if (k == NT + 1) stamp(7);
+    }
+  } else {
+    const int wv = wv_role - 8;  // head of this A / C wave
+    const int hl = l15 & 7;
+    // ======================================================================================= A / C: head h = wv
+    const int h = wv;
+    float* kscr = lds + L_HK + wv * KT;
+    // line-shaped loads of one key tile (16 keys) of head h: k_s 16 x 128 B (8 lanes per key), k_pts 16 x 96 B (6 lanes per key)
+    const int g0 = lane, g1 = lane < 32 ? lane + 64 : 95;  // k_pts chunk ids (0..95): key = id / 6, chunk = id % 6; lanes >= 32 repeat
+                                                           // chunk 95 (same data to the same LDS address: no divergent branch)
+    const float* krow = proj + prow0 * ANP;
+    const int ks_off = (lane >> 3) * ANP + OFF_KS + h * ADS + 4 * (lane & 7);  // + 8 ANP for keys 8..15, + 16 jt ANP
+    const int gk_off0 = (g0 / 6) * ANP + OFF_GK + h * 24 + 4 * (g0 % 6), gk_off1 = (g1 / 6) * ANP + OFF_GK + h * 24 + 4 * (g1 % 6);
+    const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
+    const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
+    f32x4 st[4];
+    auto load_keys = [&](int jt) {
+      const float* base = krow + jt * (16 * ANP);  // wave-uniform
+      st[0] = *reinterpret_cast<const f32x4*>(base + ks_off);
+      st[1] = *reinterpret_cast<const f32x4*>(base + ks_off + 8 * ANP);
+      st[2] = *reinterpret_cast<const f32x4*>(base + gk_off0);
+      st[3] = *reinterpret_cast<const f32x4*>(base + gk_off1);
+    };
+    auto stage_keys = [&]() {
+      *reinterpret_cast<f32x4*>(kscr + ks_dst) = st[0];
+      *reinterpret_cast<f32x4*>(kscr + ks_dst + 8 * KLD) = st[1];
+      *reinterpret_cast<f32x4*>(kscr + gk_dst0) = st[2];
+      *reinterpret_cast<f32x4*>(kscr + gk_dst1) = st[3];
+    };
+    // value side of one key tile, B operands of the P~ x V products: lane (n = l15, k = q), key 16 jt + 4 q + s.
+    // Point sums: columns 0..7 of one tile hold x of the 8 points, columns 8..15 y (z in a second tile), so 16 MFMAs per tile, not 20.
+    float2 vs[4];
+    float gxy[4], gz[4];
+    const int vs_off = (4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;
+    const int gv_off = (4 * q) * ANP + OFF_GV + h * 24 + 3 * hl;  // + (16 jt + s) ANP
+    auto load_vals = [&](int jt) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* pu = krow + (jt * 16 + s) * ANP;  // wave-uniform
+        vs[s] = *reinterpret_cast<const float2*>(pu + vs_off);
+        gxy[s] = pu[gv_off + (l15 >> 3)];
+        gz[s] = pu[gv_off + 2];
+      }
+    };
+    load_keys(0);
+    const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
+    f32x4 qa[2];
+    {
+      const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;  // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
+      qa[0] = *reinterpret_cast<const f32x4*>(qrow);
+      qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
+      // query points of the 16 rows of this head -> LDS [h][row][24] (96 chunks of 16 bytes)
+      float* gdst = lds + L_GQ + h * (TI * 24);
+      const float* gsrc = proj + (prow0 + i0) * ANP + OFF_GQ + h * 24;
+      *reinterpret_cast<f32x4*>(gdst + (g0 / 6) * 24 + 4 * (g0 % 6)) = *reinterpret_cast<const f32x4*>(gsrc + (g0 / 6) * ANP + 4 * (g0 % 6));
+      *reinterpret_cast<f32x4*>(gdst + (g1 / 6) * 24 + 4 * (g1 % 6)) = *reinterpret_cast<const f32x4*>(gsrc + (g1 / 6) * ANP + 4 * (g1 % 6));
+    }
+    f32x4 os[2], ogxy = {0.f, 0.f, 0.f, 0.f}, ogz = {0.f, 0.f, 0.f, 0.f};
+    os[0] = os[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    MEM_FENCE();
+    __syncthreads();  // prologue barrier
+    stamp(1);
+#pragma unroll
+    for (int k = 0; k < NT + 2; ++k) {
+      if (k < NT) {  // ---- keys of tile k: registers -> LDS (fragments are read back in A(k) below), then request tile k + 1
+        stage_keys();
+        if (k + 1 < NT) load_keys(k + 1);
+        MEM_FENCE();
+      }
+#ifndef FLASH_ABL_NOC  // (FLASH_ABL_*: timing-only ablation builds, results are garbage)
+      if (k >= 2) {  // ---- C(k - 2): acc = alpha . acc + P~ x V
+        const int jt = k - 2;
+        const float* Pk = lds + L_P + (jt & 1) * RING;
+        const float* Ak = lds + L_AL + (jt & 1) * (AH * TI);
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(Pk + l15 * RS + h * HS + 4 * q);  // A: P~[row l15][key 4 q + s]
+        const f32x4 al = *reinterpret_cast<const f32x4*>(Ak + h * TI + 4 * q);             // D rows 4 q + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          os[0][r] *= al[r];
+          os[1][r] *= al[r];
+          ogxy[r] *= al[r];
+          ogz[r] *= al[r];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], vs[s].x, os[0], 0, 0, 0);
+          os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], vs[s].y, os[1], 0, 0, 0);
+          ogxy = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], gxy[s], ogxy, 0, 0, 0);
+          ogz = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], gz[s], ogz, 0, 0, 0);
+        }
+      }
+      if (k >= 1 && k <= NT) {  // ---- values of tile k - 1, consumed by C(k - 1) in the next step
+        load_vals(k - 1);
+        MEM_FENCE();
+      }
+#endif
+#ifndef FLASH_ABL_NOA
+      if (k < NT) {  // ---- A(k): logits of key tile k for head h
+        float* Sk = lds + L_S + (k & 1) * RING;
+        const f32x4 kb0 = *reinterpret_cast<const f32x4*>(kscr + l15 * KLD + 4 * q);  // k_s[16 k + l15][16 sg + 4 q + s]
+        const f32x4 kb1 = *reinterpret_cast<const f32x4*>(kscr + l15 * KLD + 16 + 4 * q);
+        f32x4 gk[6];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) gk[cc] = *reinterpret_cast<const f32x4*>(kscr + 16 * KLD + l15 * GLD + 4 * cc);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc2, 0, 0, 0);
+        }
+        // acc[r] + acc2[r] = q_s[i0 + 4 q + r] . k_s[key 16 k + l15]
+        const float* gql = lds + L_GQ + h * (TI * 24) + (4 * q) * 24;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x2 d2v = {0.f, 0.f};  // packed fp32: two coordinates per instruction, two partial sums added at the end
+#ifdef FLASH_ABL_NOPTS
+          for (int cc = 0; cc < 0; ++cc) {
+#else
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc) {
+#endif
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(gql + r * 24 + 4 * cc);  // the 16 lanes of a quarter share the address
+            f32x2 dlo, dhi;  // packed subtract spelled in assembly: the compiler splits a vector fsub into two v_sub_f32
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+                : "=v"(dlo)
+                : "v"(__builtin_shufflevector(gq, gq, 0, 1)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 0, 1)));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+                : "=v"(dhi)
+                : "v"(__builtin_shufflevector(gq, gq, 2, 3)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 2, 3)));
+            d2v = __builtin_elementwise_fma(dlo, dlo, d2v);
+            d2v = __builtin_elementwise_fma(dhi, dhi, d2v);
+          }
+          const float d2 = d2v[0] + d2v[1];
+          Sk[(4 * q + r) * RS + h * HS + l15] = scale_t * ((acc[r] + acc2[r]) * scale_s + coef_p * d2);
+        }
+      }
+#endif
+      __syncthreads();
+      if (k == 0) stamp(2);
+      if (k == 1) stamp(3);
+      if (k == 4) stamp(4);
+      if (k == NT) stamp(6);
+      if (k == NT + 1) stamp(7);
+    }
+    // ---- epilogue of head h: D rows i = 4 q + r, column n = l15; normalise, global -> local frames, norms -> feature row
+    {
+      const f32x4 inv4 = *reinterpret_cast<const f32x4*>(lds + L_LI + h * TI + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = 4 * q + r;
+        const int64_t row = prow0 + i0 + il;
+        const float inv = inv4[r];
+        float* fr = feat + row * AF;
+        *reinterpret_cast<float2*>(fr + FOFF_OS + h * ADS + 2 * l15) = make_float2(os[0][r] * inv, os[1][r] * inv);
+        const float gy_ = __shfl_xor(ogxy[r], 8);  // lanes 0..7 hold x of point l15, lanes 8..15 y of point l15 - 8
+        if (l15 < 8) {
+          const float* Rr = R + row * 9;
+          const float* tr = t + row * 3;
+          const float dx = ogxy[r] * inv - tr[0], dy = gy_ * inv - tr[1], dz = ogz[r] * inv - tr[2];
+          const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
+          const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
+          const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
+          float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
+          fo[0] = lx; fo[1] = ly; fo[2] = lz;
+          fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
+        }
+      }
+    }
+  }
+  stamp(5);
+}
+
 bool attention_flash_supported(const diffab_dims* d) {
   return d->D == 128 && d->C == AC && d->H == AH && d->DS == ADS && d->PQ == AP && d->PV == AP && (d->K == 128 || d->K == 64);
 }
@@ -469,8 +863,27 @@ int launch_attention_flash(const diffab_dims* d, const float* proj, const float*
                        stamps);                                                                                                   \
     timer_end(st);                                                                                                                \
   } while (0)
-  if (d->K == 128) FLASH_LAUNCH(8);
-  else FLASH_LAUNCH(4);
+  static const int waves = [] {
+    const char* v = getenv("DIFFAB_FLASH_WAVES");
+    return v ? atoi(v) : 16;
+  }();
+#define FLASH16_LAUNCH(NT_)                                                                                                       \
+  do {                                                                                                                            \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_flash16_kernel<NT_>),                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFlashLdsBytes)));          \
+    timer_begin(st);                                                                                                              \
+    hipLaunchKernelGGL((ipa_attn_flash16_kernel<NT_>), grid, dim3(1024), kFlashLdsBytes, st, proj, e, R, t, Wb, gamma, feat, d->B, \
+                       stamps);                                                                                                   \
+    timer_end(st);                                                                                                                \
+  } while (0)
+  if (waves == 16) {
+    if (d->K == 128) FLASH16_LAUNCH(8);
+    else FLASH16_LAUNCH(4);
+  } else {
+    if (d->K == 128) FLASH_LAUNCH(8);
+    else FLASH_LAUNCH(4);
+  }
+#undef FLASH16_LAUNCH
 #undef FLASH_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;

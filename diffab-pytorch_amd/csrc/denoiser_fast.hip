@@ -1096,9 +1096,20 @@ bool fast_path_supported(const diffab_dims* d) {
          d->K <= 1024;  // any multiple of 64: keys are processed in chunks of 128 (or 64) with an online softmax
 }
 
+// DIFFAB_FP32_GEMM=1: the dense projections on the f32-input MFMA kernels of this file instead of the bf16x6 kernels
+// (gemm_bf16x6.hip; same results to fp32 rounding) - for A/B timing and as the plain-fp32 reference path
+bool use_b6_gemm() {
+  static const bool v = [] {
+    const char* e = getenv("DIFFAB_FP32_GEMM");
+    return e == nullptr || atoi(e) == 0;
+  }();
+  return v;
+}
+static size_t b6_scratch_floats() { return rowgemm128_b6_scratch_bytes(AF) / sizeof(float) + 64; }  // to_out: K = 1024
+
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
-  return rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0);
+  return rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0) + b6_scratch_floats();
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
@@ -1106,6 +1117,15 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
+  // to_out (diffab_pytorch.py:459-464): feat (rows x 1024) Wo^T + b.  sp_keep != nullptr (training tape): the tape's workspace slot has
+  // no scratch tail, fp32 kernel there.
+  float* b6_scratch = ws + static_cast<size_t>(rows) * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0);
+  b6_scratch = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(b6_scratch) + 255) & ~static_cast<uintptr_t>(255));
+  auto to_out = [&]() -> int {
+    if (use_b6_gemm() && sp_keep == nullptr && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
+      return launch_rowgemm128_b6(feat, AF, w->w_out, AF, w->b_out, nullptr, 0, y, D, rows, AF, false, b6_scratch, st);
+    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+  };
   // one GEMM for the six projections: Y[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T
   LinearSegs segs{};
   segs.W[0] = w->wq_s; segs.W[1] = w->wk_s; segs.W[2] = w->wv_s; segs.W[3] = w->wq_p; segs.W[4] = w->wk_p; segs.W[5] = w->wv_p;
@@ -1139,12 +1159,12 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   // P x V launches are not yet at their floors and the three together are slower (0.45 vs 0.37 ms) - hence opt-in.
   if (sp_keep != nullptr && attention_split_supported(d)) {  // training tape: ws has no tail here, P / d2 go to the tape's own slots
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, sp_keep, st, d2_keep)) return rc;
-    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+    return to_out();
   }
   if (attn_mode == 1 && attention_split_supported(d)) {
     float* SP = feat + static_cast<size_t>(rows) * AF + 128;
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
-    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+    return to_out();
   }
   // DIFFAB_FLAG_FLASH_ATTENTION (K = 64 / 128): the key-tile pipeline of attention_flash.hip - no logits image in LDS, the pair stream in
   // flight from the first instruction.  Parity-tested on the same goldens; measured 0.380 ms against 0.357 ms for the three-phase
@@ -1156,7 +1176,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   }();
   if ((attn_mode == 3 || (attn_mode == 0 && env_flash)) && attention_flash_supported(d)) {
     if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st)) return rc;
-    return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+    return to_out();
   }
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
@@ -1185,7 +1205,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
 #undef ATTN_LAUNCH_X
 #undef ATTN_LAUNCH
   DIFFAB_LAUNCH_CHECK();
-  return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
+  return to_out();
 }
 
 }  // namespace diffab

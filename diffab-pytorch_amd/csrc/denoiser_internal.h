@@ -29,6 +29,13 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
 bool rowgemm128_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
 int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                       int ldy, int M, int Kd, bool relu, hipStream_t st);
+// gemm_bf16x6.hip: the same product on the bf16 matrix cores, fp32-accurate (three-way bf16 split of both operands, six partial
+// products, fp32 accumulation); `scratch`: rowgemm128_b6_scratch_bytes(Kd) bytes for the split weights
+size_t rowgemm128_b6_scratch_bytes(int Kd);
+bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
+int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                         int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st);
+bool use_b6_gemm();
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
                        hipStream_t st, bool emb_tab_ready = false);  // beta == nullptr: the weights-only embedding table alone

@@ -1,0 +1,244 @@
+// gemm_bf16x6.hip - fp32-accurate dense projections on the bf16 matrix cores.
+//
+// Why: on gfx950 the f32-input MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VECTOR rate and - measured, tools/mfma4x4_probe.hip -
+// does not overlap with VALU work at all (32 cycles per MFMA + ~3.5 per v_fma issued beside it): in fp32, matrix and vector
+// arithmetic are ONE pipe, and the dense projections of an IPA layer (six projections 11.3 GFLOP, to_out 8.6 GFLOP at B = 256)
+// hold it for 0.19 ms of a 0.55 ms layer.  The bf16 matrix cores are a separate pipe, 16x the rate.  An fp32 number is exactly
+// the sum of three bf16 numbers (8 + 8 + 8 mantissa bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)), and
+//     a b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2) + O(2^-24 |a b|)
+// so SIX bf16 MFMAs with fp32 accumulation reproduce the fp32 product to fp32 rounding (each partial product of two 8-bit
+// mantissas is exact in fp32).  Measured on random data against float64: 2.7e-7 max-rel for the six-term form, 4.0e-7 for an
+// fp32 GEMM of the same operands (three terms only: 4e-6 - not used).  The parity tests hold the layers built on it to the same
+// bars as before.  6 MFMA 16x16x32 = 96 cycles per 16x16x32 block against 256 for the 8 f32 16x16x4 it replaces, and the VALU
+// (operand splitting, epilogues) runs beside them.
+//
+// Y[M x 128] = act(X[M x K] W^T + b): the N = 128 layers of the denoiser (to_out with K = 1024, the MLP layers with K = 128).
+// Reference: nn.Linear calls at diffab_pytorch.py:375-379, :459-464 (to_out), :515-556 (MLPs).
+#include "common.h"
+#include "denoiser_internal.h"
+
+namespace diffab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MEM_FENCE() asm volatile("" ::: "memory")
+
+namespace {
+constexpr int BK = 32;        // k per MFMA (16x16x32) = k per weight chunk
+constexpr int WLD = 40;       // LDS row stride of a staged row in bf16 units (32 + 8): 80 bytes = 5 x 16.  A 32x32x16 fragment read has 32
+                              // different rows on lanes 0..31 (same k half) and ds_read_b128 serves 16 of them per cycle: an odd
+                              // multiple of 16 bytes puts those 16 rows on 16 different bank quads
+constexpr int BROWS = 128;    // rows of X per work-group
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = static_cast<__bf16>(x);
+  const float r = x - static_cast<float>(h);
+  m = static_cast<__bf16>(r);
+  l = static_cast<__bf16>(r - static_cast<float>(m));
+}
+}  // namespace
+
+// W[128 x Kd] fp32 (rows ldw floats apart) -> three bf16 planes, chunk-major:  out[((chunk * 3 + s) * 128 + n) * 32 + kk],
+// chunk = k / 32, kk = k % 32.  One chunk = 24 KiB contiguous: the GEMM stages it with full-line loads and no address arithmetic.
+__global__ void wsplit128_kernel(const float* __restrict__ W, int ldw, int Kd, __bf16* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (n, k)
+  if (gid >= 128 * Kd) return;
+  const int n = gid / Kd, k = gid % Kd;
+  __bf16 h, m, l;
+  split3(W[static_cast<int64_t>(n) * ldw + k], h, m, l);
+  const int chunk = k / BK, kk = k % BK;
+  const size_t base = (static_cast<size_t>(chunk) * 3 * 128 + n) * BK + kk;
+  out[base] = h;
+  out[base + 128 * BK] = m;
+  out[base + 2 * 128 * BK] = l;
+}
+
+// LDS (dynamic, 122 880 B): weights Ws[2 buffers][3 planes][128 rows][WLD], then X As[2][3][128][WLD] - both operands are staged as
+// split bf16 planes: every element of X is split ONCE per work-group (its two column waves share the rows), and X is read from
+// HBM in full 128-byte lines (the MFMA fragment shape - adjacent lanes on different rows - costs the texture addresser four lines
+// per lane quad: with fragment-shaped loads straight from global memory this kernel took 58 us instead of ~30).
+constexpr int kB6LdsBytes = 2 * 2 * 3 * 128 * WLD * 2;
+
+template <bool RELU>
+__global__ __launch_bounds__(512) void rowgemm128_b6_kernel(const float* __restrict__ X, int ldx, const __bf16* __restrict__ Wc,
+                                                            const float* __restrict__ bias, const int64_t* __restrict__ bias_idx,
+                                                            int bias_div, float* __restrict__ Y, int ldy, int M, int Kd) {
+  // bias: one vector (bias_idx == nullptr, bias_div == 0), or a table of 128-wide rows indexed by bias_idx[row] or row / bias_div
+  extern __shared__ __attribute__((aligned(16))) __bf16 b6_lds[];
+  __bf16* Ws = b6_lds;
+  __bf16* As = b6_lds + 2 * 3 * 128 * WLD;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, hk = lane >> 5, rw = wv & 3, cw = wv >> 2;  // v_mfma_f32_32x32x16_bf16: 24 of its 32 cycles leave the
+                                                                         // vector issue port free (16x16x32: 8 of 16; measured: the
+                                                                         // splitting VALU work then adds to the MFMA time)
+  const int m0 = blockIdx.x * BROWS;
+  const int nchunk = Kd / BK;
+#ifndef B6_STAGE_MODE
+#define B6_STAGE_MODE 0  // 0: every wave stages after its MFMAs | 1: before | 2: waves 4-7 before, 0-3 after
+#endif
+  const bool stage_first = B6_STAGE_MODE == 1 || (B6_STAGE_MODE == 2 && wv >= 4);
+  // weight staging: thread -> (plane p = pass, LDS row tid / 4, 16-byte part tid % 4): a straight copy of the chunk's 24 KiB
+  const int st_row = tid >> 2, st_part = tid & 3;
+  f32x4 wreg[2][3];
+  auto load_w = [&](int slot, int ch) {
+    ch = ch < nchunk ? ch : nchunk - 1;  // unconditional prefetch (a branch around it makes the compiler wait for it at once)
+    const __bf16* src = Wc + static_cast<size_t>(ch) * (3 * 128 * BK) + st_row * BK + st_part * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wreg[slot][p] = *reinterpret_cast<const f32x4*>(src + p * (128 * BK));
+  };
+  auto store_w = [&](int slot, int buf) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(Ws + ((buf * 3 + p) * 128 + st_row) * WLD + st_part * 8) = wreg[slot][p];
+  };
+  // X staging: a chunk is 128 rows x 128 bytes; thread -> rows tid / 8 and 64 + tid / 8, 16-byte part tid % 8 (8 lanes = one line);
+  // rows past M are clamped (their results are never stored).  Requested four chunks ahead (HBM), ring slots are compile-time.
+  const int xa_row = tid >> 3, xa_part = tid & 7;
+  const float* xsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int row = m0 + xa_row + 64 * j;
+    row = row < M ? row : M - 1;
+    xsrc[j] = X + static_cast<int64_t>(row) * ldx + 4 * xa_part;
+  }
+  f32x4 xreg[4][2];
+  auto load_x = [&](int slot, int ch) {
+    ch = ch < nchunk ? ch : nchunk - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xreg[slot][j] = *reinterpret_cast<const f32x4*>(xsrc[j] + ch * BK);
+  };
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  auto store_x = [&](int slot, int buf) {  // fp32 -> three bf16 planes -> LDS
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __bf16 hh, mm, ll;
+#ifdef B6_ABL_NOSPLIT
+        hh = mm = ll = static_cast<__bf16>(xreg[slot][j][c]);
+#else
+        split3(xreg[slot][j][c], hh, mm, ll);
+#endif
+        h[c] = hh; m[c] = mm; l[c] = ll;
+      }
+      __bf16* dst = As + ((buf * 3) * 128 + xa_row + 64 * j) * WLD + 4 * xa_part;
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + 128 * WLD) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * 128 * WLD) = l;
+    }
+  };
+  f32x16 acc[2];  // wave tile: 32 rows x 64 columns = two 32 x 32 accumulators
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_x(c, c);
+  load_w(0, 0);
+  load_w(1, 1);
+  MEM_FENCE();
+  store_w(0, 0);
+  store_x(0, 0);
+  load_w(0, 2);  // slot s holds chunk c with c % 2 == s: chunk 0 is staged, its slot takes chunk 2
+  load_x(0, 4);
+  MEM_FENCE();
+  __syncthreads();
+  for (int ch0 = 0; ch0 < nchunk; ch0 += 4) {  // nchunk % 4 == 0 (launcher)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ch = ch0 + u, buf = u & 1;
+      // stage chunk ch + 1 into the other buffers (its loads were issued two / four iterations ago), then refill the ring slots
+      auto stage = [&]() {
+#ifndef B6_ABL_NOSTAGE
+        store_w((u + 1) & 1, buf ^ 1);
+        store_x((u + 1) & 3, buf ^ 1);
+#ifndef B6_ABL_NOLOAD
+        load_w((u + 1) & 1, ch + 3);
+        load_x((u + 1) & 3, ch + 5);
+#endif
+        MEM_FENCE();
+#endif
+      };
+      // The two waves of a SIMD (w, w + 4) are in lockstep behind the barrier: if both staged after their MFMAs, matrix and vector /
+      // LDS work would take turns on every SIMD (measured: 3.0 k cycles per chunk for 1.5 k of MFMAs).  Waves 4-7 stage first.
+      if (stage_first) stage();
+      // fragments: lane (row or column = l31, k half hk) of k-step ks reads 16 bytes: k = 16 ks + 8 hk .. + 7
+      const __bf16* al = As + (buf * 3 * 128 + 32 * rw + l31) * WLD + 8 * hk;
+      const __bf16* wl = Ws + (buf * 3 * 128 + 64 * cw + l31) * WLD + 8 * hk;
+      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi): smallest first
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[3], b[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[p] = *reinterpret_cast<const bf16x8*>(al + (p * 128) * WLD + 16 * ks);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) b[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (p * 128 + 32 * tt) * WLD + 16 * ks);
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#ifdef B6_ABL_NOMFMA
+            acc[tt][term] += static_cast<float>(a[TA[term]][0]) + static_cast<float>(b[tt][TB[term]][1]);
+#else
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[term]], b[tt][TB[term]], acc[tt], 0, 0, 0);
+#endif
+      }
+      if (!stage_first) stage();
+      __syncthreads();
+    }
+  }
+  // D 32x32: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); 32 lanes = 128 contiguous bytes of a row
+  const bool table = bias_idx != nullptr || bias_div > 0;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int col = 64 * cw + 32 * tt + l31;
+    float bv = (bias && !table) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * rw + (r & 3) + 8 * (r >> 2) + 4 * hk;
+      if (row >= M) continue;
+      if (table) {
+        const int64_t bi = bias_idx ? bias_idx[row] : row / bias_div;
+        bv = bias[bi * 128 + col];
+      }
+      float o = acc[tt][r] + bv;
+      if (RELU) o = fmaxf(o, 0.f);
+      Y[static_cast<int64_t>(row) * ldy + col] = o;
+    }
+  }
+}
+
+size_t rowgemm128_b6_scratch_bytes(int Kd) { return static_cast<size_t>(3) * 128 * Kd * sizeof(__bf16); }
+
+bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd) {
+  return Kd % (4 * BK) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && M >= 1;
+}
+
+// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + bias row); `scratch`: rowgemm128_b6_scratch_bytes(Kd) bytes, 16-byte aligned
+int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                         int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st) {
+  DIFFAB_REQUIRE(rowgemm128_b6_ok(X, ldx, Y, ldy, M, Kd) && scratch && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 &&
+                     (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+                 DIFFAB_ERR_ARG, "rowgemm128_b6: unsupported operands");
+  __bf16* Wc = static_cast<__bf16*>(scratch);
+  hipLaunchKernelGGL(wsplit128_kernel, dim3((128 * Kd + 255) / 256), dim3(256), 0, st, W, ldw, Kd, Wc);
+  const dim3 grid((M + BROWS - 1) / BROWS);
+  if (relu) {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kB6LdsBytes));
+    hipLaunchKernelGGL(rowgemm128_b6_kernel<true>, grid, dim3(512), kB6LdsBytes, st, X, ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);
+  } else {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kB6LdsBytes));
+    hipLaunchKernelGGL(rowgemm128_b6_kernel<false>, grid, dim3(512), kB6LdsBytes, st, X, ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);
+  }
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // namespace diffab

@@ -48,6 +48,53 @@ __global__ __launch_bounds__(512) void rate_mixed_kernel(float* out, int iters) 
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// does independent VALU work hide in the shadow of a 32-cycle v_mfma_f32_16x16x4_f32?  NF v_fma per MFMA, 4 accumulators
+template <int NF>
+__global__ __launch_bounds__(512) void rate16_mixed_kernel(float* out, int iters) {
+  const float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
+  f32x4 acc[4];
+  float v[8];
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 8; ++i) v[i] = a + i;
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f & 7] = __builtin_fmaf(v[f & 7], b, a);
+      }
+  float r = 0.f;
+  for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][3];
+  for (int i = 0; i < 8; ++i) r += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+// the same question for the bf16 matrix core: NF v_fma per v_mfma_f32_16x16x32_bf16 (16 cycles alone)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int NF>
+__global__ __launch_bounds__(512) void rate_bf16_mixed_kernel(float* out, int iters) {
+  const float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
+  bf16x8 fa, fb;
+  for (int i = 0; i < 8; ++i) { fa[i] = static_cast<__bf16>(a + i); fb[i] = static_cast<__bf16>(b - i); }
+  f32x4 acc[8];
+  float v[8];
+  for (int i = 0; i < 8; ++i) { acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; v[i] = a + i; }
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f & 7] = __builtin_fmaf(v[f & 7], b, a);
+      }
+  float r = 0.f;
+  for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][3] + v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 int main() {
   // ---- layout: a[l] = 1 + l, b[l] = 100 + l  ->  which (la, lb) product lands in d[l][r]?
   std::vector<float> ha(64), hb(64), hd(256);
@@ -105,6 +152,50 @@ int main() {
     run("4x4x1", rate_kernel<4>, 4, threads);
     run("4x4x1", rate_kernel<8>, 8, threads);
     run("4x4x1 + 1 v_fma each", rate_mixed_kernel<8>, 8, threads);
+  }
+  auto run16 = [&](const char* name, auto kern, int nf, int threads) {
+    const int iters = 20000, grid = 256;
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, out, iters);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double n_mfma = double(iters) * 16;
+    printf("16x16x4 + %d v_fma per MFMA, %4d threads/WG: %.3f ms  ~%.1f cycles per MFMA per SIMD at 2.3 GHz (32 = the MFMA alone; +4 per v_fma if nothing overlaps)\n",
+           nf, threads, ms, ms * 1e-3 * 2.3e9 / (n_mfma * (threads / 256.0)));
+  };
+  for (int threads : {256, 512}) {
+    run16("", rate16_mixed_kernel<0>, 0, threads);
+    run16("", rate16_mixed_kernel<2>, 2, threads);
+    run16("", rate16_mixed_kernel<4>, 4, threads);
+    run16("", rate16_mixed_kernel<6>, 6, threads);
+    run16("", rate16_mixed_kernel<8>, 8, threads);
+    run16("", rate16_mixed_kernel<12>, 12, threads);
+  }
+  auto runb = [&](auto kern, int nf, int threads) {
+    const int iters = 20000, grid = 256;
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, 0, out, iters);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double n_mfma = double(iters) * 16;
+    printf("bf16 16x16x32 + %d v_fma per MFMA, %4d threads/WG: %.3f ms  ~%.1f cycles per MFMA per SIMD at 2.3 GHz (16 = the MFMA alone)\n", nf, threads,
+           ms, ms * 1e-3 * 2.3e9 / (n_mfma * (threads / 256.0)));
+  };
+  for (int threads : {256, 512}) {
+    runb(rate_bf16_mixed_kernel<0>, 0, threads);
+    runb(rate_bf16_mixed_kernel<1>, 1, threads);
+    runb(rate_bf16_mixed_kernel<2>, 2, threads);
+    runb(rate_bf16_mixed_kernel<3>, 3, threads);
+    runb(rate_bf16_mixed_kernel<4>, 4, threads);
+    runb(rate_bf16_mixed_kernel<6>, 6, threads);
   }
   return 0;
 }
