@@ -56,8 +56,10 @@ static int check_dims(const diffab_dims* d, const char* who) {
 
 struct StepBuffers {
   float *cat2, *h1, *hA, *hB, *cat3, *t1, *t2, *vbuf, *logits, *ipa, *emb_tab, *beta_tab;
+  char* planes;  // split bf16 planes of the dense weights (MFMA path): NL x ipa_layer_planes_bytes(), then 8 MLP matrices
   size_t bytes;
 };
+static size_t mlp_planes_bytes() { return (rowgemm128_b6_scratch_bytes(128) + 255) & ~static_cast<size_t>(255); }
 
 static StepBuffers carve_step(const diffab_dims* d, void* ws) {
   Carver c(ws);
@@ -77,18 +79,19 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
   size_t ipa_floats = ipa_generic_workspace_floats(d);
   if (fast_path_supported(d)) ipa_floats = ipa_floats > ipa_fast_workspace_floats(d) ? ipa_floats : ipa_fast_workspace_floats(d);
   b.ipa = c.take<float>(ipa_floats);
+  b.planes = fast_path_supported(d) ? c.take<char>(d->NL * ipa_layer_planes_bytes() + 8 * mlp_planes_bytes()) : nullptr;
   b.bytes = c.bytes();
   return b;
 }
 
 static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                               const float* t, float* y, float* ws, uint32_t flags, hipStream_t st, float* sp_keep = nullptr,
-                              float* d2_keep = nullptr) {
+                              float* d2_keep = nullptr, const void* planes = nullptr) {
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
     return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : ((flags & DIFFAB_FLAG_FLASH_ATTENTION) ? 3 : 0)),
-                          sp_keep, d2_keep);
+                          sp_keep, d2_keep, planes);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -101,9 +104,31 @@ static int mlp3(const diffab_dims* d, const diffab_mlp3_weights* w, const float*
   return launch_linear(t2, D, w->w4, w->b4, out, n_out, rows, n_out, D, false, st);
 }
 
+// Everything on the folded MFMA path that depends on the weights only: the sequence-embedding bias table and the split bf16 planes
+// of every dense weight matrix.  Once per denoise_step call - or once per trajectory (diffab_sample_loop).
+static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* w, const StepBuffers& b, hipStream_t st) {
+  DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0 && w->coord.w2 && w->orient.w2 &&
+                     w->seq.w2,
+                 DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
+  if (int rc = launch_fold_tables(d, w, nullptr, b.emb_tab, nullptr, st)) return rc;
+  if (!use_b6_gemm()) return DIFFAB_OK;
+  const int D = d->D;
+  for (int l = 0; l < d->NL; ++l)
+    if (int rc = ipa_layer_split_weights(&w->layers[l], b.planes + l * ipa_layer_planes_bytes(), st)) return rc;
+  char* mlp = b.planes + d->NL * ipa_layer_planes_bytes();
+  const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
+  if (int rc = launch_wsplit128(w->res_w0, 2 * D, D, mlp, st)) return rc;                        // slot 0: res_ctx half of to_res_emb[0]
+  if (int rc = launch_wsplit128(w->res_w2, D, D, mlp + mlp_planes_bytes(), st)) return rc;      // slot 1
+  for (int hd = 0; hd < 3; ++hd) {                                                              // slots 2 + 2 hd, 3 + 2 hd
+    if (int rc = launch_wsplit128(hw[hd]->w0, D + 3, D, mlp + (2 + 2 * hd) * mlp_planes_bytes(), st)) return rc;
+    if (int rc = launch_wsplit128(hw[hd]->w2, D, D, mlp + (3 + 2 * hd) * mlp_planes_bytes(), st)) return rc;
+  }
+  return DIFFAB_OK;
+}
+
 static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
                         const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
-                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool emb_tab_ready = false) {
+                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false) {
   const StepBuffers b = carve_step(d, ws);
   const int rows = d->B * d->K, D = d->D;
   // Folded concatenations (MFMA path): the sequence-embedding half of to_res_emb[0] and the beta-embedding columns of the three
@@ -112,16 +137,30 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   if (fold) {
     DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0, DIFFAB_ERR_ARG,
                    "denoiser head: null weight pointer");
-    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, emb_tab_ready)) return rc;
-    if (int rc = launch_rowgemm128(res_ctx, D, w->res_w0, 2 * D, b.emb_tab, seq_t, 0, b.h1, D, rows, D, true, st)) return rc;
+    if (!weights_prepared)
+      if (int rc = prepare_weights(d, w, b, st)) return rc;
+    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, true)) return rc;
+  }
+  // dense N = 128 layers of the folded path: bf16x6 from the prepared planes (slot), or the fp32 kernel
+  const bool b6 = fold && use_b6_gemm() && rowgemm128_b6_ok(res_ctx, D, b.h1, D, rows, D);
+  const char* mlp = b6 ? b.planes + d->NL * ipa_layer_planes_bytes() : nullptr;
+  auto dense128 = [&](int slot, const float* X, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                      bool relu) -> int {
+    if (b6) return launch_rowgemm128_b6p(X, D, mlp + slot * mlp_planes_bytes(), bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
+    return launch_rowgemm128(X, D, W, ldw, bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
+  };
+  if (fold) {
+    if (int rc = dense128(0, res_ctx, w->res_w0, 2 * D, b.emb_tab, seq_t, 0, b.h1, true)) return rc;
+    if (int rc = dense128(1, b.h1, w->res_w2, D, w->res_b2, nullptr, 0, b.hA, false)) return rc;
   } else {
     if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, b.cat2, st)) return rc;
     if (int rc = launch_linear(b.cat2, 2 * D, w->res_w0, w->res_b0, b.h1, D, rows, D, 2 * D, true, st)) return rc;
+    if (int rc = launch_linear(b.h1, D, w->res_w2, w->res_b2, b.hA, D, rows, D, D, false, st)) return rc;
   }
-  if (int rc = launch_linear(b.h1, D, w->res_w2, w->res_b2, b.hA, D, rows, D, D, false, st)) return rc;
   float *cur = b.hA, *nxt = b.hB;
   for (int l = 0; l < d->NL; ++l) {
-    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st)) return rc;
+    const void* planes = (fold && use_b6_gemm()) ? b.planes + l * ipa_layer_planes_bytes() : nullptr;
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes)) return rc;
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   if (out_res_emb) DIFFAB_HIP_CHECK(hipMemcpyAsync(out_res_emb, cur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
@@ -132,9 +171,9 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     const int nout[3] = {3, 3, d->V};
     for (int hd = 0; hd < 3; ++hd) {
       DIFFAB_REQUIRE(hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
-      if (int rc = launch_rowgemm128(cur, D, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, D, rows,
-                                     D, true, st)) return rc;
-      if (int rc = launch_linear(b.t1, D, hw[hd]->w2, hw[hd]->b2, b.t2, D, rows, D, D, true, st)) return rc;
+      if (int rc = dense128(2 + 2 * hd, cur, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, true))
+        return rc;
+      if (int rc = dense128(3 + 2 * hd, b.t1, hw[hd]->w2, D, hw[hd]->b2, nullptr, 0, b.t2, true)) return rc;
       if (int rc = launch_linear(b.t2, D, hw[hd]->w4, hw[hd]->b4, outs[hd], nout[hd], rows, nout[hd], D, false, st)) return rc;
     }
   } else {
@@ -344,7 +383,7 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
   const bool fold = !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d) &&
                     rowgemm128_ok(res_ctx, d->D, b0.h1, d->D, d->B * d->K, d->D);
   if (fold)
-    if (int rc = launch_fold_tables(d, w, nullptr, b0.emb_tab, nullptr, st)) return rc;
+    if (int rc = prepare_weights(d, w, b0, st)) return rc;
   auto one_step = [&](int t, const int* t_dev) -> int {
     if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
     if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold))

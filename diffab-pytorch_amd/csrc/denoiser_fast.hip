@@ -1105,7 +1105,14 @@ bool use_b6_gemm() {
   }();
   return v;
 }
-static size_t b6_scratch_floats() { return rowgemm128_b6_scratch_bytes(AF) / sizeof(float) + 64; }  // to_out: K = 1024
+static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+size_t ipa_layer_planes_bytes() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
+int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st) {
+  const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
+  if (int rc = launch_pjsplit(W6, planes, st)) return rc;
+  return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + round256(proj_frames_b6_scratch_bytes()), st);
+}
+static size_t b6_scratch_floats() { return (ipa_layer_planes_bytes() + 256) / sizeof(float); }
 
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
@@ -1113,17 +1120,25 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d) {
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep) {
+                   float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep, const void* planes) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
-  // to_out (diffab_pytorch.py:459-464): feat (rows x 1024) Wo^T + b.  sp_keep != nullptr (training tape): the tape's workspace slot has
-  // no scratch tail, fp32 kernel there.
-  float* b6_scratch = ws + static_cast<size_t>(rows) * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0);
-  b6_scratch = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(b6_scratch) + 255) & ~static_cast<uintptr_t>(255));
+  // Dense projections on the bf16 matrix cores (gemm_bf16x6.hip) from split weight planes: the caller's (reverse sampler: split once
+  // per trajectory) or, per call, the tail of the workspace.  sp_keep != nullptr (training tape): that workspace slot has no tail,
+  // fp32 kernels there.
+  const bool b6 = use_b6_gemm() && (planes != nullptr || sp_keep == nullptr);
+  if (b6 && planes == nullptr) {
+    float* tail = ws + static_cast<size_t>(rows) * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0);
+    void* own = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(tail) + 255) & ~static_cast<uintptr_t>(255));
+    if (int rc = ipa_layer_split_weights(w, own, st)) return rc;
+    planes = own;
+  }
+  const void* out_planes = b6 ? static_cast<const char*>(planes) + round256(proj_frames_b6_scratch_bytes()) : nullptr;
+  // to_out (diffab_pytorch.py:459-464): feat (rows x 1024) Wo^T + b
   auto to_out = [&]() -> int {
-    if (use_b6_gemm() && sp_keep == nullptr && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
-      return launch_rowgemm128_b6(feat, AF, w->w_out, AF, w->b_out, nullptr, 0, y, D, rows, AF, false, b6_scratch, st);
+    if (b6 && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
+      return launch_rowgemm128_b6p(feat, AF, out_planes, w->b_out, nullptr, 0, y, D, rows, AF, false, st);
     return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
   };
   // one GEMM for the six projections: Y[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T
@@ -1139,7 +1154,9 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   DIFFAB_LAUNCH_CHECK();
 #else
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
-  {
+  if (b6) {
+    if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
+  } else {
     const size_t pj_lds = (2 * PJB * PJLD + PJROWS * 12) * sizeof(float);
 #define PROJ_LAUNCH(FULL_)                                                                                                        \
   do {                                                                                                                            \

@@ -19,7 +19,8 @@ bool fast_path_supported(const diffab_dims* d);
 size_t ipa_fast_workspace_floats(const diffab_dims* d);
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, int attn_mode = 0,  // 0 fused | 1 three launches | 2 logits launch + fused rest
-                   float* sp_keep = nullptr, float* d2_keep = nullptr);  // training tape: three launches, P and d2 kept in these buffers
+                   float* sp_keep = nullptr, float* d2_keep = nullptr,  // training tape: three launches, P and d2 kept in these buffers
+                   const void* planes = nullptr);  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
 // Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);
@@ -29,13 +30,24 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
 bool rowgemm128_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
 int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                       int ldy, int M, int Kd, bool relu, hipStream_t st);
-// gemm_bf16x6.hip: the same product on the bf16 matrix cores, fp32-accurate (three-way bf16 split of both operands, six partial
-// products, fp32 accumulation); `scratch`: rowgemm128_b6_scratch_bytes(Kd) bytes for the split weights
+// gemm_bf16x6.hip: the same products on the bf16 matrix cores, fp32-accurate (three-way bf16 split of both operands, six partial
+// products, fp32 accumulation).  The weights are split once into bf16 planes (launch_wsplit128 / launch_pjsplit: per call, or
+// once per trajectory by the reverse sampler) and the ...p launchers take the planes.
 size_t rowgemm128_b6_scratch_bytes(int Kd);
 bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
+int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st);
+int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                          int ldy, int M, int Kd, bool relu, hipStream_t st);
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                          int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st);
-bool use_b6_gemm();
+bool use_b6_gemm();  // false with DIFFAB_FP32_GEMM=1 in the environment
+// the six IPA projections + frames; W6 = {wq_s, wk_s, wv_s, wq_p, wk_p, wv_p}
+size_t proj_frames_b6_scratch_bytes();
+int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st);
+int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st);
+// split planes of one IPA layer's projection and to_out weights: ipa_layer_planes_bytes() bytes, 256-byte aligned
+size_t ipa_layer_planes_bytes();
+int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
                        hipStream_t st, bool emb_tab_ready = false);  // beta == nullptr: the weights-only embedding table alone

@@ -219,14 +219,20 @@ bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, i
          (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && M >= 1;
 }
 
-// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + bias row); `scratch`: rowgemm128_b6_scratch_bytes(Kd) bytes, 16-byte aligned
-int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
-                         int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st) {
-  DIFFAB_REQUIRE(rowgemm128_b6_ok(X, ldx, Y, ldy, M, Kd) && scratch && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 &&
-                     (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
-                 DIFFAB_ERR_ARG, "rowgemm128_b6: unsupported operands");
-  __bf16* Wc = static_cast<__bf16*>(scratch);
-  hipLaunchKernelGGL(wsplit128_kernel, dim3((128 * Kd + 255) / 256), dim3(256), 0, st, W, ldw, Kd, Wc);
+// W[128 x Kd] (rows ldw floats apart) -> split planes for rowgemm128_b6p (rowgemm128_b6_scratch_bytes(Kd) bytes, 16-byte aligned)
+int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st) {
+  DIFFAB_REQUIRE(W && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && Kd % BK == 0, DIFFAB_ERR_ARG, "wsplit128: bad operands");
+  hipLaunchKernelGGL(wsplit128_kernel, dim3((128 * Kd + 255) / 256), dim3(256), 0, st, W, ldw, Kd, static_cast<__bf16*>(planes));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + bias row) with W given as split planes (launch_wsplit128)
+int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                          int ldy, int M, int Kd, bool relu, hipStream_t st) {
+  DIFFAB_REQUIRE(rowgemm128_b6_ok(X, ldx, Y, ldy, M, Kd) && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, DIFFAB_ERR_ARG,
+                 "rowgemm128_b6: unsupported operands");
+  const __bf16* Wc = static_cast<const __bf16*>(planes);
   const dim3 grid((M + BROWS - 1) / BROWS);
   if (relu) {
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -236,6 +242,234 @@ int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kB6LdsBytes));
     hipLaunchKernelGGL(rowgemm128_b6_kernel<false>, grid, dim3(512), kB6LdsBytes, st, X, ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);
+  }
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// split + product in one call; `scratch`: rowgemm128_b6_scratch_bytes(Kd) bytes, 16-byte aligned
+int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
+                         int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st) {
+  if (int rc = launch_wsplit128(W, ldw, Kd, scratch, st)) return rc;
+  return launch_rowgemm128_b6p(X, ldx, scratch, bias, bias_idx, bias_div, Y, ldy, M, Kd, relu, st);
+}
+
+// ================================================================== six IPA projections + local->global frames (bf16x6)
+// proj[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T, the three point blocks mapped to the global frame (x R + t,
+// diffab_pytorch.py:324) before they are stored - the bf16x6 form of proj_frames_kernel (denoiser_fast.hip), same decomposition:
+// x-stationary (a wave keeps its 32 x 128 slab of x as SPLIT A fragments: 96 VGPRs), 14 blocks of 96 output columns, MFMA n index
+// permuted so that a lane ends up with three consecutive output columns (one point) per row.  The weights arrive pre-split
+// (pjsplit_kernel) in stage order - stage = (block, k half): 3 planes x 96 LDS rows x 64 k, 36 KiB contiguous - and are staged
+// through a ring of two LDS buffers with rows padded to 160 bytes (conflict-free ds_read_b128 for the 16-row B fragment).
+namespace {
+constexpr int PJ_NP = 1344, PJ_GQ = 768, PJ_GK = 960, PJ_GV = 1152;  // column map of the projection buffer (denoiser_fast.hip: ANP, OFF_*)
+constexpr int PJ_B = 96, PJ_NB = PJ_NP / PJ_B, PJ_ROWS = 128;
+constexpr int PJ_LD = 80;                                 // bf16 per staged row: 64 k + 16 pad (160 bytes)
+constexpr int PJ_STAGE_ELEMS = 3 * PJ_B * 64;             // bf16 per stage in global memory (36 864 bytes)
+constexpr int PJ_STAGE_LDS = 3 * PJ_B * PJ_LD;            // bf16 per stage in LDS (46 080 bytes)
+constexpr int PJ_LDS_BYTES = 2 * PJ_STAGE_LDS * 2 + PJ_ROWS * 12 * 4;
+struct __attribute__((packed, aligned(4))) pjb_f3 { float x, y, z; };
+}  // namespace
+
+// stage-ordered split weights: out[((blk * 2 + kh) * 3 + plane) * 96 + l][kk], l = 48 cw + 16 tt + j <-> output column
+// 96 blk + 48 cw + 3 j + tt, k = 64 kh + kk
+__global__ void pjsplit_kernel(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
+                               const float* __restrict__ W3, const float* __restrict__ W4, const float* __restrict__ W5,
+                               __bf16* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (output column gc, k)
+  if (gid >= PJ_NP * 128) return;
+  const int gc = gid >> 7, k = gid & 127;
+  const float* Wp;
+  int row;
+  if (gc < PJ_GQ) {
+    Wp = gc < 256 ? W0 : (gc < 512 ? W1 : W2);
+    row = gc & 255;
+  } else {
+    Wp = gc < PJ_GK ? W3 : (gc < PJ_GV ? W4 : W5);
+    row = gc - (gc < PJ_GK ? PJ_GQ : (gc < PJ_GV ? PJ_GK : PJ_GV));
+  }
+  __bf16 h, m, l;
+  split3(Wp[row * 128 + k], h, m, l);
+  const int blk = gc / PJ_B, rem = gc % PJ_B, cwl = rem / 48, r48 = rem % 48, j = r48 / 3, tt = r48 % 3;
+  const int lrow = 48 * cwl + 16 * tt + j, kh = k >> 6, kk = k & 63;
+  const size_t base = (static_cast<size_t>(blk * 2 + kh) * 3 * PJ_B + lrow) * 64 + kk;
+  out[base] = h;
+  out[base + PJ_B * 64] = m;
+  out[base + 2 * PJ_B * 64] = l;
+}
+
+template <bool FULL>  // FULL: M is a multiple of 128, no row guards
+__global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wc,
+                                                             const float* __restrict__ R, const float* __restrict__ t,
+                                                             float* __restrict__ Y, int M) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 pj_lds[];  // [2][3][96][PJ_LD] weights, then [128][12] frames (fp32)
+  float* Rt = reinterpret_cast<float*>(pj_lds + 2 * PJ_STAGE_LDS);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4, rw = wv & 3, cw = wv >> 2;
+  const int m0 = blockIdx.x * PJ_ROWS;
+  float* ybase = Y + static_cast<int64_t>(m0 + 32 * rw + 4 * g) * PJ_NP + 48 * cw + 3 * l15;
+
+  // weight staging: a stage is 2304 16-byte pieces, piece idx -> (plane idx / 768, row (idx % 768) / 8, part idx % 8); thread tid takes
+  // idx = tid + 512 i (i = 0..3) and 2048 + (tid & 255) - the two halves of the work-group duplicate the last 256 (no branch)
+  int st_src[5], st_dst[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int idx = i < 4 ? tid + 512 * i : 2048 + (tid & 255);
+    const int pl = idx / 768, rem = idx % 768;
+    st_src[i] = idx * 8;
+    st_dst[i] = (pl * PJ_B + (rem >> 3)) * PJ_LD + (rem & 7) * 8;
+  }
+  f32x4 wreg[5];
+  constexpr int NSTAGE = 2 * PJ_NB;
+  auto load_w = [&](int stg) {
+    stg = stg < NSTAGE ? stg : NSTAGE - 1;
+    const __bf16* src = Wc + static_cast<size_t>(stg) * PJ_STAGE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wreg[i] = *reinterpret_cast<const f32x4*>(src + st_src[i]);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<f32x4*>(pj_lds + buf * PJ_STAGE_LDS + st_dst[i]) = wreg[i];
+  };
+  load_w(0);
+  // A fragments (v_mfma_f32_16x16x32_bf16: lane = row l15, k group g): a[mt][q][plane] = split(x[m0 + 32 rw + 16 mt + l15][32 q + 8 g .. + 7])
+  bf16x8 a[2][4][3];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = m0 + 32 * rw + 16 * mt + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (FULL || row < M) {
+        const float* xp = X + static_cast<int64_t>(row) * 128 + 32 * q + 8 * g;
+        v0 = *reinterpret_cast<const f32x4*>(xp);
+        v1 = *reinterpret_cast<const f32x4*>(xp + 4);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        __bf16 hh, mm, ll;
+        split3(c < 4 ? v0[c & 3] : v1[c & 3], hh, mm, ll);
+        a[mt][q][0][c] = hh; a[mt][q][1][c] = mm; a[mt][q][2][c] = ll;
+      }
+    }
+  }
+  for (int idx = tid; idx < PJ_ROWS * 12; idx += 512) {
+    const int row = idx / 12, cc = idx % 12, gr = m0 + row;
+    float v = 0.0f;
+    if (FULL || gr < M) v = cc < 9 ? R[static_cast<int64_t>(gr) * 9 + cc] : t[static_cast<int64_t>(gr) * 3 + (cc - 9)];
+    Rt[idx] = v;
+  }
+  MEM_FENCE();
+  store_w(0);
+  load_w(1);
+  MEM_FENCE();
+  __syncthreads();
+
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+  // one (mt, r) slice of a finished block: 3 consecutive columns of one row per lane
+  auto epilogue_piece = [&](const f32x4 (&acc)[2][3], int blk, int piece) {
+    const int mt = piece >> 2, r = piece & 3;
+    const int lrow = 32 * rw + 16 * mt + 4 * g + r;
+    float vx = acc[mt][0][r], vy = acc[mt][1][r], vz = acc[mt][2][r];
+    if (blk >= PJ_GQ / PJ_B) {  // point columns: local -> global frame
+      const f32x4* F = reinterpret_cast<const f32x4*>(Rt + lrow * 12);
+      const f32x4 f0 = F[0], f1 = F[1], f2 = F[2];  // R row-major 0..8, t 9..11
+      const float ox = (vx * f0[0] + vy * f0[3] + vz * f1[2]) + f2[1];
+      const float oy = (vx * f0[1] + vy * f1[0] + vz * f1[3]) + f2[2];
+      const float oz = (vx * f0[2] + vy * f1[1] + vz * f2[0]) + f2[3];
+      vx = ox; vy = oy; vz = oz;
+    }
+#ifdef PJB6_NOSTORE
+    if (M < 0) {
+#else
+    if (FULL || m0 + lrow < M) {
+#endif
+      pjb_f3 o{vx, vy, vz};
+      *reinterpret_cast<pjb_f3*>(ybase + (16 * mt + r) * PJ_NP + PJ_B * blk) = o;
+    }
+  };
+  // block `blk` into `cur`; the previous block's epilogue (`prev`) is issued between the MFMA groups of the first k half, so the
+  // stores drain while the matrix pipe works (all waves storing at once in front of the barrier left it idle)
+  auto run_block = [&](f32x4 (&cur)[2][3], const f32x4 (&prev)[2][3], int blk) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) cur[mt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      // stage s = 2 blk + kh is in buffer kh; stage s + 1 (loaded during stage s - 1) goes to buffer kh ^ 1, then s + 2 is requested
+      // - before this stage issues any global store (a wait for loads behind stores in flight degenerates to vmcnt(0))
+#ifndef PJB6_NOSTAGE
+      store_w(kh ^ 1);
+      load_w(2 * blk + kh + 2);
+#endif
+      MEM_FENCE();
+      const __bf16* wl = pj_lds + kh * PJ_STAGE_LDS + (48 * cw + l15) * PJ_LD + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 b[3][3];
+        constexpr int PORD[3] = {1, 0, 2};  // planes in the order the terms need them (mid, hi, lo): the first MFMAs wait for 3 reads, not 9
+#pragma unroll
+        for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+          for (int tt = 0; tt < 3; ++tt)
+            b[tt][PORD[pi]] = *reinterpret_cast<const bf16x8*>(wl + (PORD[pi] * PJ_B + 16 * tt) * PJ_LD + 32 * ks);
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#ifdef PJB6_NOMFMA
+              cur[mt][tt][term & 3] += static_cast<float>(a[mt][2 * kh + ks][TA[term]][0]) + static_cast<float>(b[tt][TB[term]][1]);
+#else
+              cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2 * kh + ks][TA[term]], b[tt][TB[term]], cur[mt][tt], 0, 0, 0);
+#endif
+          if (kh == 0 && blk > 0 && term >= 1 && term <= 4) {
+            epilogue_piece(prev, blk - 1, 4 * ks + term - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  };
+  f32x4 accA[2][3], accB[2][3];
+  static_assert(PJ_NB % 2 == 0, "two blocks per iteration");
+  for (int blk = 0; blk < PJ_NB; blk += 2) {
+    run_block(accA, accB, blk);
+    run_block(accB, accA, blk + 1);
+  }
+#pragma unroll
+  for (int piece = 0; piece < 8; ++piece) epilogue_piece(accB, PJ_NB - 1, piece);
+}
+
+size_t proj_frames_b6_scratch_bytes() { return static_cast<size_t>(2 * PJ_NB) * PJ_STAGE_ELEMS * sizeof(__bf16); }
+
+// W6 = {wq_s, wk_s, wv_s, wq_p, wk_p, wv_p} -> stage-ordered split planes (proj_frames_b6_scratch_bytes() bytes, 16-byte aligned)
+int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st) {
+  DIFFAB_REQUIRE(planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, DIFFAB_ERR_ARG, "pjsplit: bad operands");
+  hipLaunchKernelGGL(pjsplit_kernel, dim3((PJ_NP * 128 + 255) / 256), dim3(256), 0, st, W6[0], W6[1], W6[2], W6[3], W6[4], W6[5],
+                     static_cast<__bf16*>(planes));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// the six projections of one IPA layer (D = 128) into proj[rows x 1344], weights given as split planes (launch_pjsplit)
+int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st) {
+  DIFFAB_REQUIRE(planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(proj) & 3) == 0 && rows >= 1,
+                 DIFFAB_ERR_ARG, "proj_frames_b6: unsupported operands");
+  const __bf16* Wc = static_cast<const __bf16*>(planes);
+  const dim3 grid((rows + PJ_ROWS - 1) / PJ_ROWS);
+  if (rows % PJ_ROWS == 0) {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         PJ_LDS_BYTES));
+    hipLaunchKernelGGL(proj_frames_b6_kernel<true>, grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, proj, rows);
+  } else {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         PJ_LDS_BYTES));
+    hipLaunchKernelGGL(proj_frames_b6_kernel<false>, grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, proj, rows);
   }
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
