@@ -193,9 +193,14 @@ static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weight
   if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, tp.cat2, st)) return rc;
   if (int rc = launch_linear(tp.cat2, 2 * D, w->res_w0, w->res_b0, tp.h1, D, rows, D, 2 * D, true, st)) return rc;
   if (int rc = launch_linear(tp.h1, D, w->res_w2, w->res_b2, tp.x[0], D, rows, D, D, false, st)) return rc;
-  for (int l = 0; l < d->NL; ++l)
-    if (int rc = ipa_layer_dispatch(d, &w->layers[l], tp.x[l], pair_ctx, O_t, x_t, tp.x[l + 1], tp.ipa_ws[l], flags, st, tp.sp[l], tp.d2[l]))
+  const bool b6 = tp.planes && use_b6_gemm() && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d);
+  for (int l = 0; l < d->NL; ++l) {
+    if (b6)
+      if (int rc = ipa_layer_split_weights(&w->layers[l], tp.planes, st)) return rc;
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], tp.x[l], pair_ctx, O_t, x_t, tp.x[l + 1], tp.ipa_ws[l], flags, st, tp.sp[l], tp.d2[l],
+                                    b6 ? tp.planes : nullptr))
       return rc;
+  }
   if (int rc = launch_beta_concat(tp.x[d->NL], beta, D, d->K, rows, tp.cat3, st)) return rc;
   const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
   float* outs[3] = {out_eps, tp.vbuf, tp.logits};

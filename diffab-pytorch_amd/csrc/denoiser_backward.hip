@@ -1259,7 +1259,7 @@ size_t train_tape_floats(const diffab_dims* d) {
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
   const size_t keep = (fast_path_supported(d) && attention_split_supported(d)) ? 2 * static_cast<size_t>(d->B) * d->H * d->K * d->K : 0;
   return rows * (2 * D + D + D) + static_cast<size_t>(d->NL) * (rows * (NP + F + D) + keep) + rows * (D + 3) + 6 * rows * D + rows * 3 +
-         rows * d->V + 1024;
+         rows * d->V + 1024 + (fast_path_supported(d) ? ipa_layer_planes_bytes() / sizeof(float) + 64 : 0);
 }
 
 TrainTape carve_tape(const diffab_dims* d, float* base) {
@@ -1288,6 +1288,11 @@ TrainTape carve_tape(const diffab_dims* d, float* base) {
   t.vbuf = take(rows * 3);
   t.logits = take(rows * d->V);
   t.scratch = take(1024);  // (the +1024 of train_tape_floats)
+  t.planes = nullptr;
+  if (fast_path_supported(d)) {  // split bf16 planes of one layer's dense weights, re-filled by every layer's forward (stream order)
+    float* raw = take(ipa_layer_planes_bytes() / sizeof(float) + 64);
+    t.planes = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(raw) + 255) & ~static_cast<uintptr_t>(255));
+  }
   return t;
 }
 

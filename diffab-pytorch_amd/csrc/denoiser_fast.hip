@@ -1108,6 +1108,7 @@ bool use_b6_gemm() {
 static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 size_t ipa_layer_planes_bytes() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st) {
+  DIFFAB_REQUIRE(w && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && w->w_out, DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
   if (int rc = launch_pjsplit(W6, planes, st)) return rc;
   return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + round256(proj_frames_b6_scratch_bytes()), st);

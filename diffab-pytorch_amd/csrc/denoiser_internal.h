@@ -82,6 +82,7 @@ constexpr int kMaxLayers = 16;
 struct TrainTape {
   float *cat2, *h1, *x[kMaxLayers + 1], *ipa_ws[kMaxLayers], *cat3, *t1[3], *t2[3], *vbuf, *logits;
   float* scratch;  // 1024 floats: partial sums of the loss reduction
+  void* planes;    // ipa_layer_planes_bytes(): the current layer's split weights for the bf16x6 forward GEMMs (null off the MFMA path)
   // per layer, benchmark geometry with K = 64 / 128 only (else null): the attention probabilities and the squared point distances
   // [b][h][i][j], saved by the three-launch forward so that the backward does not recompute them
   float *sp[kMaxLayers], *d2[kMaxLayers];
