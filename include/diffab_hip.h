@@ -17,7 +17,16 @@
  *     (torch.bool);
  *   - the caller owns every buffer including the workspace (size from the
  *     matching *_workspace_bytes query); kernels are enqueued on `stream` and
- *     never synchronise; no hidden global state; re-entrant across streams;
+ *     never synchronise; no hidden global state; re-entrant across streams.
+ *     Exceptions, all opt-in and off by default: (a) the two DIAGNOSTIC entry points
+ *     diffab_kernel_timer_enable/read and diffab_debug_set_attn_stamps keep
+ *     process-global state (an event list, a stamp-buffer pointer), are not
+ *     thread-safe and must not be left enabled in production; (b)
+ *     DIFFAB_FLAG_GRAPH_SAMPLER makes diffab_sample_loop drain a private stream
+ *     before it returns; (c) the environment variables DIFFAB_FP32_GEMM,
+ *     DIFFAB_ATTN_FLASH, DIFFAB_FLASH_WAVES, DIFFAB_E_DEPTH0 select kernel
+ *     variants for A/B timing, are read once per process, and change results
+ *     only within rounding;
  *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
  *     diffab_last_error() gives the thread's last message.
  */
