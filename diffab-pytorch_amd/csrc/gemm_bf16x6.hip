@@ -26,10 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int BK = 32;        // k per MFMA (16x16x32) = k per weight chunk
-constexpr int WLD = 40;       // LDS row stride of a staged row in bf16 units (32 + 8): 80 bytes = 5 x 16.  A 32x32x16 fragment read has 32
-                              // different rows on lanes 0..31 (same k half) and ds_read_b128 serves 16 of them per cycle: an odd
-                              // multiple of 16 bytes puts those 16 rows on 16 different bank quads
-constexpr int BROWS = 128;    // rows of X per work-group
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = static_cast<__bf16>(x);
@@ -54,52 +50,63 @@ __global__ void wsplit128_kernel(const float* __restrict__ W, int ldw, int Kd, _
   out[base + 2 * 128 * BK] = l;
 }
 
-// LDS (dynamic, 122 880 B): weights Ws[2 buffers][3 planes][128 rows][WLD], then X As[2][3][128][WLD] - both operands are staged as
-// split bf16 planes: every element of X is split ONCE per work-group (its two column waves share the rows), and X is read from
-// HBM in full 128-byte lines (the MFMA fragment shape - adjacent lanes on different rows - costs the texture addresser four lines
-// per lane quad: with fragment-shaped loads straight from global memory this kernel took 58 us instead of ~30).
-constexpr int kB6LdsBytes = 2 * 2 * 3 * 128 * WLD * 2;
+// LDS (dynamic): weights Ws[2 buffers][3 planes][128 rows][32 k], then X As[2][3][ROWS][32] - both operands are staged as split
+// bf16 planes: every element of X is split ONCE per work-group (its two column waves share the rows), and X is read from HBM in
+// full 128-byte lines (the MFMA fragment shape - adjacent lanes on different rows - costs the texture addresser four lines per
+// lane quad: with fragment-shaped loads straight from global memory this kernel took 58 us instead of 48).  Rows are 64 bytes,
+// unpadded; the 16-byte slot s of row r lives at slot s ^ ((r >> 2) & 3), which makes the 32-row ds_read_b128 fragment reads
+// conflict-free (the four 16-lane groups of the instruction each take 16 different bank quads).
+// ROWS = 128: 512 threads, waves 4 (rows) x 2 (columns), 96 KiB of LDS, one work-group per CU.
+// ROWS = 64: 256 threads, waves 2 x 2, 72 KiB: two work-groups per CU - one group's MFMAs run under the other's staging and
+// barrier - and twice the work-groups for the same rows (B <= 128 patches per GPU leave half the CUs idle with 128-row groups).
+template <int ROWS>
+constexpr int b6_lds_bytes() { return 2 * 3 * (128 + ROWS) * BK * 2; }
+__device__ __forceinline__ int b6_off(int row, int slot) { return row * BK + 8 * (slot ^ ((row >> 2) & 3)); }  // bf16 elements
 
-template <bool RELU>
-__global__ __launch_bounds__(512) void rowgemm128_b6_kernel(const float* __restrict__ X, int ldx, const __bf16* __restrict__ Wc,
-                                                            const float* __restrict__ bias, const int64_t* __restrict__ bias_idx,
-                                                            int bias_div, float* __restrict__ Y, int ldy, int M, int Kd) {
+template <bool RELU, int ROWS>
+__global__ __launch_bounds__(ROWS * 4) void rowgemm128_b6_kernel(const float* __restrict__ X, int ldx, const __bf16* __restrict__ Wc,
+                                                                 const float* __restrict__ bias, const int64_t* __restrict__ bias_idx,
+                                                                 int bias_div, float* __restrict__ Y, int ldy, int M, int Kd) {
   // bias: one vector (bias_idx == nullptr, bias_div == 0), or a table of 128-wide rows indexed by bias_idx[row] or row / bias_div
+  constexpr int T = ROWS * 4, NRW = ROWS / 32;  // threads; row waves
   extern __shared__ __attribute__((aligned(16))) __bf16 b6_lds[];
   __bf16* Ws = b6_lds;
-  __bf16* As = b6_lds + 2 * 3 * 128 * WLD;
+  __bf16* As = b6_lds + 2 * 3 * 128 * BK;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int l31 = lane & 31, hk = lane >> 5, rw = wv & 3, cw = wv >> 2;  // v_mfma_f32_32x32x16_bf16: 24 of its 32 cycles leave the
-                                                                         // vector issue port free (16x16x32: 8 of 16; measured: the
-                                                                         // splitting VALU work then adds to the MFMA time)
-  const int m0 = blockIdx.x * BROWS;
+  const int l31 = lane & 31, hk = lane >> 5, rw = wv % NRW, cw = wv / NRW;  // v_mfma_f32_32x32x16_bf16: wave tile 32 rows x 64 columns
+  const int m0 = blockIdx.x * ROWS;
   const int nchunk = Kd / BK;
-#ifndef B6_STAGE_MODE
-#define B6_STAGE_MODE 0  // 0: every wave stages after its MFMAs | 1: before | 2: waves 4-7 before, 0-3 after
-#endif
-  const bool stage_first = B6_STAGE_MODE == 1 || (B6_STAGE_MODE == 2 && wv >= 4);
-  // weight staging: thread -> (plane p = pass, LDS row tid / 4, 16-byte part tid % 4): a straight copy of the chunk's 24 KiB
-  const int st_row = tid >> 2, st_part = tid & 3;
-  f32x4 wreg[2][3];
+  // weight staging: a chunk is 3 planes x 128 rows x 64 bytes = 1536 16-byte pieces, a straight copy of 24 KiB
+  constexpr int WP = 1536 / T;  // pieces per thread (3 or 6)
+  int w_dst[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int idx = tid + T * i, p = idx / 512, row = (idx % 512) >> 2, part = idx & 3;
+    w_dst[i] = (p * 128) * BK + b6_off(row, part);
+  }
+  f32x4 wreg[2][WP];
   auto load_w = [&](int slot, int ch) {
     ch = ch < nchunk ? ch : nchunk - 1;  // unconditional prefetch (a branch around it makes the compiler wait for it at once)
-    const __bf16* src = Wc + static_cast<size_t>(ch) * (3 * 128 * BK) + st_row * BK + st_part * 8;
+    const __bf16* src = Wc + static_cast<size_t>(ch) * (3 * 128 * BK) + tid * 8;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) wreg[slot][p] = *reinterpret_cast<const f32x4*>(src + p * (128 * BK));
+    for (int i = 0; i < WP; ++i) wreg[slot][i] = *reinterpret_cast<const f32x4*>(src + T * 8 * i);
   };
   auto store_w = [&](int slot, int buf) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(Ws + ((buf * 3 + p) * 128 + st_row) * WLD + st_part * 8) = wreg[slot][p];
+    for (int i = 0; i < WP; ++i) *reinterpret_cast<f32x4*>(Ws + buf * (3 * 128 * BK) + w_dst[i]) = wreg[slot][i];
   };
-  // X staging: a chunk is 128 rows x 128 bytes; thread -> rows tid / 8 and 64 + tid / 8, 16-byte part tid % 8 (8 lanes = one line);
-  // rows past M are clamped (their results are never stored).  Requested four chunks ahead (HBM), ring slots are compile-time.
+  // X staging: a chunk is ROWS rows x 128 bytes; thread -> rows tid / 8 and ROWS / 2 + tid / 8, 16-byte part tid % 8 (8 lanes = one
+  // line); rows past M are clamped (their results are never stored).  Requested four chunks ahead (HBM), ring slots are compile-time.
   const int xa_row = tid >> 3, xa_part = tid & 7;
   const float* xsrc[2];
+  int x_dst[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int row = m0 + xa_row + 64 * j;
+    const int lrow = xa_row + (ROWS / 2) * j;
+    int row = m0 + lrow;
     row = row < M ? row : M - 1;
     xsrc[j] = X + static_cast<int64_t>(row) * ldx + 4 * xa_part;
+    x_dst[j] = b6_off(lrow, xa_part >> 1) + 4 * (xa_part & 1);
   }
   f32x4 xreg[4][2];
   auto load_x = [&](int slot, int ch) {
@@ -115,17 +122,13 @@ __global__ __launch_bounds__(512) void rowgemm128_b6_kernel(const float* __restr
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         __bf16 hh, mm, ll;
-#ifdef B6_ABL_NOSPLIT
-        hh = mm = ll = static_cast<__bf16>(xreg[slot][j][c]);
-#else
         split3(xreg[slot][j][c], hh, mm, ll);
-#endif
         h[c] = hh; m[c] = mm; l[c] = ll;
       }
-      __bf16* dst = As + ((buf * 3) * 128 + xa_row + 64 * j) * WLD + 4 * xa_part;
+      __bf16* dst = As + buf * (3 * ROWS * BK) + x_dst[j];
       *reinterpret_cast<bf16x4*>(dst) = h;
-      *reinterpret_cast<bf16x4*>(dst + 128 * WLD) = m;
-      *reinterpret_cast<bf16x4*>(dst + 2 * 128 * WLD) = l;
+      *reinterpret_cast<bf16x4*>(dst + ROWS * BK) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * ROWS * BK) = l;
     }
   };
   f32x16 acc[2];  // wave tile: 32 rows x 64 columns = two 32 x 32 accumulators
@@ -145,49 +148,38 @@ __global__ __launch_bounds__(512) void rowgemm128_b6_kernel(const float* __restr
   load_x(0, 4);
   MEM_FENCE();
   __syncthreads();
+  // fragments: lane (row or column l31, k half hk) of k-step ks reads the 16-byte slot 2 ks + hk of its row
+  const int fx = (l31 >> 2) & 3;
+  const int a_off = (32 * rw + l31) * BK, w_off = (64 * cw + l31) * BK;
   for (int ch0 = 0; ch0 < nchunk; ch0 += 4) {  // nchunk % 4 == 0 (launcher)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ch = ch0 + u, buf = u & 1;
-      // stage chunk ch + 1 into the other buffers (its loads were issued two / four iterations ago), then refill the ring slots
-      auto stage = [&]() {
-#ifndef B6_ABL_NOSTAGE
-        store_w((u + 1) & 1, buf ^ 1);
-        store_x((u + 1) & 3, buf ^ 1);
-#ifndef B6_ABL_NOLOAD
-        load_w((u + 1) & 1, ch + 3);
-        load_x((u + 1) & 3, ch + 5);
-#endif
-        MEM_FENCE();
-#endif
-      };
-      // The two waves of a SIMD (w, w + 4) are in lockstep behind the barrier: if both staged after their MFMAs, matrix and vector /
-      // LDS work would take turns on every SIMD (measured: 3.0 k cycles per chunk for 1.5 k of MFMAs).  Waves 4-7 stage first.
-      if (stage_first) stage();
-      // fragments: lane (row or column = l31, k half hk) of k-step ks reads 16 bytes: k = 16 ks + 8 hk .. + 7
-      const __bf16* al = As + (buf * 3 * 128 + 32 * rw + l31) * WLD + 8 * hk;
-      const __bf16* wl = Ws + (buf * 3 * 128 + 64 * cw + l31) * WLD + 8 * hk;
+      const __bf16* al = As + buf * (3 * ROWS * BK) + a_off;
+      const __bf16* wl = Ws + buf * (3 * 128 * BK) + w_off;
       constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi): smallest first
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        const int so = 8 * ((2 * ks + hk) ^ fx);
         bf16x8 a[3], b[2][3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          a[p] = *reinterpret_cast<const bf16x8*>(al + (p * 128) * WLD + 16 * ks);
+          a[p] = *reinterpret_cast<const bf16x8*>(al + (p * ROWS) * BK + so);
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) b[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (p * 128 + 32 * tt) * WLD + 16 * ks);
+          for (int tt = 0; tt < 2; ++tt) b[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (p * 128 + 32 * tt) * BK + so);
         }
 #pragma unroll
         for (int term = 0; term < 6; ++term)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt)
-#ifdef B6_ABL_NOMFMA
-            acc[tt][term] += static_cast<float>(a[TA[term]][0]) + static_cast<float>(b[tt][TB[term]][1]);
-#else
             acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[term]], b[tt][TB[term]], acc[tt], 0, 0, 0);
-#endif
       }
-      if (!stage_first) stage();
+      // stage chunk ch + 1 into the other buffers (its loads were issued two / four iterations ago), then refill the ring slots
+      store_w((u + 1) & 1, buf ^ 1);
+      store_x((u + 1) & 3, buf ^ 1);
+      load_w((u + 1) & 1, ch + 3);
+      load_x((u + 1) & 3, ch + 5);
+      MEM_FENCE();
       __syncthreads();
     }
   }
@@ -233,16 +225,28 @@ int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const flo
   DIFFAB_REQUIRE(rowgemm128_b6_ok(X, ldx, Y, ldy, M, Kd) && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, DIFFAB_ERR_ARG,
                  "rowgemm128_b6: unsupported operands");
   const __bf16* Wc = static_cast<const __bf16*>(planes);
-  const dim3 grid((M + BROWS - 1) / BROWS);
-  if (relu) {
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kB6LdsBytes));
-    hipLaunchKernelGGL(rowgemm128_b6_kernel<true>, grid, dim3(512), kB6LdsBytes, st, X, ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);
+  // 128-row work-groups when they fill the chip (measured at 256 groups: 47 us against 53 for 64-row groups, K = 1024), 64-row
+  // groups below that (B <= 128 patches of 128 residues per GPU: twice the groups); DIFFAB_B6_ROWS=64|128 forces one
+  static const int rows_force = [] {
+    const char* e = getenv("DIFFAB_B6_ROWS");
+    return e ? atoi(e) : 0;
+  }();
+  const int rows_env = rows_force ? rows_force : ((M + 127) / 128 >= 256 ? 128 : 64);
+#define B6_LAUNCH(RELU_, ROWS_)                                                                                                         \
+  do {                                                                                                                                  \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<RELU_, ROWS_>),                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, b6_lds_bytes<ROWS_>()));                           \
+    hipLaunchKernelGGL((rowgemm128_b6_kernel<RELU_, ROWS_>), dim3((M + ROWS_ - 1) / ROWS_), dim3(ROWS_ * 4), b6_lds_bytes<ROWS_>(), st, X, \
+                       ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);                                                               \
+  } while (0)
+  if (rows_env == 128) {
+    if (relu) B6_LAUNCH(true, 128);
+    else B6_LAUNCH(false, 128);
   } else {
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kB6LdsBytes));
-    hipLaunchKernelGGL(rowgemm128_b6_kernel<false>, grid, dim3(512), kB6LdsBytes, st, X, ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);
+    if (relu) B6_LAUNCH(true, 64);
+    else B6_LAUNCH(false, 64);
   }
+#undef B6_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
