@@ -251,6 +251,11 @@ static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
                    const GemmSegs* segs = nullptr) {
   GemmSegs sg{};
   if (segs) sg = *segs;
+  if (use_b6_gemm() && gemm_tn_b6_ok(A, lda, B, ldb, M, N1, N2) && M >= 128) {
+    bool seg_ok = true;
+    for (int i = 0; i < sg.nseg; ++i) seg_ok = seg_ok && sg.n_end[i] % 64 == 0;
+    if (seg_ok) return launch_gemm_tn_b6(A, lda, B, ldb, C, ldc, M, N1, N2, sg.p, sg.n_end, sg.nseg, st);
+  }
   const bool aligned = N1 % 64 == 0 && N2 % 64 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(B) & 15) == 0;
   // enough (tile, M-chunk) waves to fill the chip: ~2048 waves, chunks of at least 256 rows
@@ -1296,6 +1301,15 @@ TrainTape carve_tape(const diffab_dims* d, float* base) {
   return t;
 }
 
+// split bf16 planes of one transposed weight operand at a time (bf16x6 input-gradient products; stream-ordered reuse)
+static size_t bwd_planes_floats(const diffab_dims* d) {
+  if (d->D != 128) return 0;
+  const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
+  const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
+  const size_t kmax = ((NP > F ? NP : F) + 31) / 32 * 32;
+  const size_t a = rowgemm128_b6_scratch_bytes(static_cast<int>(kmax)), b = xstat_b6_scratch_bytes(static_cast<int>(F));
+  return (a > b ? a : b) / sizeof(float) + 128;
+}
 size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
   const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
@@ -1303,7 +1317,8 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
   return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64 + 2 * HKK +
          rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64 +
-         ((fast_path_supported(d) && attention_split_supported(d)) ? 3 * HKK : 0);  // probabilities / g, squared distances, dA_kv
+         ((fast_path_supported(d) && attention_split_supported(d)) ? 3 * HKK : 0) +  // probabilities / g, squared distances, dA_kv
+         bwd_planes_floats(d);
 }
 
 int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
@@ -1337,6 +1352,9 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
   float* Pn = mfma_probs ? take(HKK) : nullptr;
   float* D2g = mfma_probs ? take(HKK) : nullptr;
   float* dAkv = mfma_probs ? take(HKK) : nullptr;
+  void* planes = nullptr;  // bf16x6 input-gradient products (D = 128): the transposed weights as split planes, one operand at a time
+  if (bwd_planes_floats(d) > 0 && use_b6_gemm())
+    planes = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(take(bwd_planes_floats(d))) + 255) & ~static_cast<uintptr_t>(255));
 
   hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
   DIFFAB_LAUNCH_CHECK();
@@ -1371,8 +1389,14 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     const float* feat = tp.ipa_ws[l] + static_cast<size_t>(rows) * NP;
     const float* xin = tp.x[l];
     // to_out
-    if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows, D, F,
-                            false, st)) return rc;
+    if (planes && (reinterpret_cast<uintptr_t>(dcur) & 15) == 0) {  // d feat = d y W_out on the bf16x6 x-stationary kernel
+      if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), nullptr, F, rows, D,
+                              F, false, st)) return rc;
+      if (int rc = launch_xstat_b6(dcur, lw->w_out, 1, F, dfeat, F, rows, F, planes, st)) return rc;
+    } else if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows,
+                                   D, F, false, st)) {
+      return rc;
+    }
     const size_t lds = (3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) * sizeof(float);
     const int vec = (DS % 4 == 0 && C % 4 == 0 && (PQ * 3) % 4 == 0 && (PV * 3) % 4 == 0 && H % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(pair_ctx) & 15) == 0 && (reinterpret_cast<uintptr_t>(lw->w_bias) & 15) == 0) ? 1 : 0;
@@ -1474,7 +1498,17 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     }
     if (segs_ok) {  // the six projections as ONE weight-gradient product and ONE input-gradient product over the 1344-wide dproj
       if (int rc = gemm_tn(dproj, NP, xin, D, nullptr, D, rows, NP, D, st, &gd)) return rc;
-      if (int rc = gemm_nn(dproj, NP, nullptr, D, dnxt, D, rows, D, NP, false, st, &gw)) return rc;
+      if (planes && NP % 32 == 0 && rowgemm128_b6_ok(dproj, NP, dnxt, D, rows, NP)) {
+        // dx = dproj [W_q_s; ...; W_v_p] as Y = X W'^T with W'[n][k] = W_seg[k - k0][n]: six strided splits into one set of planes
+        int k0 = 0;
+        for (int q = 0; q < 6; ++q) {
+          if (int rc = launch_wsplit128_strided(Ws[q], 1, D, Ns[q], k0, planes, st)) return rc;
+          k0 += Ns[q];
+        }
+        if (int rc = launch_rowgemm128_b6p(dproj, NP, planes, nullptr, nullptr, 0, dnxt, D, rows, NP, false, st)) return rc;
+      } else if (int rc = gemm_nn(dproj, NP, nullptr, D, dnxt, D, rows, D, NP, false, st, &gw)) {
+        return rc;
+      }
     } else {
       col = 0;
       for (int q = 0; q < 6; ++q) {

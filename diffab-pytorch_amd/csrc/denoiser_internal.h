@@ -36,6 +36,7 @@ int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const fl
 size_t rowgemm128_b6_scratch_bytes(int Kd);
 bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
 int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st);
+int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, int k0, void* planes, hipStream_t st);  // (n, k) = W[n sn + k sk]
 int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                           int ldy, int M, int Kd, bool relu, hipStream_t st);
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
@@ -45,6 +46,13 @@ bool use_b6_gemm();  // false with DIFFAB_FP32_GEMM=1 in the environment
 size_t proj_frames_b6_scratch_bytes();
 int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st);
 int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st);
+// the same x-stationary kernel as a plain product Y[rows x N] = X[rows x 128] W'^T, (n, k) of W' = W[n sn + k sk] (to_out input gradient)
+size_t xstat_b6_scratch_bytes(int N);
+int launch_xstat_b6(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st);
+// weight-gradient product C[N1 x N2] += A[M x N1]^T B[M x N2] (transposing LDS reads); rows of C optionally spread over nseg matrices
+bool gemm_tn_b6_ok(const float* A, int lda, const float* B, int ldb, int M, int N1, int N2);
+int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* const* seg_ptrs,
+                      const int* seg_ends, int nseg, hipStream_t st);
 // split planes of one IPA layer's projection and to_out weights: ipa_layer_planes_bytes() bytes, 256-byte aligned
 size_t ipa_layer_planes_bytes();
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);

@@ -50,6 +50,21 @@ __global__ void wsplit128_kernel(const float* __restrict__ W, int ldw, int Kd, _
   out[base + 2 * 128 * BK] = l;
 }
 
+// the same planes from a strided view: element (n, k) of the 128 x kseg operand is W[n * sn + k * sk]; it lands at k index k0 + k
+// (k0 % 32 == 0).  Transposed weights for the input-gradient products (dX = dY W is Y = X W'^T with W' = W^T).
+__global__ void wsplit128_strided_kernel(const float* __restrict__ W, int64_t sn, int64_t sk, int kseg, int k0, __bf16* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (k, n): n fastest, so sn == 1 reads are coalesced
+  if (gid >= 128 * kseg) return;
+  const int n = gid & 127, k = gid >> 7;
+  __bf16 h, m, l;
+  split3(W[n * sn + k * sk], h, m, l);
+  const int kg = k0 + k, chunk = kg / BK, kk = kg % BK;
+  const size_t base = (static_cast<size_t>(chunk) * 3 * 128 + n) * BK + kk;
+  out[base] = h;
+  out[base + 128 * BK] = m;
+  out[base + 2 * 128 * BK] = l;
+}
+
 // LDS (dynamic): weights Ws[2 buffers][3 planes][128 rows][32 k], then X As[2][3][ROWS][32] - both operands are staged as split
 // bf16 planes: every element of X is split ONCE per work-group (its two column waves share the rows), and X is read from HBM in
 // full 128-byte lines (the MFMA fragment shape - adjacent lanes on different rows - costs the texture addresser four lines per
@@ -151,10 +166,11 @@ __global__ __launch_bounds__(ROWS * 4) void rowgemm128_b6_kernel(const float* __
   // fragments: lane (row or column l31, k half hk) of k-step ks reads the 16-byte slot 2 ks + hk of its row
   const int fx = (l31 >> 2) & 3;
   const int a_off = (32 * rw + l31) * BK, w_off = (64 * cw + l31) * BK;
-  for (int ch0 = 0; ch0 < nchunk; ch0 += 4) {  // nchunk % 4 == 0 (launcher)
+  for (int ch0 = 0; ch0 < nchunk; ch0 += 4) {  // ring slots are compile-time indices: four chunks per trip, the tail guarded (uniform)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ch = ch0 + u, buf = u & 1;
+      if (ch >= nchunk) break;
       const __bf16* al = As + buf * (3 * ROWS * BK) + a_off;
       const __bf16* wl = Ws + buf * (3 * 128 * BK) + w_off;
       constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi): smallest first
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(ROWS * 4) void rowgemm128_b6_kernel(const float* __
 size_t rowgemm128_b6_scratch_bytes(int Kd) { return static_cast<size_t>(3) * 128 * Kd * sizeof(__bf16); }
 
 bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd) {
-  return Kd % (4 * BK) == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+  return Kd % BK == 0 && Kd >= BK && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && M >= 1;
 }
 
@@ -215,6 +231,14 @@ bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, i
 int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st) {
   DIFFAB_REQUIRE(W && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && Kd % BK == 0, DIFFAB_ERR_ARG, "wsplit128: bad operands");
   hipLaunchKernelGGL(wsplit128_kernel, dim3((128 * Kd + 255) / 256), dim3(256), 0, st, W, ldw, Kd, static_cast<__bf16*>(planes));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, int k0, void* planes, hipStream_t st) {
+  DIFFAB_REQUIRE(W && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && k0 % BK == 0 && kseg >= 1, DIFFAB_ERR_ARG,
+                 "wsplit128_strided: bad operands");
+  hipLaunchKernelGGL(wsplit128_strided_kernel, dim3((128 * kseg + 255) / 256), dim3(256), 0, st, W, sn, sk, kseg, k0, static_cast<__bf16*>(planes));
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -302,16 +326,22 @@ __global__ void pjsplit_kernel(const float* __restrict__ W0, const float* __rest
   out[base + 2 * PJ_B * 64] = l;
 }
 
-template <bool FULL>  // FULL: M is a multiple of 128, no row guards
+// Geometry at run time: N output columns in NB (even) blocks of 96 (columns past N are zero planes, never stored), rows of Y ldy
+// floats apart, frames applied to blocks >= frames_from (NB: none; R, t may then be null).  The same kernel is the input-gradient
+// product of to_out: dfeat[M x 1024] = dy[M x 128] Wo, with the planes of Wo^T (xsplit_kernel).
+// PROJ: the geometry of the six projections at compile time (runtime geometry costs this kernel 11 %: 70 vs 63 us)
+template <bool FULL, bool PROJ>  // FULL: M is a multiple of 128, no row guards
 __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wc,
                                                              const float* __restrict__ R, const float* __restrict__ t,
-                                                             float* __restrict__ Y, int M) {
+                                                             float* __restrict__ Y, int M, int N_, int NB_, int ldy_, int frames_from_) {
+  const int N = PROJ ? PJ_NP : N_, NB = PROJ ? PJ_NB : NB_, ldy = PROJ ? PJ_NP : ldy_, frames_from = PROJ ? PJ_GQ / PJ_B : frames_from_;
   extern __shared__ __attribute__((aligned(16))) __bf16 pj_lds[];  // [2][3][96][PJ_LD] weights, then [128][12] frames (fp32)
   float* Rt = reinterpret_cast<float*>(pj_lds + 2 * PJ_STAGE_LDS);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4, rw = wv & 3, cw = wv >> 2;
   const int m0 = blockIdx.x * PJ_ROWS;
-  float* ybase = Y + static_cast<int64_t>(m0 + 32 * rw + 4 * g) * PJ_NP + 48 * cw + 3 * l15;
+  float* ybase = Y + static_cast<int64_t>(m0 + 32 * rw + 4 * g) * ldy + 48 * cw + 3 * l15;
+  const int col0 = 48 * cw + 3 * l15;  // first of this lane's three columns inside a block
 
   // weight staging: a stage is 2304 16-byte pieces, piece idx -> (plane idx / 768, row (idx % 768) / 8, part idx % 8); thread tid takes
   // idx = tid + 512 i (i = 0..3) and 2048 + (tid & 255) - the two halves of the work-group duplicate the last 256 (no branch)
@@ -324,7 +354,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     st_dst[i] = (pl * PJ_B + (rem >> 3)) * PJ_LD + (rem & 7) * 8;
   }
   f32x4 wreg[5];
-  constexpr int NSTAGE = 2 * PJ_NB;
+  const int NSTAGE = 2 * NB;
   auto load_w = [&](int stg) {
     stg = stg < NSTAGE ? stg : NSTAGE - 1;
     const __bf16* src = Wc + static_cast<size_t>(stg) * PJ_STAGE_ELEMS;
@@ -357,12 +387,13 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
       }
     }
   }
-  for (int idx = tid; idx < PJ_ROWS * 12; idx += 512) {
-    const int row = idx / 12, cc = idx % 12, gr = m0 + row;
-    float v = 0.0f;
-    if (FULL || gr < M) v = cc < 9 ? R[static_cast<int64_t>(gr) * 9 + cc] : t[static_cast<int64_t>(gr) * 3 + (cc - 9)];
-    Rt[idx] = v;
-  }
+  if (frames_from < NB)
+    for (int idx = tid; idx < PJ_ROWS * 12; idx += 512) {
+      const int row = idx / 12, cc = idx % 12, gr = m0 + row;
+      float v = 0.0f;
+      if (FULL || gr < M) v = cc < 9 ? R[static_cast<int64_t>(gr) * 9 + cc] : t[static_cast<int64_t>(gr) * 3 + (cc - 9)];
+      Rt[idx] = v;
+    }
   MEM_FENCE();
   store_w(0);
   load_w(1);
@@ -375,7 +406,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     const int mt = piece >> 2, r = piece & 3;
     const int lrow = 32 * rw + 16 * mt + 4 * g + r;
     float vx = acc[mt][0][r], vy = acc[mt][1][r], vz = acc[mt][2][r];
-    if (blk >= PJ_GQ / PJ_B) {  // point columns: local -> global frame
+    if (blk >= frames_from) {  // point columns: local -> global frame
       const f32x4* F = reinterpret_cast<const f32x4*>(Rt + lrow * 12);
       const f32x4 f0 = F[0], f1 = F[1], f2 = F[2];  // R row-major 0..8, t 9..11
       const float ox = (vx * f0[0] + vy * f0[3] + vz * f1[2]) + f2[1];
@@ -383,13 +414,16 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
       const float oz = (vx * f0[2] + vy * f1[1] + vz * f2[0]) + f2[3];
       vx = ox; vy = oy; vz = oz;
     }
-#ifdef PJB6_NOSTORE
-    if (M < 0) {
-#else
     if (FULL || m0 + lrow < M) {
-#endif
-      pjb_f3 o{vx, vy, vz};
-      *reinterpret_cast<pjb_f3*>(ybase + (16 * mt + r) * PJ_NP + PJ_B * blk) = o;
+      float* yp = ybase + (16 * mt + r) * ldy + PJ_B * blk;
+      const int c = PJ_B * blk + col0;
+      if (c + 2 < N) {
+        pjb_f3 o{vx, vy, vz};
+        *reinterpret_cast<pjb_f3*>(yp) = o;
+      } else {  // the block that straddles N (N % 96 != 0)
+        if (c < N) yp[0] = vx;
+        if (c + 1 < N) yp[1] = vy;
+      }
     }
   };
   // block `blk` into `cur`; the previous block's epilogue (`prev`) is issued between the MFMA groups of the first k half, so the
@@ -403,10 +437,8 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     for (int kh = 0; kh < 2; ++kh) {
       // stage s = 2 blk + kh is in buffer kh; stage s + 1 (loaded during stage s - 1) goes to buffer kh ^ 1, then s + 2 is requested
       // - before this stage issues any global store (a wait for loads behind stores in flight degenerates to vmcnt(0))
-#ifndef PJB6_NOSTAGE
       store_w(kh ^ 1);
       load_w(2 * blk + kh + 2);
-#endif
       MEM_FENCE();
       const __bf16* wl = pj_lds + kh * PJ_STAGE_LDS + (48 * cw + l15) * PJ_LD + 8 * g;
 #pragma unroll
@@ -424,11 +456,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt)
-#ifdef PJB6_NOMFMA
-              cur[mt][tt][term & 3] += static_cast<float>(a[mt][2 * kh + ks][TA[term]][0]) + static_cast<float>(b[tt][TB[term]][1]);
-#else
               cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2 * kh + ks][TA[term]], b[tt][TB[term]], cur[mt][tt], 0, 0, 0);
-#endif
           if (kh == 0 && blk > 0 && term >= 1 && term <= 4) {
             epilogue_piece(prev, blk - 1, 4 * ks + term - 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -439,13 +467,12 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     }
   };
   f32x4 accA[2][3], accB[2][3];
-  static_assert(PJ_NB % 2 == 0, "two blocks per iteration");
-  for (int blk = 0; blk < PJ_NB; blk += 2) {
+  for (int blk = 0; blk < NB; blk += 2) {  // NB is even (launcher)
     run_block(accA, accB, blk);
     run_block(accB, accA, blk + 1);
   }
 #pragma unroll
-  for (int piece = 0; piece < 8; ++piece) epilogue_piece(accB, PJ_NB - 1, piece);
+  for (int piece = 0; piece < 8; ++piece) epilogue_piece(accB, NB - 1, piece);
 }
 
 size_t proj_frames_b6_scratch_bytes() { return static_cast<size_t>(2 * PJ_NB) * PJ_STAGE_ELEMS * sizeof(__bf16); }
@@ -459,22 +486,238 @@ int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st) {
   return DIFFAB_OK;
 }
 
-// the six projections of one IPA layer (D = 128) into proj[rows x 1344], weights given as split planes (launch_pjsplit)
-int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st) {
+static int launch_xstat(const float* x, const void* planes, const float* R, const float* t, float* Y, int rows, int N, int NB, int ldy,
+                        int frames_from, hipStream_t st) {
   DIFFAB_REQUIRE(planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(proj) & 3) == 0 && rows >= 1,
+                     (reinterpret_cast<uintptr_t>(Y) & 3) == 0 && rows >= 1 && NB % 2 == 0 && NB * PJ_B >= N,
                  DIFFAB_ERR_ARG, "proj_frames_b6: unsupported operands");
   const __bf16* Wc = static_cast<const __bf16*>(planes);
   const dim3 grid((rows + PJ_ROWS - 1) / PJ_ROWS);
+  const bool proj_geom = N == PJ_NP && NB == PJ_NB && ldy == PJ_NP && frames_from == PJ_GQ / PJ_B;
+#define XSTAT_LAUNCH(FULL_, PROJ_)                                                                                                       \
+  do {                                                                                                                                   \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<FULL_, PROJ_>),                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, PJ_LDS_BYTES));                                      \
+    hipLaunchKernelGGL((proj_frames_b6_kernel<FULL_, PROJ_>), grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, Y, rows, N, NB, ldy,         \
+                       frames_from);                                                                                                     \
+  } while (0)
   if (rows % PJ_ROWS == 0) {
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         PJ_LDS_BYTES));
-    hipLaunchKernelGGL(proj_frames_b6_kernel<true>, grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, proj, rows);
+    if (proj_geom) XSTAT_LAUNCH(true, true);
+    else XSTAT_LAUNCH(true, false);
   } else {
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         PJ_LDS_BYTES));
-    hipLaunchKernelGGL(proj_frames_b6_kernel<false>, grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, proj, rows);
+    if (proj_geom) XSTAT_LAUNCH(false, true);
+    else XSTAT_LAUNCH(false, false);
   }
+#undef XSTAT_LAUNCH
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// the six projections of one IPA layer (D = 128) into proj[rows x 1344], weights given as split planes (launch_pjsplit)
+int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st) {
+  return launch_xstat(x, planes, R, t, proj, rows, PJ_NP, PJ_NB, PJ_NP, PJ_GQ / PJ_B, st);
+}
+
+// ---- the x-stationary kernel as a plain product: Y[rows x N] = X[rows x 128] W'^T, element (n, k) of W' = W[n sn + k sk]
+static int xstat_blocks(int N) { return ((N + PJ_B - 1) / PJ_B + 1) / 2 * 2; }
+size_t xstat_b6_scratch_bytes(int N) { return static_cast<size_t>(2 * xstat_blocks(N)) * PJ_STAGE_ELEMS * sizeof(__bf16); }
+__global__ void xsplit_kernel(const float* __restrict__ W, int64_t sn, int64_t sk, int N, int ncols, __bf16* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (k, column): column fastest (sn == 1 reads are coalesced)
+  if (gid >= ncols * 128) return;
+  const int gc = gid % ncols, k = gid / ncols;
+  __bf16 h, m, l;
+  split3(gc < N ? W[gc * sn + k * sk] : 0.0f, h, m, l);
+  const int blk = gc / PJ_B, rem = gc % PJ_B, cwl = rem / 48, r48 = rem % 48, j = r48 / 3, tt = r48 % 3;
+  const int lrow = 48 * cwl + 16 * tt + j, kh = k >> 6, kk = k & 63;
+  const size_t base = (static_cast<size_t>(blk * 2 + kh) * 3 * PJ_B + lrow) * 64 + kk;
+  out[base] = h;
+  out[base + PJ_B * 64] = m;
+  out[base + 2 * PJ_B * 64] = l;
+}
+int launch_xstat_b6(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st) {
+  DIFFAB_REQUIRE(W && scratch && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && N >= 1, DIFFAB_ERR_ARG, "xstat_b6: bad operands");
+  const int NB = xstat_blocks(N), ncols = NB * PJ_B;
+  hipLaunchKernelGGL(xsplit_kernel, dim3((ncols * 128 + 255) / 256), dim3(256), 0, st, W, sn, sk, N, ncols, static_cast<__bf16*>(scratch));
+  DIFFAB_LAUNCH_CHECK();
+  return launch_xstat(X, scratch, nullptr, nullptr, Y, rows, N, NB, ldy, NB, st);
+}
+
+// ================================================================== weight-gradient products: C[N1 x N2] += A^T B  (bf16x6)
+// A = dY [M x N1], B = X [M x N2], both fp32 row-major: the contraction runs over the rows, i.e. over the STRIDED index of both
+// operands, while a bf16 MFMA fragment wants 8 consecutive k per lane.  A work-group stages 32-row slabs of both operands as
+// split bf16 planes in their natural [row][column] orientation (full-line loads, split once) and reads the fragments with
+// ds_read_b64_tr_b16, the transposing LDS read of gfx950: per 16-lane group, lane i receives column i of a 4-row block.  Two such
+// reads (rows 8 g .. 8 g + 3 and 8 g + 4 .. 8 g + 7 of the slab) are one 16x16x32 fragment; A and B use the same row order, which
+// is all the contraction needs.  Image: 256-byte rows, 16-byte chunk c of row r at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3))
+// (conflict-free transposed reads, MI355X guide T10 image (b)).  Output tile 128 x 128 per work-group, split over M in chunks;
+// partial tiles are added with fp32 atomics (as the f32 kernel does).  Rows of C may live in up to six matrices (the IPA
+// projections: `segs`), selected per 16-row group.
+namespace {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int TN_PLANE = 32 * 128;  // bf16 elements of one plane of one slab
+__device__ __forceinline__ int tn_off(int row, int chunk) {  // bf16 element offset of 16-byte chunk `chunk` of row `row`
+  return row * 128 + 8 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+}  // namespace
+
+struct TnSegs {
+  float* p[6];
+  int n_end[6];
+  int nseg;  // 0: one plain matrix C
+};
+
+__global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int m_chunk, int N1, TnSegs segs) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 tn_lds[];  // [2 buffers][A | B][3 planes][32][128]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int aw = wv & 3, bw = wv >> 2;  // wave tile: 32 rows of C (A columns) x 64 columns (B columns)
+  const int a0 = blockIdx.y * 128, b0 = blockIdx.x * 128;
+  const int m_lo = blockIdx.z * m_chunk, m_hi = min(M, m_lo + m_chunk);
+  const int nstep = (m_hi - m_lo + 31) / 32;
+  // staging: a slab is 32 rows x 128 columns of each operand = 1024 float4 each; thread -> rows tid / 32 and 16 + tid / 32, float4 tid % 32
+  const int s_row = tid >> 5, s_f4 = tid & 31;
+  const bool a_ok = a0 + 4 * s_f4 < N1;  // N1 % 4 == 0: a float4 is inside or outside
+  f32x4 ra[2][2], rb[2][2];
+  auto load_slab = [&](int slot, int step) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m_lo + 32 * step + s_row + 16 * j;
+      const bool ok = m < m_hi;
+      const int mc = ok ? m : m_lo;  // clamped address, zeroed value (unconditional loads: see rowgemm128_b6_kernel)
+      f32x4 va = *reinterpret_cast<const f32x4*>(A + static_cast<int64_t>(mc) * lda + (a_ok ? a0 + 4 * s_f4 : 0));
+      f32x4 vb = *reinterpret_cast<const f32x4*>(Bm + static_cast<int64_t>(mc) * ldb + b0 + 4 * s_f4);
+      if (!ok || !a_ok) va = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!ok) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[slot][j] = va;
+      rb[slot][j] = vb;
+    }
+  };
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  auto store_slab = [&](int slot, int buf) {
+    __bf16* base = tn_lds + buf * (6 * TN_PLANE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int off = tn_off(s_row + 16 * j, s_f4 >> 1) + 4 * (s_f4 & 1);
+#pragma unroll
+      for (int op = 0; op < 2; ++op) {
+        const f32x4 v = op == 0 ? ra[slot][j] : rb[slot][j];
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          __bf16 hh, mm, ll;
+          split3(v[c], hh, mm, ll);
+          h[c] = hh; m[c] = mm; l[c] = ll;
+        }
+        __bf16* dst = base + op * (3 * TN_PLANE) + off;
+        *reinterpret_cast<bf16x4*>(dst) = h;
+        *reinterpret_cast<bf16x4*>(dst + TN_PLANE) = m;
+        *reinterpret_cast<bf16x4*>(dst + 2 * TN_PLANE) = l;
+      }
+    }
+  };
+  // transposed fragment reads: lane 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3 of the 4 x 16 block; group g takes
+  // slab rows 8 g + 4 rd + q.  Offsets per (tile, read) differ by a constant only within a row pair, so all are precomputed.
+  const int q = l15 >> 2, pp = l15 & 3;
+  int offA[2][2], offB[4][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int row = 8 * g + 4 * rd + q;
+#pragma unroll
+    for (int at = 0; at < 2; ++at) offA[at][rd] = tn_off(row, 4 * aw + 2 * at + (pp >> 1)) + 4 * (pp & 1);
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) offB[bt][rd] = 3 * TN_PLANE + tn_off(row, 8 * bw + 2 * bt + (pp >> 1)) + 4 * (pp & 1);
+  }
+  auto frag = [&](const __bf16* base, int off0, int off1) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + off1));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) acc[at][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_slab(0, 0);
+  load_slab(1, 1);
+  MEM_FENCE();
+  store_slab(0, 0);
+  load_slab(0, 2);
+  MEM_FENCE();
+  __syncthreads();
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+  for (int st0 = 0; st0 < nstep; st0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int step = st0 + u;
+      if (step >= nstep) break;
+      const __bf16* base = tn_lds + u * (6 * TN_PLANE);
+      // stage slab step + 1 (loaded two steps ago) into the other buffer, request slab step + 3
+      store_slab(u ^ 1, u ^ 1);
+      load_slab(u ^ 1, step + 3);
+      MEM_FENCE();
+      bf16x8 fa[2][3], fb[4][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int at = 0; at < 2; ++at) fa[at][p] = frag(base + p * TN_PLANE, offA[at][0], offA[at][1]);
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) fb[bt][p] = frag(base + p * TN_PLANE, offB[bt][0], offB[bt][1]);
+      }
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int at = 0; at < 2; ++at)
+#pragma unroll
+          for (int bt = 0; bt < 4; ++bt)
+            acc[at][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][TA[term]], fb[bt][TB[term]], acc[at][bt], 0, 0, 0);
+      __syncthreads();
+    }
+  }
+  // D: column l15 <-> C column b0 + 64 bw + 16 bt + l15; row 4 g + r <-> C row a0 + 32 aw + 16 at + 4 g + r
+#pragma unroll
+  for (int at = 0; at < 2; ++at) {
+    const int rbase = a0 + 32 * aw + 16 * at;  // 16-row group: inside one segment (segment ends are multiples of 64) and one side of N1
+    if (rbase >= N1) continue;
+    float* cbase = C;
+    int rloc = rbase;
+    if (segs.nseg > 0) {
+      int s_ = 0, beg = 0;
+      while (s_ + 1 < segs.nseg && rbase >= segs.n_end[s_]) { beg = segs.n_end[s_]; ++s_; }
+      cbase = segs.p[s_];
+      rloc = rbase - beg;
+    }
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(cbase + static_cast<int64_t>(rloc + 4 * g + r) * ldc + b0 + 64 * bw + 16 * bt + l15, acc[at][bt][r]);
+  }
+}
+
+bool gemm_tn_b6_ok(const float* A, int lda, const float* B, int ldb, int M, int N1, int N2) {
+  return N2 % 128 == 0 && N1 % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(B) & 15) == 0 && M >= 1;
+}
+
+// C[N1 x N2] += A[M x N1]^T B[M x N2]; seg_ptrs / seg_ends (nseg <= 6, ends multiples of 64): rows of C spread over several matrices
+int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* const* seg_ptrs,
+                      const int* seg_ends, int nseg, hipStream_t st) {
+  DIFFAB_REQUIRE(gemm_tn_b6_ok(A, lda, B, ldb, M, N1, N2) && nseg >= 0 && nseg <= 6 && (nseg > 0 || C), DIFFAB_ERR_ARG,
+                 "gemm_tn_b6: unsupported operands");
+  TnSegs sg{};
+  sg.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) { sg.p[i] = seg_ptrs[i]; sg.n_end[i] = seg_ends[i]; }
+  const int t1 = (N1 + 127) / 128, t2 = N2 / 128, tiles = t1 * t2;
+  int splits = (256 + tiles - 1) / tiles;  // one (tile, M chunk) work-group per CU
+  int m_chunk = (M + splits - 1) / splits;
+  m_chunk = ((m_chunk < 256 ? 256 : m_chunk) + 31) / 32 * 32;
+  const int nchunks = (M + m_chunk - 1) / m_chunk;
+  constexpr int lds = 2 * 6 * TN_PLANE * 2;  // 98 304 bytes
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_b6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(gemm_tn_b6_kernel, dim3(t2, t1, nchunks), dim3(512), lds, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, sg);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
