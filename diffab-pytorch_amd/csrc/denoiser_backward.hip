@@ -247,14 +247,18 @@ __global__ __launch_bounds__(256) void gemm_tn_mfma_kernel(const float* __restri
   }
 }
 
+// db / db_done: the bias gradient db[N1] += column sums of A rides along when the bf16x6 kernel takes the product (*db_done = true)
 static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, hipStream_t st,
-                   const GemmSegs* segs = nullptr) {
+                   const GemmSegs* segs = nullptr, float* db = nullptr, bool* db_done = nullptr) {
   GemmSegs sg{};
   if (segs) sg = *segs;
   if (use_b6_gemm() && gemm_tn_b6_ok(A, lda, B, ldb, M, N1, N2) && M >= 128) {
-    bool seg_ok = true;
+    bool seg_ok = sg.nseg == 0 || (lda % 4 == 0 && N1 % 16 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0);
     for (int i = 0; i < sg.nseg; ++i) seg_ok = seg_ok && sg.n_end[i] % 64 == 0;
-    if (seg_ok) return launch_gemm_tn_b6(A, lda, B, ldb, C, ldc, M, N1, N2, sg.p, sg.n_end, sg.nseg, st);
+    if (seg_ok) {
+      if (db_done) *db_done = db != nullptr;
+      return launch_gemm_tn_b6(A, lda, B, ldb, C, ldc, M, N1, N2, db_done ? db : nullptr, sg.p, sg.n_end, sg.nseg, st);
+    }
   }
   const bool aligned = N1 % 64 == 0 && N2 % 64 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(B) & 15) == 0;
@@ -286,8 +290,9 @@ static int relu_mask(float* dY, const float* act, int64_t n, hipStream_t st) {
 // Y = act(X W^T + b) backward: dW += dY^T X, db += colsum dY, dX (+)= dY W.   dY must already carry the activation mask.
 static int linear_bwd(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M,
                       int N, int Kd, bool acc_dx, hipStream_t st) {
-  if (int rc = gemm_tn(dY, ldy, X, ldx, dW, Kd, M, N, Kd, st)) return rc;
-  if (db)
+  bool db_done = false;
+  if (int rc = gemm_tn(dY, ldy, X, ldx, dW, Kd, M, N, Kd, st, nullptr, db, &db_done)) return rc;
+  if (db && !db_done)
     if (int rc = colsum(dY, ldy, M, N, db, st)) return rc;
   if (dX) return gemm_nn(dY, ldy, W, Kd, dX, lddx, M, Kd, N, acc_dx, st);
   return DIFFAB_OK;

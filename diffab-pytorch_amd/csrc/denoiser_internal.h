@@ -49,10 +49,11 @@ int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, c
 // the same x-stationary kernel as a plain product Y[rows x N] = X[rows x 128] W'^T, (n, k) of W' = W[n sn + k sk] (to_out input gradient)
 size_t xstat_b6_scratch_bytes(int N);
 int launch_xstat_b6(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st);
-// weight-gradient product C[N1 x N2] += A[M x N1]^T B[M x N2] (transposing LDS reads); rows of C optionally spread over nseg matrices
+// weight-gradient product C[N1 x N2] += A[M x N1]^T B[M x N2] (transposing LDS reads), any widths / row strides; rows of C optionally
+// spread over nseg matrices
 bool gemm_tn_b6_ok(const float* A, int lda, const float* B, int ldb, int M, int N1, int N2);
-int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* const* seg_ptrs,
-                      const int* seg_ends, int nseg, hipStream_t st);
+int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db,
+                      float* const* seg_ptrs, const int* seg_ends, int nseg, hipStream_t st);  // db (nullable): += column sums of A
 // split planes of one IPA layer's projection and to_out weights: ipa_layer_planes_bytes() bytes, 256-byte aligned
 size_t ipa_layer_planes_bytes();
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);

@@ -567,8 +567,13 @@ struct TnSegs {
   int nseg;  // 0: one plain matrix C
 };
 
+// A_VEC / B_VEC: the operand's rows are 16-byte aligned and its width a multiple of 4 (float4 loads); otherwise guarded scalar loads
+// (the 131-wide cat[h, tau] input of the head MLPs, the 3- and 20-wide head outputs).  db (nullable): db[n1] += sum_m A[m][n1], the
+// bias gradient, from the A values the b-tile-0 work-groups load anyway.
+template <bool A_VEC, bool B_VEC>
 __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                         float* __restrict__ C, int ldc, int M, int m_chunk, int N1, TnSegs segs) {
+                                                         float* __restrict__ C, int ldc, int M, int m_chunk, int N1, int N2, TnSegs segs,
+                                                         float* __restrict__ db) {
   extern __shared__ __attribute__((aligned(16))) __bf16 tn_lds[];  // [2 buffers][A | B][3 planes][32][128]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int aw = wv & 3, bw = wv >> 2;  // wave tile: 32 rows of C (A columns) x 64 columns (B columns)
@@ -577,18 +582,41 @@ __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict
   const int nstep = (m_hi - m_lo + 31) / 32;
   // staging: a slab is 32 rows x 128 columns of each operand = 1024 float4 each; thread -> rows tid / 32 and 16 + tid / 32, float4 tid % 32
   const int s_row = tid >> 5, s_f4 = tid & 31;
-  const bool a_ok = a0 + 4 * s_f4 < N1;  // N1 % 4 == 0: a float4 is inside or outside
-  f32x4 ra[2][2], rb[2][2];
+  const int acol = a0 + 4 * s_f4, bcol = b0 + 4 * s_f4;
+  const bool a_ok = acol < N1, b_ok = bcol < N2;  // vector path: the width is a multiple of 4, a float4 is inside or outside
+  const bool want_db = db != nullptr && blockIdx.x == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[4][2], rb[4][2];  // ring of four slabs in registers
   auto load_slab = [&](int slot, int step) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = m_lo + 32 * step + s_row + 16 * j;
       const bool ok = m < m_hi;
       const int mc = ok ? m : m_lo;  // clamped address, zeroed value (unconditional loads: see rowgemm128_b6_kernel)
-      f32x4 va = *reinterpret_cast<const f32x4*>(A + static_cast<int64_t>(mc) * lda + (a_ok ? a0 + 4 * s_f4 : 0));
-      f32x4 vb = *reinterpret_cast<const f32x4*>(Bm + static_cast<int64_t>(mc) * ldb + b0 + 4 * s_f4);
-      if (!ok || !a_ok) va = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!ok) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 va, vb;
+      if (A_VEC) {
+        va = *reinterpret_cast<const f32x4*>(A + static_cast<int64_t>(mc) * lda + (a_ok ? acol : 0));
+        if (!ok || !a_ok) va = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool in = acol + c < N1;
+          const float v = A[static_cast<int64_t>(mc) * lda + (in ? acol + c : 0)];
+          va[c] = (ok && in) ? v : 0.0f;
+        }
+      }
+      if (B_VEC) {
+        vb = *reinterpret_cast<const f32x4*>(Bm + static_cast<int64_t>(mc) * ldb + (b_ok ? bcol : 0));
+        if (!ok || !b_ok) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool in = bcol + c < N2;
+          const float v = Bm[static_cast<int64_t>(mc) * ldb + (in ? bcol + c : 0)];
+          vb[c] = (ok && in) ? v : 0.0f;
+        }
+      }
+      if (want_db) csum += va;
       ra[slot][j] = va;
       rb[slot][j] = vb;
     }
@@ -606,7 +634,11 @@ __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           __bf16 hh, mm, ll;
+#ifdef TN_ABL_NOSPLIT
+          hh = mm = ll = static_cast<__bf16>(v[c]);
+#else
           split3(v[c], hh, mm, ll);
+#endif
           h[c] = hh; m[c] = mm; l[c] = ll;
         }
         __bf16* dst = base + op * (3 * TN_PLANE) + off;
@@ -640,23 +672,23 @@ __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict
 #pragma unroll
     for (int bt = 0; bt < 4; ++bt) acc[at][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_slab(0, 0);
-  load_slab(1, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_slab(i, i);
   MEM_FENCE();
   store_slab(0, 0);
-  load_slab(0, 2);
+  load_slab(0, 4);  // slot k holds the slab with index == k (mod 4)
   MEM_FENCE();
   __syncthreads();
   constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
-  for (int st0 = 0; st0 < nstep; st0 += 2) {
+  for (int st0 = 0; st0 < nstep; st0 += 4) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int step = st0 + u;
       if (step >= nstep) break;
-      const __bf16* base = tn_lds + u * (6 * TN_PLANE);
-      // stage slab step + 1 (loaded two steps ago) into the other buffer, request slab step + 3
-      store_slab(u ^ 1, u ^ 1);
-      load_slab(u ^ 1, step + 3);
+      const __bf16* base = tn_lds + (u & 1) * (6 * TN_PLANE);
+      // stage slab step + 1 (requested four steps ago) into the other buffer, request slab step + 5 into the freed slot
+      store_slab((u + 1) & 3, (u & 1) ^ 1);
+      load_slab((u + 1) & 3, step + 5);
       MEM_FENCE();
       bf16x8 fa[2][3], fb[4][3];
 #pragma unroll
@@ -679,7 +711,7 @@ __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict
   // D: column l15 <-> C column b0 + 64 bw + 16 bt + l15; row 4 g + r <-> C row a0 + 32 aw + 16 at + 4 g + r
 #pragma unroll
   for (int at = 0; at < 2; ++at) {
-    const int rbase = a0 + 32 * aw + 16 * at;  // 16-row group: inside one segment (segment ends are multiples of 64) and one side of N1
+    const int rbase = a0 + 32 * aw + 16 * at;  // 16-row group: inside one segment (segment ends are multiples of 64)
     if (rbase >= N1) continue;
     float* cbase = C;
     int rloc = rbase;
@@ -690,34 +722,63 @@ __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict
       rloc = rbase - beg;
     }
 #pragma unroll
-    for (int bt = 0; bt < 4; ++bt)
+    for (int bt = 0; bt < 4; ++bt) {
+      const int col = b0 + 64 * bw + 16 * bt + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(cbase + static_cast<int64_t>(rloc + 4 * g + r) * ldc + b0 + 64 * bw + 16 * bt + l15, acc[at][bt][r]);
+        if (col < N2 && rbase + 4 * g + r < N1) atomicAdd(cbase + static_cast<int64_t>(rloc + 4 * g + r) * ldc + col, acc[at][bt][r]);
+    }
+  }
+  if (db != nullptr) {  // uniform per launch.  The slabs requested past the end loaded zeros, so csum holds exactly this chunk's rows.
+    __syncthreads();  // every wave is done with the staging buffers
+    float* red = reinterpret_cast<float*>(tn_lds);  // [8 waves][32 column groups][4]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) csum[c] += __shfl_xor(csum[c], 32);  // lanes l and l + 32 hold the same columns (rows 2 wv, 2 wv + 1)
+    if (lane < 32) *reinterpret_cast<f32x4*>(red + (wv * 32 + lane) * 4) = csum;
+    __syncthreads();
+    if (want_db && tid < 128) {
+      const int col = a0 + tid;  // column group tid / 4, component tid % 4
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 32 + (tid >> 2)) * 4 + (tid & 3)];
+      if (col < N1) atomicAdd(db + col, v);
+    }
   }
 }
 
 bool gemm_tn_b6_ok(const float* A, int lda, const float* B, int ldb, int M, int N1, int N2) {
-  return N2 % 128 == 0 && N1 % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
-         (reinterpret_cast<uintptr_t>(B) & 15) == 0 && M >= 1;
+  return N1 >= 1 && N2 >= 1 && M >= 1 && (reinterpret_cast<uintptr_t>(A) & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 3) == 0;
 }
 
-// C[N1 x N2] += A[M x N1]^T B[M x N2]; seg_ptrs / seg_ends (nseg <= 6, ends multiples of 64): rows of C spread over several matrices
-int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* const* seg_ptrs,
-                      const int* seg_ends, int nseg, hipStream_t st) {
-  DIFFAB_REQUIRE(gemm_tn_b6_ok(A, lda, B, ldb, M, N1, N2) && nseg >= 0 && nseg <= 6 && (nseg > 0 || C), DIFFAB_ERR_ARG,
-                 "gemm_tn_b6: unsupported operands");
+// C[N1 x N2] += A[M x N1]^T B[M x N2]; db (nullable): db[N1] += column sums of A; seg_ptrs / seg_ends (nseg <= 6, ends multiples of
+// 64, vector-aligned A only): rows of C spread over several matrices
+int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db,
+                      float* const* seg_ptrs, const int* seg_ends, int nseg, hipStream_t st) {
+  const bool a_vec = lda % 4 == 0 && N1 % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const bool b_vec = ldb % 4 == 0 && N2 % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  DIFFAB_REQUIRE(gemm_tn_b6_ok(A, lda, B, ldb, M, N1, N2) && nseg >= 0 && nseg <= 6 && (nseg > 0 || C) && (nseg == 0 || (a_vec && N1 % 16 == 0)),
+                 DIFFAB_ERR_ARG, "gemm_tn_b6: unsupported operands");
   TnSegs sg{};
   sg.nseg = nseg;
   for (int i = 0; i < nseg; ++i) { sg.p[i] = seg_ptrs[i]; sg.n_end[i] = seg_ends[i]; }
-  const int t1 = (N1 + 127) / 128, t2 = N2 / 128, tiles = t1 * t2;
+  const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128, tiles = t1 * t2;
   int splits = (256 + tiles - 1) / tiles;  // one (tile, M chunk) work-group per CU
   int m_chunk = (M + splits - 1) / splits;
   m_chunk = ((m_chunk < 256 ? 256 : m_chunk) + 31) / 32 * 32;
   const int nchunks = (M + m_chunk - 1) / m_chunk;
   constexpr int lds = 2 * 6 * TN_PLANE * 2;  // 98 304 bytes
-  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_b6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(gemm_tn_b6_kernel, dim3(t2, t1, nchunks), dim3(512), lds, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, sg);
+  const dim3 grid(t2, t1, nchunks);
+#define TN_LAUNCH(AV_, BV_)                                                                                                           \
+  do {                                                                                                                                \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_b6_kernel<AV_, BV_>),                                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                           \
+    hipLaunchKernelGGL((gemm_tn_b6_kernel<AV_, BV_>), grid, dim3(512), lds, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2, sg, db);   \
+  } while (0)
+  if (a_vec && b_vec) TN_LAUNCH(true, true);
+  else if (a_vec) TN_LAUNCH(true, false);
+  else if (b_vec) TN_LAUNCH(false, true);
+  else TN_LAUNCH(false, false);
+#undef TN_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
