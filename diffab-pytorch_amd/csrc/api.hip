@@ -57,6 +57,7 @@ static int check_dims(const diffab_dims* d, const char* who) {
 struct StepBuffers {
   float *cat2, *h1, *hA, *hB, *cat3, *t1, *t2, *vbuf, *logits, *ipa, *emb_tab, *beta_tab;
   char* planes;  // split bf16 planes of the dense weights (MFMA path): NL x ipa_layer_planes_bytes(), then 8 MLP matrices
+  float* pair;   // fp16 planes of the pair embedding (launch_pair_split), null when the fused kernel cannot take them
   size_t bytes;
 };
 static size_t mlp_planes_bytes() { return (rowgemm128_b6_scratch_bytes(128) + 255) & ~static_cast<size_t>(255); }
@@ -80,18 +81,19 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
   if (fast_path_supported(d)) ipa_floats = ipa_floats > ipa_fast_workspace_floats(d) ? ipa_floats : ipa_fast_workspace_floats(d);
   b.ipa = c.take<float>(ipa_floats);
   b.planes = fast_path_supported(d) ? c.take<char>(d->NL * ipa_layer_planes_bytes() + 8 * mlp_planes_bytes()) : nullptr;
+  b.pair = pair_planes_supported(d) ? c.take<float>(pair_planes_floats(d)) : nullptr;
   b.bytes = c.bytes();
   return b;
 }
 
 static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                               const float* t, float* y, float* ws, uint32_t flags, hipStream_t st, float* sp_keep = nullptr,
-                              float* d2_keep = nullptr, const void* planes = nullptr) {
+                              float* d2_keep = nullptr, const void* planes = nullptr, const float* pair_planes = nullptr) {
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
     return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : ((flags & DIFFAB_FLAG_FLASH_ATTENTION) ? 3 : 0)),
-                          sp_keep, d2_keep, planes);
+                          sp_keep, d2_keep, planes, pair_planes);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -102,6 +104,16 @@ static int mlp3(const diffab_dims* d, const diffab_mlp3_weights* w, const float*
   if (int rc = launch_linear(cat3, D + 3, w->w0, w->b0, t1, D, rows, D, D + 3, true, st)) return rc;
   if (int rc = launch_linear(t1, D, w->w2, w->b2, t2, D, rows, D, D, true, st)) return rc;
   return launch_linear(t2, D, w->w4, w->b4, out, n_out, rows, n_out, D, false, st);
+}
+
+static bool use_pair_planes(const diffab_dims* d, uint32_t flags, const float* pair_ctx, const StepBuffers& b) {
+  static const bool env_off = [] {
+    const char* e = getenv("DIFFAB_PAIR_F32");  // =1: keep the fp32 pair stream (A/B timing)
+    return e != nullptr && atoi(e) != 0;
+  }();
+  const uint32_t other = DIFFAB_FLAG_FORCE_GENERIC | DIFFAB_FLAG_SPLIT_ATTENTION | DIFFAB_FLAG_EXTERNAL_LOGITS | DIFFAB_FLAG_FLASH_ATTENTION;
+  return (flags & DIFFAB_FLAG_PAIR_PLANES) && !(flags & other) && !env_off && b.pair != nullptr && pair_planes_supported(d) &&
+         (reinterpret_cast<uintptr_t>(pair_ctx) & 15) == 0;
 }
 
 // Everything on the folded MFMA path that depends on the weights only: the sequence-embedding bias table and the split bf16 planes
@@ -128,9 +140,18 @@ static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* 
 
 static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
                         const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
-                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false) {
+                        float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false,
+                        bool pair_prepared = false) {
   const StepBuffers b = carve_step(d, ws);
   const int rows = d->B * d->K, D = d->D;
+  // DIFFAB_FLAG_PAIR_PLANES: the pair embedding as two fp16 planes (same bytes), attention's pair-tile products on the f16 matrix
+  // cores.  The reverse sampler splits once per trajectory (pair_prepared); a single call splits here, per call.
+  const float* pair_planes = nullptr;
+  if (use_pair_planes(d, flags, pair_ctx, b)) {
+    if (!pair_prepared)
+      if (int rc = launch_pair_split(d, pair_ctx, b.pair, st)) return rc;
+    pair_planes = b.pair;
+  }
   // Folded concatenations (MFMA path): the sequence-embedding half of to_res_emb[0] and the beta-embedding columns of the three
   // head MLPs become bias tables, so neither cat[res_ctx, E[s]] nor cat[h, tau] is written or re-read.
   const bool fold = !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d) && rowgemm128_ok(res_ctx, D, b.h1, D, rows, D);
@@ -160,7 +181,8 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   float *cur = b.hA, *nxt = b.hB;
   for (int l = 0; l < d->NL; ++l) {
     const void* planes = (fold && use_b6_gemm()) ? b.planes + l * ipa_layer_planes_bytes() : nullptr;
-    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes)) return rc;
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes, pair_planes))
+      return rc;
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   if (out_res_emb) DIFFAB_HIP_CHECK(hipMemcpyAsync(out_res_emb, cur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
@@ -303,7 +325,12 @@ int diffab_ipa_layer_fwd(const diffab_dims* d, const diffab_ipa_layer_weights* w
   DIFFAB_REQUIRE(x && e && R && t && y && workspace, DIFFAB_ERR_ARG, "ipa_layer_fwd: null pointer");
   const StepBuffers b = carve_step(d, workspace);
   DIFFAB_REQUIRE(workspace_bytes >= b.bytes, DIFFAB_ERR_WORKSPACE, "ipa_layer_fwd: workspace %zu < %zu bytes", workspace_bytes, b.bytes);
-  return ipa_layer_dispatch(d, w, x, e, R, t, y, b.ipa, flags, as_stream(stream));
+  const float* pair_planes = nullptr;
+  if (use_pair_planes(d, flags, e, b)) {
+    if (int rc = launch_pair_split(d, e, b.pair, as_stream(stream))) return rc;
+    pair_planes = b.pair;
+  }
+  return ipa_layer_dispatch(d, w, x, e, R, t, y, b.ipa, flags, as_stream(stream), nullptr, nullptr, nullptr, pair_planes);
 }
 
 int diffab_denoise_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
@@ -389,9 +416,15 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
                     rowgemm128_ok(res_ctx, d->D, b0.h1, d->D, d->B * d->K, d->D);
   if (fold)
     if (int rc = prepare_weights(d, w, b0, st)) return rc;
+  // the pair embedding is the same tensor in all T x NL attention launches of a trajectory: its fp16 planes are built once here
+  flags |= DIFFAB_FLAG_PAIR_PLANES;
+  const bool pair_ready = use_pair_planes(d, flags, pair_ctx, b0);
+  if (pair_ready)
+    if (int rc = launch_pair_split(d, pair_ctx, b0.pair, st)) return rc;
   auto one_step = [&](int t, const int* t_dev) -> int {
     if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
-    if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold))
+    if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold,
+                              pair_ready))
       return rc;
     return launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K, d->V, st,
                                         t_dev);

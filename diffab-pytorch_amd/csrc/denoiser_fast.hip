@@ -380,14 +380,23 @@ constexpr int TI = 16;  // query residues per work-group
 // rescale branch fold away and it is the same straight-line kernel as before the chunk loop existed (the loop costs 13 % at K=128).
 // EXT_S (single chunk only): phase 1 is not computed here; the logits image is copied from Sg[b][h][i][j], written by
 // ipa_logits_kernel (attention_split.hip), whose work-groups share the staged key side over 64 query rows instead of 16.
-template <int NT, bool MULTI, bool EXT_S = false>
+// PLANES (single chunk only): `e` is not the fp32 pair embedding but its two-plane fp16 image written by pair_split_kernel (same
+// bytes: e s = h1 + h2 to 2^-23 of the tensor maximum, fragment order of the bias product), `esc` = {s, 1 / s}; the two products on
+// the pair tile then run on the f16 matrix cores as three exact partial products each (h1 w1, h1 w2, h2 w1 with fp32 accumulation)
+// instead of f32 MFMAs: 96 instead of 512 matrix-pipe cycles per key tile for the bias, 768 instead of 4096 per row for o_e.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+template <int NT, bool MULTI, bool EXT_S = false, bool PLANES = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps,
-                                                            const float* __restrict__ Sg = nullptr, int pf_slots = 0) {
+                                                            const float* __restrict__ Sg = nullptr, const float* __restrict__ esc = nullptr) {
   static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
+  static_assert(!(PLANES && MULTI), "fp16 pair planes: single key chunk only");
+  static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
   // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
@@ -479,9 +488,15 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     const int l15 = lane & 15, q = lane >> 4;
     f32x4 ev[2][NT][4];
     auto load_e_tile = [&](int ii, int cc_, int jt) {
-      const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii] + (cc_ * KC + jt * 16 + 4 * q) * AC + 4 * l15);
+      if constexpr (PLANES) {  // four 1 KiB blocks per key tile, lane order: ev[ii][jt][2 p + ks] = fragment (plane p, k-step ks)
+        const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii]) + (cc_ * NT + jt) * 256 + lane;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
+        for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * 64);
+      } else {
+        const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii] + (cc_ * KC + jt * 16 + 4 * q) * AC + 4 * l15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
+      }
     };
     // ---------------------------------------------------------------- phase 1: wave = head
     if constexpr (EXT_S) {
@@ -637,7 +652,37 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #pragma unroll
       for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
       f32x4 wb[4];  // single-chunk kernel: bias B fragments in registers; multi-chunk: read from LDS per tile (VGPR pressure)
-      if constexpr (!MULTI) {
+      f16x8 wp[2][2];  // PLANES: bias B fragments as two fp16 planes, wp[plane][ks]: lane (head l15, channels 32 ks + 8 q ..), scaled by sw
+      float bscale = scale_t, oscale = 1.0f;
+      if constexpr (PLANES) {
+        f32x4 wv4[2][2];
+        float wmax = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 32 * ks + 8 * q + 4 * hf);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wmax = fmaxf(wmax, fabsf(wv4[ks][hf][s]));
+          }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        // sw = 2^(7 - exponent(wmax)): the largest weight lands in [128, 256), far from fp16's subnormals and its overflow
+        const int ew = static_cast<int>((__float_as_uint(wmax) >> 23) & 255u);
+        const float sw = (ew == 0 || ew > 230) ? 1.0f : __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ew) << 23);
+        const float isw = (ew == 0 || ew > 230) ? 1.0f : __uint_as_float(static_cast<unsigned>(ew - 7) << 23);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int c8 = 0; c8 < 8; ++c8) {
+            const float x = l15 < 8 ? wv4[ks][c8 >> 2][c8 & 3] * sw : 0.0f;
+            const _Float16 h1 = static_cast<_Float16>(x);
+            wp[0][ks][c8] = h1;
+            wp[1][ks][c8] = static_cast<_Float16>(x - static_cast<float>(h1));
+          }
+        bscale = scale_t * esc[1] * isw;          // logits: bias = (sum e s w sw) / (s sw)
+        oscale = esc[1] * (1.0f / 256.0f);       // o_e: probabilities enter scaled by 256
+      } else if constexpr (!MULTI) {
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
           wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
@@ -661,20 +706,37 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         float* Srow = S + il * IS + h * HS;
         float lg[NT][4];  // logits, then exp(logit - M), of keys j = 16 jt + 4 q + r of this chunk for head h
         float mx = -INFINITY;
-        stage_e(ii, 0);
+        if constexpr (!PLANES) stage_e(ii, 0);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
-          if (jt + 1 < NT) stage_e(ii, jt + 1);
-          const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains of 8: half the dependent-MFMA latency
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: half the dependent-MFMA latency
+          if constexpr (PLANES) {
+            // A fragments straight from the loaded registers: lane (key l15, channels 32 ks + 8 q ..); smallest terms first
 #pragma unroll
-          for (int sg = 0; sg < 4; ++sg) {
-            const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
-            const f32x4 wbf = MULTI ? *reinterpret_cast<const f32x4*>(wb_lds + (sg * 64 + lane) * 4) : wb[sg];
+            for (int ks = 0; ks < 2; ++ks) {
+              const f16x8 a1 = __builtin_bit_cast(f16x8, ev[ii][jt][ks]), a2 = __builtin_bit_cast(f16x8, ev[ii][jt][2 + ks]);
+              if (ks == 0) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wp[0][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[1][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[0][0], acc, 0, 0, 0);
+              } else {
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wp[0][1], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[1][1], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[0][1], acc2, 0, 0, 0);
+              }
+            }
+          } else {
+            if (jt + 1 < NT) stage_e(ii, jt + 1);
+            const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc2, 0, 0, 0);
-              else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
+            for (int sg = 0; sg < 4; ++sg) {
+              const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
+              const f32x4 wbf = MULTI ? *reinterpret_cast<const f32x4*>(wb_lds + (sg * 64 + lane) * 4) : wb[sg];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
+              }
             }
           }
           if (ii == 0 && jt + E_DEPTH0 < NT) {
@@ -684,7 +746,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = sv[r] + scale_t * (acc[r] + acc2[r]);
+            const float v = sv[r] + bscale * (acc[r] + acc2[r]);
             lg[jt][r] = v;
             mx = fmaxf(mx, v);
           }
@@ -711,6 +773,78 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         f32x4 oe[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PLANES) {
+          // o_e[channel][head] = sum_keys e^T P on the f16 matrix cores, 32 keys per step.  The A operand wants 8 keys per lane for one
+          // channel: the two key tiles of a step go (as loaded: lane = key, 16 bytes of channels) into a per-wave [key][channel] image
+          // and come back through ds_read_b64_tr_b16 (lane i of a 16-lane group = channel i of a 4-key block).  k order of a step,
+          // identical for both operands: lane group q, element t < 4: key 4 q + t of the first tile, t >= 4: of the second - which is
+          // how the probabilities already sit in this lane.  Image: 128-byte rows, 8-byte unit u of row r at u ^ (4 ((r >> 1) & 3)):
+          // the transposed reads of a 32-lane half touch 32 distinct bank pairs.
+          char* trt = reinterpret_cast<char*>(scr);                     // [2 tiles][2 planes][16 keys][128 bytes] = 8 KiB
+          const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)));  // + 64 ks: unit 8 ks + 2 q (XOR keeps bit 3)
+          const int rrow = 4 * q + (l15 >> 2);
+          const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // + 32 ct (unit 4 ct + pp; XOR acts on bits 2-3)
+#pragma unroll
+          for (int T = 0; T < NT / 2; ++T) {
+            f16x8 p1, p2;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+              const float x = 256.0f * lg[2 * T + (tt >> 2)][tt & 3];
+              const _Float16 hh = static_cast<_Float16>(x);
+              p1[tt] = hh;
+              p2[tt] = static_cast<_Float16>(x - static_cast<float>(hh));
+            }
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+              const f32x4 pv = {lg[2 * T + tl][0], lg[2 * T + tl][1], lg[2 * T + tl][2], lg[2 * T + tl][3]};
+              if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q) = pv;
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                  *reinterpret_cast<f32x4*>(trt + (tl * 2 + pl) * 2048 + (wr_off ^ (64 * ks))) = ev[ii][2 * T + tl][2 * pl + ks];
+            }
+            f16x8 a[2][4];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct) {
+                const int ro = rd_off ^ (32 * ct);
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (0 * 2 + pl) * 2048 + ro));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (1 * 2 + pl) * 2048 + ro));
+                const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[pl][ct] = __builtin_bit_cast(f16x8, v8);
+              }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][ct], p1, oe[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p2, oe[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p1, oe[ct], 0, 0, 0);
+            if (ii == 0) {  // retired tiles free their registers: start the next row
+              load_e_tile(1, c, 2 * T);
+              load_e_tile(1, c, 2 * T + 1);
+              MEM_FENCE();
+            }
+          }
+          // D: column = head l15, row 4 q + r <-> channel 16 ct + 4 q + r
+          if (l15 < 8) {
+            float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 4 * q;
+            const float sc = inv * oscale;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              f32x4 v = oe[ct];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) v[s] *= sc;
+              *reinterpret_cast<f32x4*>(fo + 16 * ct) = v;
+            }
+            if (q == 0) {
+              st_fac[il * AH + h] = fac;
+              st_inv[il * AH + h] = inv;
+            }
+          }
+          continue;
+        }
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           const f32x4 pv = {lg[jt][0], lg[jt][1], lg[jt][2], lg[jt][3]};
@@ -1096,6 +1230,73 @@ bool fast_path_supported(const diffab_dims* d) {
          d->K <= 1024;  // any multiple of 64: keys are processed in chunks of 128 (or 64) with an online softmax
 }
 
+// ================================================================== fp16 planes of the pair embedding (PLANES attention kernel)
+// e s = h1 + h2 with h1 = fp16(e s), h2 = fp16(e s - h1), s = the power of two that puts max |e| into [128, 256): two fp16 planes
+// hold e to 2^-23 of the tensor maximum in the same bytes as fp32.  Layout per (patch, query row i): [key tile jt][plane][k-step
+// ks][lane = key % 16 + 16 g][8 channels 32 ks + 8 g ..] - each 1 KiB block is one MFMA A fragment of the bias product, so the
+// attention kernel loads fragments with linear 1 KiB wave loads.  Built once per trajectory (the pair embedding does not change
+// between reverse steps) or once per call.
+__global__ void pair_absmax_kernel(const float* __restrict__ e, int64_t n4, unsigned* __restrict__ out_bits) {
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(e)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+__global__ void pair_scale_kernel(const unsigned* __restrict__ max_bits, float* __restrict__ esc) {
+  const unsigned b = *max_bits;
+  const int ex = static_cast<int>((b >> 23) & 255u);
+  const bool ok = ex > 0 && ex < 231 && b < 0x7f800000u;  // zero / subnormal / huge / inf-nan maximum: no scaling (inf / nan propagate as in fp32)
+  esc[0] = ok ? __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ex) << 23) : 1.0f;
+  esc[1] = ok ? __uint_as_float(static_cast<unsigned>(ex - 7) << 23) : 1.0f;
+}
+__global__ void pair_split_kernel(const float* __restrict__ e, const float* __restrict__ esc, int K, int64_t n_groups,
+                                  _Float16* __restrict__ out) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;  // (row (b, i), key j, 8-channel group cg)
+  if (gid >= n_groups) return;
+  const int cg = static_cast<int>(gid & 7);
+  const int64_t rj = gid >> 3;
+  const int j = static_cast<int>(rj % K);
+  const int64_t row = rj / K;
+  const float s = esc[0];
+  const f32x4 v0 = reinterpret_cast<const f32x4*>(e)[gid * 2], v1 = reinterpret_cast<const f32x4*>(e)[gid * 2 + 1];
+  f16x8 h1, h2;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float x = (c < 4 ? v0[c & 3] : v1[c & 3]) * s;
+    const _Float16 a = static_cast<_Float16>(x);
+    h1[c] = a;
+    h2[c] = static_cast<_Float16>(x - static_cast<float>(a));
+  }
+  const int jt = j >> 4, l15 = j & 15, ks = cg >> 2, g = cg & 3;
+  _Float16* base = out + (row * K) * 128 + static_cast<int64_t>(jt) * 2048 + ks * 512 + (l15 + 16 * g) * 8;  // 2048 fp16 per key tile
+  *reinterpret_cast<f16x8*>(base) = h1;          // plane 0: blocks (0, ks)
+  *reinterpret_cast<f16x8*>(base + 1024) = h2;   // plane 1: blocks (1, ks)
+}
+bool pair_planes_supported(const diffab_dims* d) { return fast_path_supported(d) && (d->K == 64 || d->K == 128); }
+size_t pair_planes_floats(const diffab_dims* d) {  // planes + {max bits, s, 1 / s} (64 floats)
+  return pair_planes_supported(d) ? static_cast<size_t>(d->B) * d->K * d->K * AC + 64 : 0;
+}
+// planes: pair_planes_floats(d) floats, 256-byte aligned; afterwards PairPlanes{planes + 64, planes + 1} feeds ipa_layer_fast
+int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipStream_t st) {
+  DIFFAB_REQUIRE(pair_planes_supported(d) && e && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(e) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_split: unsupported operands");
+  const int64_t n = static_cast<int64_t>(d->B) * d->K * d->K * AC;
+  unsigned* bits = reinterpret_cast<unsigned*>(planes);
+  DIFFAB_HIP_CHECK(hipMemsetAsync(bits, 0, 4, st));
+  hipLaunchKernelGGL(pair_absmax_kernel, dim3(2048), dim3(256), 0, st, e, n / 4, bits);
+  hipLaunchKernelGGL(pair_scale_kernel, dim3(1), dim3(1), 0, st, bits, planes + 1);
+  hipLaunchKernelGGL(pair_split_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, st, e, planes + 1, d->K, n / 8,
+                     reinterpret_cast<_Float16*>(planes + 64));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+
 // DIFFAB_FP32_GEMM=1: the dense projections on the f32-input MFMA kernels of this file instead of the bf16x6 kernels
 // (gemm_bf16x6.hip; same results to fp32 rounding) - for A/B timing and as the plain-fp32 reference path
 bool use_b6_gemm() {
@@ -1121,7 +1322,8 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d) {
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep, const void* planes) {
+                   float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep, const void* planes,
+                   const float* pair_planes) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1214,7 +1416,20 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     timer_end(st);                                                                                                                    \
   } while (0)
 #define ATTN_LAUNCH(NT_, MULTI_) ATTN_LAUNCH_X(NT_, MULTI_, false)
-  if (ext_logits && nt == 8) ATTN_LAUNCH_X(8, false, true);
+#define ATTN_LAUNCH_PLANES(NT_)                                                                                                       \
+  do {                                                                                                                                \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, false, false, true>),                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
+    timer_begin(st);                                                                                                                  \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, false, false, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R, t,       \
+                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_planes + 1);                                     \
+    timer_end(st);                                                                                                                    \
+  } while (0)
+  // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores; single key chunk, attention default mode only
+  if (pair_planes != nullptr && attn_mode == 0 && nc == 1 && pair_planes_supported(d)) {
+    if (nt == 8) ATTN_LAUNCH_PLANES(8);
+    else ATTN_LAUNCH_PLANES(4);
+  } else if (ext_logits && nt == 8) ATTN_LAUNCH_X(8, false, true);
   else if (ext_logits) ATTN_LAUNCH_X(4, false, true);
   else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
   else if (nt == 8) ATTN_LAUNCH(8, true);
@@ -1222,6 +1437,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   else ATTN_LAUNCH(4, true);
 #undef ATTN_LAUNCH_X
 #undef ATTN_LAUNCH
+#undef ATTN_LAUNCH_PLANES
   DIFFAB_LAUNCH_CHECK();
   return to_out();
 }

@@ -20,7 +20,12 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d);
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, int attn_mode = 0,  // 0 fused | 1 three launches | 2 logits launch + fused rest
                    float* sp_keep = nullptr, float* d2_keep = nullptr,  // training tape: three launches, P and d2 kept in these buffers
-                   const void* planes = nullptr);  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
+                   const void* planes = nullptr,  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
+                   const float* pair_planes = nullptr);  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
+// fp16 planes of the pair embedding for the fused attention kernel (K = 64 / 128): pair_planes_floats(d) floats, 256-byte aligned
+bool pair_planes_supported(const diffab_dims* d);
+size_t pair_planes_floats(const diffab_dims* d);
+int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipStream_t st);
 // Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);

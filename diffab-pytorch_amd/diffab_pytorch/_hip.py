@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("DIFFAB_HIP_LIB") or os.path.join(os.path.dirname(_HER
 FLAG_FORCE_GENERIC = 1
 FLAG_EXTERNAL_LOGITS = 4  # K = 64 / 128: logits in their own launch, the fused kernel copies them (csrc/attention_split.hip)
 FLAG_FLASH_ATTENTION = 8  # K = 64 / 128: attention as a key-tile pipeline with an online softmax (csrc/attention_flash.hip)
+FLAG_PAIR_PLANES = 32  # K = 64 / 128: pair embedding as two fp16 planes, pair-tile products on the f16 matrix cores (always on in sample_loop)
 FLAG_GRAPH_SAMPLER = 16  # sample_loop: one captured step replayed as a hipGraph (launch-bound small batches)
 FLAG_SPLIT_ATTENTION = 2  # K = 64 / 128: attention as three launches (csrc/attention_split.hip); default is the fused kernel
 

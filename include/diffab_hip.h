@@ -56,6 +56,12 @@ extern "C" {
 #define DIFFAB_FLAG_FLASH_ATTENTION 8u /* K = 64 / 128: the attention of each layer as a key-tile pipeline with an online softmax
                                           (csrc/attention_flash.hip) instead of the three-phase kernel; same results to rounding */
 
+#define DIFFAB_FLAG_PAIR_PLANES 32u /* K = 64 / 128, default attention kernel: the pair embedding is first rewritten as two fp16 planes (e s =
+                                      h1 + h2 to 2^-23 of the tensor maximum, same bytes, in the workspace) and the two products on
+                                      the pair tile run on the f16 matrix cores as three exact partial products each, fp32
+                                      accumulation.  diffab_sample_loop always does this (once per trajectory); for single calls
+                                      the flag adds the rewrite (2x the pair embedding in HBM traffic) to every call. */
+
 #define DIFFAB_FLAG_GRAPH_SAMPLER 16u /* diffab_sample_loop: capture one reverse step into a hipGraph (timestep read from device memory)
                                          and replay it for the remaining steps - one host call per step instead of ~45.  Bitwise the
                                          eager trajectory.  The call drains its private replay stream before it returns (the graph

@@ -24,12 +24,13 @@ w_, x_, y_, z_ = q.unbind(-1)
 R = torch.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_), 2 * (x_ * y_ + z_ * w_),
                  1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_), 2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_),
                  1 - 2 * (x_ * x_ + y_ * y_)], -1).view(B, K, 3, 3).contiguous()
+FLAGS = int(os.environ.get("ATTN_FLAGS", "0"))  # e.g. 32 = _hip.FLAG_PAIR_PLANES
 for _ in range(3):
-    layer(x, e, R, t)
+    layer(x, e, R, t, flags=FLAGS)
 nwg = B * (K // 16)
 stamps = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
 lib.diffab_debug_set_attn_stamps(_hip.ptr(stamps))
-layer(x, e, R, t)
+layer(x, e, R, t, flags=FLAGS)
 torch.cuda.synchronize()
 lib.diffab_debug_set_attn_stamps(None)
 s = stamps.view(nwg, 8, 8).cpu().double()
