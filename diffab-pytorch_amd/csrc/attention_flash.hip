@@ -36,6 +36,9 @@ namespace diffab {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define MEM_FENCE() asm volatile("" ::: "memory")
 #ifdef DIFFAB_ACCURATE_EXP
 #define FAST_EXP(x) expf(x)
@@ -456,11 +459,17 @@ __global__ __launch_bounds__(512) void ipa_attn_flash_kernel(const float* __rest
 // Sixteen-wave form of the same pipeline: waves 0-7 run B only (two rows each), waves 8-15 run A and C only (one head each), 128
 // registers per wave, four waves per SIMD - twice as many instruction streams for the scheduler to interleave as in the eight-wave
 // form above, where matrix, vector and LDS work of the two co-resident waves was measured to add up rather than overlap.
-template <int NT>
+// PLANES: `e` is the two-plane fp16 image of the pair embedding (pair_split_kernel, denoiser_fast.hip: same bytes, e s = h1 + h2 to
+// 2^-23 of the tensor maximum, each 1 KiB block one A fragment of the bias product), esc = {s, 1 / s}.  The producers' two products
+// then run on the f16 matrix cores as three exact partial products each: the bias straight from the loaded registers (6 MFMAs
+// 16x16x32 instead of 16 f32 MFMAs and an LDS round trip), o_e with the tile staged once in a per-wave [key][channel] image and read
+// back through ds_read_b64_tr_b16 (12 MFMAs 16x16x16 instead of 16 f32 MFMAs).
+template <int NT, bool PLANES = false>
 __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                                 const float* __restrict__ R, const float* __restrict__ t,
                                                                 const float* __restrict__ Wb, const float* __restrict__ gamma,
-                                                                float* __restrict__ feat, int B, unsigned long long* __restrict__ stamps) {
+                                                                float* __restrict__ feat, int B, unsigned long long* __restrict__ stamps,
+                                                                const float* __restrict__ esc = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int K = NT * 16;
   constexpr int ntile = K / TI;
@@ -502,20 +511,68 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
     f32x4 ev[ERING][4];
     auto load_rs = [&](int rs) {  // -> ring slot rs % ERING
       const float* eu = ebase + (rs & 1) * (K * AC) + (rs >> 1) * (16 * AC);
+      if constexpr (PLANES) {  // four 1 KiB blocks (plane p, k-step ks) of the tile, lane order: ev[slot][2 p + ks]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ev[rs % ERING][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(eu + eoff + r * AC));
+        for (int r = 0; r < 4; ++r) ev[rs % ERING][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(eu + r * 256 + lane * 4));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[rs % ERING][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(eu + eoff + r * AC));
+      }
     };
 #pragma unroll
     for (int rs = 0; rs < ERING && rs < NRS; ++rs) load_rs(rs);  // the stream starts with the kernel
     MEM_FENCE();
     // B fragments of the bias product, Wb[h][16 sg + 4 q + s], per lane: kept in LDS [sg][lane] (the same for every wave; 16 VGPRs
     // that the pipeline needs more), read back beside the pair tile in front()
-    if (wv == 0) {
+    // PLANES: bias B fragments as two fp16 planes [plane][ks]: lane (head l15, channels 32 ks + 8 q ..), scaled by sw into [128, 256);
+    // kept in LDS (L_WB: [2 p + ks][lane] x 16 bytes, written by wave 0, the same for every wave) - the producers have 128 registers
+    float bscale = scale_t, oscale = 1.0f;
+    if constexpr (PLANES) {
+      f32x4 wv4[2][2];
+      float wmax = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + hl * AC + 32 * ks + 8 * q + 4 * hf);
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) wmax = fmaxf(wmax, fabsf(wv4[ks][hf][s_]));
+        }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+      const int ew = static_cast<int>((__float_as_uint(wmax) >> 23) & 255u);
+      const bool okw = ew > 0 && ew < 231;
+      const float sw = okw ? __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ew) << 23) : 1.0f;
+      const float isw = okw ? __uint_as_float(static_cast<unsigned>(ew - 7) << 23) : 1.0f;
+      if (wv == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f16x8 w1, w2;
+#pragma unroll
+          for (int c8 = 0; c8 < 8; ++c8) {
+            const float x = wv4[ks][c8 >> 2][c8 & 3] * sw;  // lanes l15 >= 8 DUPLICATE head l15 - 8 (they store the same P~ / alpha values)
+            const _Float16 h1 = static_cast<_Float16>(x);
+            w1[c8] = h1;
+            w2[c8] = static_cast<_Float16>(x - static_cast<float>(h1));
+          }
+          *reinterpret_cast<f16x8*>(lds + L_WB + ((0 * 2 + ks) * 64 + lane) * 4) = w1;
+          *reinterpret_cast<f16x8*>(lds + L_WB + ((1 * 2 + ks) * 64 + lane) * 4) = w2;
+        }
+      }
+      bscale = scale_t * esc[1] * isw;     // logits: bias = (sum e s w sw) / (s sw)
+      oscale = esc[1] * (1.0f / 256.0f);  // o_e: probabilities enter scaled by 256
+    } else if (wv == 0) {
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg)
         *reinterpret_cast<f32x4*>(lds + L_WB + (sg * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(Wb + hl * AC + 16 * sg + 4 * q);
     }
     float* escr = lds + L_SE + wv * (16 * ELD);
+    // PLANES: per-wave [2 planes][16 keys][128 bytes] image of the current tile (4 KiB of the 4.5 KiB slot); 8-byte unit u of row r at
+    // u ^ (4 ((r >> 1) & 3)): the transposed reads of a 32-lane half touch 32 distinct bank pairs
+    char* trt = reinterpret_cast<char*>(escr);
+    const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)));      // ^ 64 ks: unit 8 ks + 2 q of row (key) l15
+    const int rrow = 4 * q + (l15 >> 2);
+    const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // ^ 32 ct: unit 4 ct + (l15 & 3) of row rrow
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     f32x4 oe[2][4];
 #pragma unroll
@@ -531,6 +588,7 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
     f32x4 acc_n;
     auto front = [&](int rs) {
       const int sl = rs % ERING;
+      if constexpr (PLANES) return;  // the bias product is six MFMAs straight from the loaded registers: done in back(), no hand pipelining
       float* t_ = escr + 4 * q * ELD + 4 * l15;  // write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
 #pragma unroll
       for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[sl][r];
@@ -581,11 +639,31 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
       const float* Sk = lds + L_S + (jt & 1) * RING;
       float* Pk = lds + L_P + (jt & 1) * RING;
       float* Ak = lds + L_AL + (jt & 1) * (AH * TI);
+      f32x4 accb = acc;
+      if constexpr (PLANES) {
+        // bias[key 4 q + r][head l15] = sum_c e w on the f16 matrix cores: A fragments are the loaded registers themselves (lane = key
+        // l15, channels 32 ks + 8 q ..), B fragments from LDS one plane at a time (128-register budget); h2 w1 + h1 w1 + h1 w2
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        const f16x8 a10 = __builtin_bit_cast(f16x8, ev[sl][0]), a11 = __builtin_bit_cast(f16x8, ev[sl][1]);
+        {
+          const f16x8 w10 = *reinterpret_cast<const f16x8*>(lds + L_WB + (0 * 64 + lane) * 4), w11 = *reinterpret_cast<const f16x8*>(lds + L_WB + (1 * 64 + lane) * 4);
+          b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ev[sl][2]), w10, b0, 0, 0, 0);
+          b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ev[sl][3]), w11, b1, 0, 0, 0);
+          b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, w10, b0, 0, 0, 0);
+          b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, w11, b1, 0, 0, 0);
+        }
+        {
+          const f16x8 w20 = *reinterpret_cast<const f16x8*>(lds + L_WB + (2 * 64 + lane) * 4), w21 = *reinterpret_cast<const f16x8*>(lds + L_WB + (3 * 64 + lane) * 4);
+          b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, w20, b0, 0, 0, 0);
+          b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, w21, b1, 0, 0, 0);
+        }
+        accb = b0 + b1;
+      }
       const f32x4 sv = *reinterpret_cast<const f32x4*>(Sk + il * RS + hl * HS + 4 * q);
       float s_[4], mt = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s_[r] = sv[r] + scale_t * acc[r];
+        s_[r] = sv[r] + bscale * accb[r];
         mt = fmaxf(mt, s_[r]);
       }
 #ifdef FLASH_ABL_NOSOFTMAX
@@ -611,14 +689,50 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) oe[ii][ct][r] *= alpha;
-#ifdef FLASH_ABL_NOOE
-      for (int ct = 0; ct < 4; ++ct) oe[ii][ct] += ev[sl][ct] * pv[ct];
-#else
+      if constexpr (PLANES) {
+        // o_e[channel 16 ct + 4 q + r][head l15] += e^T P~ on the f16 matrix cores (16x16x16: 4 keys per lane).  A: the tile goes as
+        // loaded (lane = key, 16 bytes of channels) into the per-wave image and comes back transposed (lane i of a 16-lane group =
+        // channel i of the 4-key block 4 q ..); B: this lane's own four probabilities, x 256, as two fp16 planes
+        f16x4 p1, p2;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          const float x = 256.0f * pv[r];
+          const _Float16 hh = static_cast<_Float16>(x);
+          p1[r] = hh;
+          p2[r] = static_cast<_Float16>(x - static_cast<float>(hh));
+        }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[sl][r][ct], pv[r], oe[ii][ct], 0, 0, 0);
-#endif
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<f32x4*>(trt + pl * 2048 + (wr_off ^ (64 * ks))) = ev[sl][2 * pl + ks];
+        MEM_FENCE();  // the image is complete before the transposed reads (LDS operations of a wave complete in issue order)
+        auto tr4 = [&](int pl, int ct) {
+          const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(trt + pl * 2048 + (rd_off ^ (32 * ct))));
+          return __builtin_bit_cast(f16x4, v4);
+        };
+        {  // plane 2 (the small one) first: h2 p1
+          f16x4 a2[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) a2[ct] = tr4(1, ct);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(a2[ct], p1, oe[ii][ct], 0, 0, 0);
+        }
+        {  // h1 p2, h1 p1
+          f16x4 a1[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) a1[ct] = tr4(0, ct);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1[ct], p2, oe[ii][ct], 0, 0, 0);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1[ct], p1, oe[ii][ct], 0, 0, 0);
+        }
+        MEM_FENCE();  // ... and read before the next row-step overwrites it
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) oe[ii][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[sl][r][ct], pv[r], oe[ii][ct], 0, 0, 0);
+      }
 #ifndef FLASH_ABL_NOSOFTMAX
       ls = xq_sum(ls);
 #endif
@@ -641,11 +755,21 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
         const int he = le & 7, qe = le >> 4;
         lds[L_LI + he * TI + il] = inv;
         if ((le & 15) < 8) {
-          float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + he * AC + 16 * qe;  // D rows m = 4 q + r' <-> channels 16 q + 4 r' + ct
+          if constexpr (PLANES) {  // D rows 4 q + r <-> channels 16 ct + 4 q + r
+            float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + he * AC + 4 * qe;
+            const float sc = inv * oscale;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const f32x4 v = {oe[ii][0][r] * inv, oe[ii][1][r] * inv, oe[ii][2][r] * inv, oe[ii][3][r] * inv};
-            *reinterpret_cast<f32x4*>(fo + 4 * r) = v;
+            for (int ct = 0; ct < 4; ++ct) {
+              const f32x4 v = {oe[ii][ct][0] * sc, oe[ii][ct][1] * sc, oe[ii][ct][2] * sc, oe[ii][ct][3] * sc};
+              *reinterpret_cast<f32x4*>(fo + 16 * ct) = v;
+            }
+          } else {
+            float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + he * AC + 16 * qe;  // D rows m = 4 q + r' <-> channels 16 q + 4 r' + ct
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const f32x4 v = {oe[ii][0][r] * inv, oe[ii][1][r] * inv, oe[ii][2][r] * inv, oe[ii][3][r] * inv};
+              *reinterpret_cast<f32x4*>(fo + 4 * r) = v;
+            }
           }
         }
       }
@@ -664,6 +788,7 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
 #ifndef FLASH_ABL_NOB
           if (rs + 1 < NRS) front(rs + 1);
           back(rs, a0);
+          if constexpr (PLANES) __builtin_amdgcn_sched_barrier(0);  // one row-step's transients at a time (128 registers)
 #endif
         }
       }
@@ -851,7 +976,7 @@ bool attention_flash_supported(const diffab_dims* d) {
 }
 
 int launch_attention_flash(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
-                           const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st) {
+                           const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st, const float* pair_planes) {
   DIFFAB_REQUIRE(attention_flash_supported(d), DIFFAB_ERR_UNSUPPORTED, "attention_flash: K must be 64 or 128 at the benchmark geometry");
   const dim3 grid(d->B * (d->K / TI));
 #define FLASH_LAUNCH(NT_)                                                                                                         \
@@ -876,13 +1001,26 @@ int launch_attention_flash(const diffab_dims* d, const float* proj, const float*
                        stamps);                                                                                                   \
     timer_end(st);                                                                                                                \
   } while (0)
-  if (waves == 16) {
+#define FLASH16P_LAUNCH(NT_)                                                                                                      \
+  do {                                                                                                                            \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_flash16_kernel<NT_, true>),                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFlashLdsBytes)));          \
+    timer_begin(st);                                                                                                              \
+    hipLaunchKernelGGL((ipa_attn_flash16_kernel<NT_, true>), grid, dim3(1024), kFlashLdsBytes, st, proj, pair_planes + 64, R, t, Wb, \
+                       gamma, feat, d->B, stamps, pair_planes + 1);                                                               \
+    timer_end(st);                                                                                                                \
+  } while (0)
+  if (pair_planes != nullptr) {  // launch_pair_split() output: producers on the f16 matrix cores (16-wave form only)
+    if (d->K == 128) FLASH16P_LAUNCH(8);
+    else FLASH16P_LAUNCH(4);
+  } else if (waves == 16) {
     if (d->K == 128) FLASH16_LAUNCH(8);
     else FLASH16_LAUNCH(4);
   } else {
     if (d->K == 128) FLASH_LAUNCH(8);
     else FLASH_LAUNCH(4);
   }
+#undef FLASH16P_LAUNCH
 #undef FLASH16_LAUNCH
 #undef FLASH_LAUNCH
   DIFFAB_LAUNCH_CHECK();

@@ -648,9 +648,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #define DIFFAB_E_DEPTH0 3  // tiles of the first row in flight before its bias loop starts; the rest follow one per consumed tile (all 8 at once:
                            // 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it builds delays every other CU's loads)
 #endif
-      constexpr int E_DEPTH0 = DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT;
+      constexpr int E_DEPTH0 = PLANES ? NT : (DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT);
+      if constexpr (!PLANES) {
 #pragma unroll
-      for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
+        for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
+      }
       f32x4 wb[4];  // single-chunk kernel: bias B fragments in registers; multi-chunk: read from LDS per tile (VGPR pressure)
       f16x8 wp[2][2];  // PLANES: bias B fragments as two fp16 planes, wp[plane][ks]: lane (head l15, channels 32 ks + 8 q ..), scaled by sw
       float bscale = scale_t, oscale = 1.0f;
@@ -682,6 +684,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           }
         bscale = scale_t * esc[1] * isw;          // logits: bias = (sum e s w sw) / (s sw)
         oscale = esc[1] * (1.0f / 256.0f);       // o_e: probabilities enter scaled by 256
+        // the rest of the first row, requested AFTER the weight loads above have been consumed: vmcnt retires in order, a wait for a
+        // load issued behind these tiles would wait for all of them (measured: 9 k cycles in front of the barrier)
+        asm volatile("" ::"v"(wp[0][0]), "v"(wp[1][0]), "v"(wp[0][1]), "v"(wp[1][1]));
+#pragma unroll
+        for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);
       } else if constexpr (!MULTI) {
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
@@ -700,32 +707,158 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[ii][jt][r];
       };
 
+      if constexpr (PLANES) {
+        // Key tiles are consumed in pairs (32 keys), each pair completely - bias, softmax bookkeeping, o_e - as soon as it is in
+        // registers (an online softmax inside the row), so a tile's registers are free after ONE use and the next row's tiles are
+        // requested eight tiles ahead of their use from the first step on: the pair stream of the wave's two rows is one continuous
+        // pipeline.  (Two passes per row - all bias products, softmax, all o_e products - left the second row's loads exposed once
+        // the products had moved to the f16 matrix cores: phase 2 had become a wait for HBM latency, 38 k of its 20 k cycles.)
+        // The probabilities go to LDS relative to the running maximum of their step and are rescaled to the row maximum after the row.
+        char* trt = reinterpret_cast<char*>(scr);                                    // [2 tiles][2 planes][16 keys][128 bytes] = 8 KiB
+        const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)));      // ^ 64 ks: 8-byte unit 8 ks + 2 q of row l15
+        const int rrow = 4 * q + (l15 >> 2);
+        const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // ^ 32 ct: unit 4 ct + (l15 & 3) of row rrow
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int il = 2 * wv + ii;  // local row
+          float* Srow = S + il * IS + h * HS;
+          float m_run = -INFINITY, l_run = 0.f, m_hist[NT / 2];
+          f32x4 oe[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int T = 0; T < NT / 2; ++T) {
+            // ---- bias of the two tiles: A fragments straight from the loaded registers (lane = key l15, channels 32 ks + 8 q ..)
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 a1 = __builtin_bit_cast(f16x8, ev[ii][2 * T + tl][ks]), a2 = __builtin_bit_cast(f16x8, ev[ii][2 * T + tl][2 + ks]);
+                f32x4 a_ = {0.f, 0.f, 0.f, 0.f};
+                a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wp[0][ks], a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[1][ks], a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[0][ks], a_, 0, 0, 0);
+                acc[tl][ks] = a_;
+              }
+            float v[8], smax = -INFINITY;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+              const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[4 * tl + r] = sv[r] + bscale * (acc[tl][0][r] + acc[tl][1][r]);
+                smax = fmaxf(smax, v[4 * tl + r]);
+              }
+            }
+            smax = fmaxf(smax, __shfl_xor(smax, 16));
+            smax = fmaxf(smax, __shfl_xor(smax, 32));
+            const float m_new = fmaxf(m_run, smax);
+            const float alpha = T == 0 ? 0.0f : FAST_EXP(m_run - m_new);
+            m_run = m_new;
+            m_hist[T] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+              v[tt] = FAST_EXP(v[tt] - m_new);
+              psum += v[tt];
+            }
+            l_run = l_run * alpha + psum;  // lane-partial; the key quarters are added after the row (alpha is the same in all four)
+            if (T > 0) {
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oe[ct][r] *= alpha;
+            }
+            // ---- probabilities: to LDS for phase 3 (relative to m_hist[T]), and as two fp16 planes (x 256) into the o_e product
+            f16x8 p1, p2;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+              const float x = 256.0f * v[tt];
+              const _Float16 hh = static_cast<_Float16>(x);
+              p1[tt] = hh;
+              p2[tt] = static_cast<_Float16>(x - static_cast<float>(hh));
+            }
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+              if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q) = f32x4{v[4 * tl], v[4 * tl + 1], v[4 * tl + 2], v[4 * tl + 3]};
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                  *reinterpret_cast<f32x4*>(trt + (tl * 2 + pl) * 2048 + (wr_off ^ (64 * ks))) = ev[ii][2 * T + tl][2 * pl + ks];
+            }
+            if (ii == 0) {  // the tiles are in LDS: their registers take the same tiles of the next row (eight tiles ahead)
+              load_e_tile(1, c, 2 * T);
+              load_e_tile(1, c, 2 * T + 1);
+              MEM_FENCE();
+            }
+            // ---- o_e[channel][head] += e^T P: the A operand (8 keys per lane for one channel) through the transposing LDS read
+            f16x8 a[2][4];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct) {
+                const int ro = rd_off ^ (32 * ct);
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (0 * 2 + pl) * 2048 + ro));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (1 * 2 + pl) * 2048 + ro));
+                const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[pl][ct] = __builtin_bit_cast(f16x8, v8);
+              }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][ct], p1, oe[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p2, oe[ct], 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p1, oe[ct], 0, 0, 0);
+          }
+          l_run += __shfl_xor(l_run, 16);
+          l_run += __shfl_xor(l_run, 32);
+          const float inv = 1.0f / l_run;
+          // the probabilities of the earlier steps are relative to their own running maximum: rescale to the row maximum
+#pragma unroll
+          for (int T = 0; T < NT / 2 - 1; ++T) {
+            const float f = FAST_EXP(m_hist[T] - m_run);
+            if (l15 < 8) {
+#pragma unroll
+              for (int tl = 0; tl < 2; ++tl) {
+                f32x4* sp = reinterpret_cast<f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q);
+                f32x4 pv = *sp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] *= f;
+                *sp = pv;
+              }
+            }
+          }
+          // D: column = head l15, row 4 q + r <-> channel 16 ct + 4 q + r
+          if (l15 < 8) {
+            float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 4 * q;
+            const float sc = inv * oscale;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              f32x4 o = oe[ct];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] *= sc;
+              *reinterpret_cast<f32x4*>(fo + 16 * ct) = o;
+            }
+            if (q == 0) {
+              st_fac[il * AH + h] = 0.0f;
+              st_inv[il * AH + h] = inv;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int il = 2 * wv + ii;  // local row
         float* Srow = S + il * IS + h * HS;
         float lg[NT][4];  // logits, then exp(logit - M), of keys j = 16 jt + 4 q + r of this chunk for head h
         float mx = -INFINITY;
-        if constexpr (!PLANES) stage_e(ii, 0);
+        stage_e(ii, 0);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: half the dependent-MFMA latency
-          if constexpr (PLANES) {
-            // A fragments straight from the loaded registers: lane (key l15, channels 32 ks + 8 q ..); smallest terms first
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-              const f16x8 a1 = __builtin_bit_cast(f16x8, ev[ii][jt][ks]), a2 = __builtin_bit_cast(f16x8, ev[ii][jt][2 + ks]);
-              if (ks == 0) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wp[0][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[1][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[0][0], acc, 0, 0, 0);
-              } else {
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wp[0][1], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[1][1], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[0][1], acc2, 0, 0, 0);
-              }
-            }
-          } else {
+          {
             if (jt + 1 < NT) stage_e(ii, jt + 1);
             const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
 #pragma unroll
@@ -773,78 +906,6 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         f32x4 oe[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (PLANES) {
-          // o_e[channel][head] = sum_keys e^T P on the f16 matrix cores, 32 keys per step.  The A operand wants 8 keys per lane for one
-          // channel: the two key tiles of a step go (as loaded: lane = key, 16 bytes of channels) into a per-wave [key][channel] image
-          // and come back through ds_read_b64_tr_b16 (lane i of a 16-lane group = channel i of a 4-key block).  k order of a step,
-          // identical for both operands: lane group q, element t < 4: key 4 q + t of the first tile, t >= 4: of the second - which is
-          // how the probabilities already sit in this lane.  Image: 128-byte rows, 8-byte unit u of row r at u ^ (4 ((r >> 1) & 3)):
-          // the transposed reads of a 32-lane half touch 32 distinct bank pairs.
-          char* trt = reinterpret_cast<char*>(scr);                     // [2 tiles][2 planes][16 keys][128 bytes] = 8 KiB
-          const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)));  // + 64 ks: unit 8 ks + 2 q (XOR keeps bit 3)
-          const int rrow = 4 * q + (l15 >> 2);
-          const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // + 32 ct (unit 4 ct + pp; XOR acts on bits 2-3)
-#pragma unroll
-          for (int T = 0; T < NT / 2; ++T) {
-            f16x8 p1, p2;
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-              const float x = 256.0f * lg[2 * T + (tt >> 2)][tt & 3];
-              const _Float16 hh = static_cast<_Float16>(x);
-              p1[tt] = hh;
-              p2[tt] = static_cast<_Float16>(x - static_cast<float>(hh));
-            }
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-              const f32x4 pv = {lg[2 * T + tl][0], lg[2 * T + tl][1], lg[2 * T + tl][2], lg[2 * T + tl][3]};
-              if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q) = pv;
-#pragma unroll
-              for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                  *reinterpret_cast<f32x4*>(trt + (tl * 2 + pl) * 2048 + (wr_off ^ (64 * ks))) = ev[ii][2 * T + tl][2 * pl + ks];
-            }
-            f16x8 a[2][4];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-              for (int ct = 0; ct < 4; ++ct) {
-                const int ro = rd_off ^ (32 * ct);
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (0 * 2 + pl) * 2048 + ro));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (1 * 2 + pl) * 2048 + ro));
-                const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                a[pl][ct] = __builtin_bit_cast(f16x8, v8);
-              }
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][ct], p1, oe[ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p2, oe[ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p1, oe[ct], 0, 0, 0);
-            if (ii == 0) {  // retired tiles free their registers: start the next row
-              load_e_tile(1, c, 2 * T);
-              load_e_tile(1, c, 2 * T + 1);
-              MEM_FENCE();
-            }
-          }
-          // D: column = head l15, row 4 q + r <-> channel 16 ct + 4 q + r
-          if (l15 < 8) {
-            float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 4 * q;
-            const float sc = inv * oscale;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              f32x4 v = oe[ct];
-#pragma unroll
-              for (int s = 0; s < 4; ++s) v[s] *= sc;
-              *reinterpret_cast<f32x4*>(fo + 16 * ct) = v;
-            }
-            if (q == 0) {
-              st_fac[il * AH + h] = fac;
-              st_inv[il * AH + h] = inv;
-            }
-          }
-          continue;
-        }
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           const f32x4 pv = {lg[jt][0], lg[jt][1], lg[jt][2], lg[jt][3]};
@@ -885,6 +946,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           }
         }
       }
+      }  // !PLANES
     }
     if (c == 0) stamp(3);
 
@@ -1395,7 +1457,8 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     return v != nullptr && atoi(v) != 0;
   }();
   if ((attn_mode == 3 || (attn_mode == 0 && env_flash)) && attention_flash_supported(d)) {
-    if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st)) return rc;
+    const float* pp = (attn_mode == 0 && pair_planes_supported(d)) ? pair_planes : nullptr;
+    if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st, pp)) return rc;
     return to_out();
   }
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk

@@ -82,7 +82,8 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
 // attention_flash.hip: the fused attention as a key-tile pipeline with an online softmax (K = 64 / 128); default for those K
 bool attention_flash_supported(const diffab_dims* d);
 int launch_attention_flash(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
-                           const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st);
+                           const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st,
+                           const float* pair_planes = nullptr);  // launch_pair_split() output: 16-wave form, producers on f16 MFMA
 
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
