@@ -380,7 +380,7 @@ constexpr int TI = 16;  // query residues per work-group
 // rescale branch fold away and it is the same straight-line kernel as before the chunk loop existed (the loop costs 13 % at K=128).
 // EXT_S (single chunk only): phase 1 is not computed here; the logits image is copied from Sg[b][h][i][j], written by
 // ipa_logits_kernel (attention_split.hip), whose work-groups share the staged key side over 64 query rows instead of 16.
-// PLANES (single chunk only): `e` is not the fp32 pair embedding but its two-plane fp16 image written by pair_split_kernel (same
+// PLANES: `e` is not the fp32 pair embedding but its two-plane fp16 image written by pair_split_kernel (same
 // bytes: e s = h1 + h2 to 2^-23 of the tensor maximum, fragment order of the bias product), `esc` = {s, 1 / s}; the two products on
 // the pair tile then run on the f16 matrix cores as three exact partial products each (h1 w1, h1 w2, h2 w1 with fp32 accumulation)
 // instead of f32 MFMAs: 96 instead of 512 matrix-pipe cycles per key tile for the bias, 768 instead of 4096 per row for o_e.
@@ -395,7 +395,6 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
                                                             unsigned long long* __restrict__ stamps,
                                                             const float* __restrict__ Sg = nullptr, const float* __restrict__ esc = nullptr) {
   static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
-  static_assert(!(PLANES && MULTI), "fp16 pair planes: single key chunk only");
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
@@ -814,11 +813,18 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           }
           l_run += __shfl_xor(l_run, 16);
           l_run += __shfl_xor(l_run, 32);
-          const float inv = 1.0f / l_run;
-          // the probabilities of the earlier steps are relative to their own running maximum: rescale to the row maximum
+          // this chunk's (m_run, l_run) joins the row's running (M, L) over the chunks: everything of this chunk is scaled by cf,
+          // everything accumulated before it by fac (single chunk: cf = 1, fac = 0)
+          const float Mnew = MULTI ? fmaxf(Mrun[ii], m_run) : m_run;
+          const float fac = (!MULTI || c == 0) ? 0.0f : expf(Mrun[ii] - Mnew);
+          const float cf = MULTI ? expf(m_run - Mnew) : 1.0f;
+          Mrun[ii] = Mnew;
+          Lrun[ii] = Lrun[ii] * fac + l_run * cf;
+          const float inv = last ? 1.0f / Lrun[ii] : 1.0f;
+          // the probabilities of a step are relative to the running maximum of that step: rescale to the row maximum so far
 #pragma unroll
-          for (int T = 0; T < NT / 2 - 1; ++T) {
-            const float f = FAST_EXP(m_hist[T] - m_run);
+          for (int T = 0; T < NT / 2 - (MULTI ? 0 : 1); ++T) {
+            const float f = FAST_EXP(m_hist[T] - Mnew);
             if (l15 < 8) {
 #pragma unroll
               for (int tl = 0; tl < 2; ++tl) {
@@ -833,16 +839,23 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           // D: column = head l15, row 4 q + r <-> channel 16 ct + 4 q + r
           if (l15 < 8) {
             float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 4 * q;
-            const float sc = inv * oscale;
+            const float sc = cf * oscale;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
               f32x4 o = oe[ct];
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] *= sc;
+              if (MULTI && c > 0) {
+                const f32x4 old = *reinterpret_cast<const f32x4*>(fo + 16 * ct);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += old[r] * fac;
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] *= inv;
               *reinterpret_cast<f32x4*>(fo + 16 * ct) = o;
             }
             if (q == 0) {
-              st_fac[il * AH + h] = 0.0f;
+              st_fac[il * AH + h] = fac;
               st_inv[il * AH + h] = inv;
             }
           }
@@ -1338,6 +1351,8 @@ __global__ void pair_split_kernel(const float* __restrict__ e, const float* __re
   *reinterpret_cast<f16x8*>(base) = h1;          // plane 0: blocks (0, ks)
   *reinterpret_cast<f16x8*>(base + 1024) = h2;   // plane 1: blocks (1, ks)
 }
+// K = 64 / 128 (one key chunk).  The PLANES phase 2 also handles the chunked instantiation (parity-tested at K = 192 / 256), but at
+// 256 registers it spills 63 and measured SLOWER than the fp32 form there (5.93 vs 5.49 ms per step at B = 128, K = 256): not used.
 bool pair_planes_supported(const diffab_dims* d) { return fast_path_supported(d) && (d->K == 64 || d->K == 128); }
 size_t pair_planes_floats(const diffab_dims* d) {  // planes + {max bits, s, 1 / s} (64 floats)
   return pair_planes_supported(d) ? static_cast<size_t>(d->B) * d->K * d->K * AC + 64 : 0;
@@ -1479,19 +1494,19 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     timer_end(st);                                                                                                                    \
   } while (0)
 #define ATTN_LAUNCH(NT_, MULTI_) ATTN_LAUNCH_X(NT_, MULTI_, false)
-#define ATTN_LAUNCH_PLANES(NT_)                                                                                                       \
+#define ATTN_LAUNCH_PLANES(NT_, MULTI_)                                                                                               \
   do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, false, false, true>),                \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, false, true>),               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, false, false, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R, t,       \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, false, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R, t,      \
                        w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_planes + 1);                                     \
     timer_end(st);                                                                                                                    \
   } while (0)
   // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores; single key chunk, attention default mode only
-  if (pair_planes != nullptr && attn_mode == 0 && nc == 1 && pair_planes_supported(d)) {
-    if (nt == 8) ATTN_LAUNCH_PLANES(8);
-    else ATTN_LAUNCH_PLANES(4);
+  if (pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d)) {
+    if (nt == 8) ATTN_LAUNCH_PLANES(8, false);
+    else ATTN_LAUNCH_PLANES(4, false);
   } else if (ext_logits && nt == 8) ATTN_LAUNCH_X(8, false, true);
   else if (ext_logits) ATTN_LAUNCH_X(4, false, true);
   else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
