@@ -1505,11 +1505,7 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
       if (int rc = gemm_tn(dproj, NP, xin, D, nullptr, D, rows, NP, D, st, &gd)) return rc;
       if (planes && NP % 32 == 0 && rowgemm128_b6_ok(dproj, NP, dnxt, D, rows, NP)) {
         // dx = dproj [W_q_s; ...; W_v_p] as Y = X W'^T with W'[n][k] = W_seg[k - k0][n]: six strided splits into one set of planes
-        int k0 = 0;
-        for (int q = 0; q < 6; ++q) {
-          if (int rc = launch_wsplit128_strided(Ws[q], 1, D, Ns[q], k0, planes, st)) return rc;
-          k0 += Ns[q];
-        }
+        if (int rc = launch_wsplit128_segs(Ws, gw.n_end, 6, planes, st)) return rc;
         if (int rc = launch_rowgemm128_b6p(dproj, NP, planes, nullptr, nullptr, 0, dnxt, D, rows, NP, false, st)) return rc;
       } else if (int rc = gemm_nn(dproj, NP, nullptr, D, dnxt, D, rows, D, NP, false, st, &gw)) {
         return rc;

@@ -42,6 +42,7 @@ size_t rowgemm128_b6_scratch_bytes(int Kd);
 bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
 int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st);
 int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, int k0, void* planes, hipStream_t st);  // (n, k) = W[n sn + k sk]
+int launch_wsplit128_segs(const float* const* W, const int* k_end, int nseg, void* planes, hipStream_t st);  // W_q[k][n] stacked along k
 int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                           int ldy, int M, int Kd, bool relu, hipStream_t st);
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,

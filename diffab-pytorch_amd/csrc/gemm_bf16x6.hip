@@ -65,6 +65,24 @@ __global__ void wsplit128_strided_kernel(const float* __restrict__ W, int64_t sn
   out[base + 2 * 128 * BK] = l;
 }
 
+// the transposed planes of up to six matrices stacked along k (the IPA projections' input gradient): segment q holds rows
+// [k_end[q-1], k_end[q]) of the stacked operand as W_q[k - k_begin][n], n = 0..127 (one launch instead of six)
+struct SplitSegs { const float* p[6]; int k_end[6]; int nseg; };
+__global__ void wsplit128_segs_kernel(SplitSegs sg, int Ktot, __bf16* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (k, n): n fastest - coalesced reads of W_q rows
+  if (gid >= 128 * Ktot) return;
+  const int n = gid & 127, kg = gid >> 7;
+  int q = 0, beg = 0;
+  while (q + 1 < sg.nseg && kg >= sg.k_end[q]) { beg = sg.k_end[q]; ++q; }
+  __bf16 h, m, l;
+  split3(sg.p[q][static_cast<int64_t>(kg - beg) * 128 + n], h, m, l);
+  const int chunk = kg / BK, kk = kg % BK;
+  const size_t base = (static_cast<size_t>(chunk) * 3 * 128 + n) * BK + kk;
+  out[base] = h;
+  out[base + 128 * BK] = m;
+  out[base + 2 * 128 * BK] = l;
+}
+
 // LDS (dynamic): weights Ws[2 buffers][3 planes][128 rows][32 k], then X As[2][3][ROWS][32] - both operands are staged as split
 // bf16 planes: every element of X is split ONCE per work-group (its two column waves share the rows), and X is read from HBM in
 // full 128-byte lines (the MFMA fragment shape - adjacent lanes on different rows - costs the texture addresser four lines per
@@ -239,6 +257,18 @@ int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, i
   DIFFAB_REQUIRE(W && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && k0 % BK == 0 && kseg >= 1, DIFFAB_ERR_ARG,
                  "wsplit128_strided: bad operands");
   hipLaunchKernelGGL(wsplit128_strided_kernel, dim3((128 * kseg + 255) / 256), dim3(256), 0, st, W, sn, sk, kseg, k0, static_cast<__bf16*>(planes));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int launch_wsplit128_segs(const float* const* W, const int* k_end, int nseg, void* planes, hipStream_t st) {
+  DIFFAB_REQUIRE(W && k_end && nseg >= 1 && nseg <= 6 && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && k_end[nseg - 1] % BK == 0,
+                 DIFFAB_ERR_ARG, "wsplit128_segs: bad operands");
+  SplitSegs sg{};
+  sg.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) { sg.p[i] = W[i]; sg.k_end[i] = k_end[i]; }
+  const int Ktot = k_end[nseg - 1];
+  hipLaunchKernelGGL(wsplit128_segs_kernel, dim3((128 * Ktot + 255) / 256), dim3(256), 0, st, sg, Ktot, static_cast<__bf16*>(planes));
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
