@@ -283,6 +283,16 @@ int diffab_device_ok(void) {
   return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
+int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
+                           size_t scratch_bytes, void* stream) {
+  DIFFAB_REQUIRE(X && W && Y && M >= 1 && M < (1LL << 31) && Kd >= 32 && Kd % 32 == 0, DIFFAB_ERR_ARG, "debug_linear128: bad operands");
+  hipStream_t st = as_stream(stream);
+  if (mode == 0) return launch_linear(X, Kd, W, bias, Y, 128, static_cast<int>(M), 128, Kd, false, st);  // rowgemm128 / tiled f32 MFMA
+  DIFFAB_REQUIRE(mode == 1 && scratch && scratch_bytes >= rowgemm128_b6_scratch_bytes(Kd) && rowgemm128_b6_ok(X, Kd, Y, 128, static_cast<int>(M), Kd),
+                 DIFFAB_ERR_ARG, "debug_linear128: mode 1 needs 16-byte aligned operands and %zu bytes of scratch", rowgemm128_b6_scratch_bytes(Kd));
+  return launch_rowgemm128_b6(X, Kd, W, Kd, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, scratch, st);
+}
+
 int diffab_debug_set_attn_stamps(void* device_buffer) {
   set_attn_stamps(device_buffer);
   return DIFFAB_OK;

@@ -149,6 +149,11 @@ int diffab_kernel_timer_enable(int on);
 /* Diagnostics only: while a device buffer of (work-groups x 8 waves x 8) uint64 is registered, the fused attention kernel
  * writes s_memtime stamps at its phase boundaries into it (tools/attn_phase_profile.py).  NULL (default) disables it. */
 int diffab_debug_set_attn_stamps(void* device_buffer);
+/* Diagnostics / accuracy tests: Y[M x 128] = X[M x Kd] W[128 x Kd]^T + bias through ONE of the two dense kernels of the MFMA path -
+ * mode 0: f32-input MFMA (rowgemm128_kernel), mode 1: bf16 matrix cores, six-term split (rowgemm128_b6_kernel; scratch >=
+ * 3 * 128 * Kd * 2 bytes, 16-byte aligned operands).  Kd a multiple of 32.  Lets a test measure both against float64. */
+int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
+                           size_t scratch_bytes, void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
 
 /* ---- SO(3) maps, n matrices/vectors each --------------------------------- */

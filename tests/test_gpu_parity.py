@@ -958,3 +958,28 @@ def test_encode_context_benchmark_dims_and_end_to_end(hip):
     out = model.sample(dev["seq_idx"], dev["xyz"], dev["orientations"], res_context_emb=res, pair_context_emb=pair,
                        generation_mask=dev["generation_mask"], seed=5, t_start=100, t_stop=90)
     assert torch.isfinite(out["translations"]).all() and out["translations"].shape == (B, K, 3)
+
+
+@pytest.mark.parametrize("Kd", [128, 1024, 1344])
+def test_split_precision_gemm_is_fp32_accurate(hip, Kd):
+    """The bf16x6 dense kernel (three exact bf16 pieces per operand, six exact partial products, fp32 accumulation) against float64,
+    side by side with the f32-input MFMA kernel it replaces: its error must be of the same size, on operands whose
+    magnitudes span six decades (the split must not care) and at the three contraction lengths of the model."""
+    g = torch.Generator(device="cuda").manual_seed(Kd)
+    M = 4096 + 37  # ragged last work-group
+    X = torch.randn(M, Kd, device="cuda", generator=g) * torch.exp(3 * torch.randn(M, 1, device="cuda", generator=g))
+    W = torch.randn(128, Kd, device="cuda", generator=g) * 0.1 * torch.exp(2 * torch.randn(128, 1, device="cuda", generator=g))
+    b = torch.randn(128, device="cuda", generator=g)
+    want = X.double() @ W.double().T + b.double()
+    scale = (X.double().abs() @ W.double().abs().T) + b.double().abs()  # the natural error scale of a dot product: sum |x w|
+    scratch = torch.empty(3 * 128 * Kd * 2 + 256, dtype=torch.uint8, device="cuda")
+    errs = {}
+    for mode in (0, 1):
+        Y = torch.empty(M, 128, device="cuda")
+        rc = hip.diffab_debug_linear128(_hip.ptr(X), _hip.ptr(W), _hip.ptr(b), _hip.ptr(Y), M, Kd, mode, _hip.ptr(scratch), scratch.numel(),
+                                        _hip.stream_ptr())
+        assert rc == 0, hip.diffab_last_error()
+        errs[mode] = float(((Y.double() - want).abs() / scale).max())
+    print(f"Kd={Kd}: max |err| / sum|x w|: f32 MFMA {errs[0]:.2e}, bf16x6 {errs[1]:.2e}")
+    assert errs[0] < 2e-6 and errs[1] < 2e-6, errs      # both at fp32 accumulation noise (a plain bf16 product would be ~4e-3)
+    assert errs[1] < 4 * errs[0] + 1e-7, errs           # and the split form is not worse than the fp32 kernel by more than noise
