@@ -647,7 +647,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #define DIFFAB_E_DEPTH0 3  // tiles of the first row in flight before its bias loop starts; the rest follow one per consumed tile (all 8 at once:
                            // 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it builds delays every other CU's loads)
 #endif
-      constexpr int E_DEPTH0 = PLANES ? NT : (DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT);
+      // PLANES: RT = pair tiles of the wave's 2 NT-tile stream held in registers (requested RT tiles ahead of their use): a whole row
+      // in the single-chunk kernel, half a row in the chunked one (whose chunk loop leaves 64 registers less)
+      constexpr int RT = MULTI ? NT / 2 : NT;
+      constexpr int E_DEPTH0 = PLANES ? RT : (DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT);
       if constexpr (!PLANES) {
 #pragma unroll
         for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
@@ -787,10 +790,15 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
                 for (int ks = 0; ks < 2; ++ks)
                   *reinterpret_cast<f32x4*>(trt + (tl * 2 + pl) * 2048 + (wr_off ^ (64 * ks))) = ev[ii][2 * T + tl][2 * pl + ks];
             }
-            if (ii == 0) {  // the tiles are in LDS: their registers take the same tiles of the next row (eight tiles ahead)
-              load_e_tile(1, c, 2 * T);
-              load_e_tile(1, c, 2 * T + 1);
-              MEM_FENCE();
+            {  // the two tiles are in LDS: request the tiles RT ahead in the wave's stream (rest of this row, then the next row)
+              constexpr int dummy_ = 0;
+              (void)dummy_;
+              const int nx = ii * NT + 2 * T + RT;  // compile-time after unrolling
+              if (nx < 2 * NT) {
+                load_e_tile(nx / NT, c, nx % NT);
+                load_e_tile((nx + 1) / NT, c, (nx + 1) % NT);
+                MEM_FENCE();
+              }
             }
             // ---- o_e[channel][head] += e^T P: the A operand (8 keys per lane for one channel) through the transposing LDS read
             f16x8 a[2][4];
@@ -1351,9 +1359,7 @@ __global__ void pair_split_kernel(const float* __restrict__ e, const float* __re
   *reinterpret_cast<f16x8*>(base) = h1;          // plane 0: blocks (0, ks)
   *reinterpret_cast<f16x8*>(base + 1024) = h2;   // plane 1: blocks (1, ks)
 }
-// K = 64 / 128 (one key chunk).  The PLANES phase 2 also handles the chunked instantiation (parity-tested at K = 192 / 256), but at
-// 256 registers it spills 63 and measured SLOWER than the fp32 form there (5.93 vs 5.49 ms per step at B = 128, K = 256): not used.
-bool pair_planes_supported(const diffab_dims* d) { return fast_path_supported(d) && (d->K == 64 || d->K == 128); }
+bool pair_planes_supported(const diffab_dims* d) { return fast_path_supported(d); }  // any K the fused kernel takes (K % 64 == 0)
 size_t pair_planes_floats(const diffab_dims* d) {  // planes + {max bits, s, 1 / s} (64 floats)
   return pair_planes_supported(d) ? static_cast<size_t>(d->B) * d->K * d->K * AC + 64 : 0;
 }
@@ -1505,8 +1511,10 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   } while (0)
   // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores; single key chunk, attention default mode only
   if (pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d)) {
-    if (nt == 8) ATTN_LAUNCH_PLANES(8, false);
-    else ATTN_LAUNCH_PLANES(4, false);
+    if (nt == 8 && nc == 1) ATTN_LAUNCH_PLANES(8, false);
+    else if (nt == 8) ATTN_LAUNCH_PLANES(8, true);
+    else if (nc == 1) ATTN_LAUNCH_PLANES(4, false);
+    else ATTN_LAUNCH_PLANES(4, true);
   } else if (ext_logits && nt == 8) ATTN_LAUNCH_X(8, false, true);
   else if (ext_logits) ATTN_LAUNCH_X(4, false, true);
   else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
