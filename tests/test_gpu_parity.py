@@ -983,3 +983,25 @@ def test_split_precision_gemm_is_fp32_accurate(hip, Kd):
     print(f"Kd={Kd}: max |err| / sum|x w|: f32 MFMA {errs[0]:.2e}, bf16x6 {errs[1]:.2e}")
     assert errs[0] < 2e-6 and errs[1] < 2e-6, errs      # both at fp32 accumulation noise (a plain bf16 product would be ~4e-3)
     assert errs[1] < 4 * errs[0] + 1e-7, errs           # and the split form is not worse than the fp32 kernel by more than noise
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4])
+def test_pair_planes_scale_robustness(hip, scale):
+    """fp16 planes of the pair embedding (DIFFAB_FLAG_PAIR_PLANES) against the fp32-pair kernel when the tensor's magnitude is far from
+    one and a single outlier sets the maximum: the power-of-two rescaling keeps both fp16 pieces in range, and the bias weights shrink
+    by the same factor so that the logits keep their size (otherwise the softmax would saturate and hide any error)."""
+    from diffab_pytorch.diffab_pytorch import InvariantPointAttentionLayer
+
+    d = syn.BENCH_DIMS
+    torch.manual_seed(1)
+    layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    inp = {k: v.cuda() for k, v in syn.patches(2, 128, d, seed=9, coord_sigma=6.0).items()}
+    e = inp["pair_context_emb"] * scale
+    e[0, 3, 5, 7] = 37.0 * scale  # one element far above the rest: the scale is chosen for it, everything else sits 5 binades lower
+    with torch.no_grad():
+        layer.to_pair_bias.weight.mul_(1.0 / scale)
+    args = (inp["res_context_emb"], e, inp["orientations"], inp["translations"])
+    ref = layer(*args)
+    got = layer(*args, flags=_hip.FLAG_PAIR_PLANES)
+    assert torch.isfinite(got).all()
+    assert maxrel(got, ref) < 2e-6, (scale, maxrel(got, ref))
