@@ -56,7 +56,7 @@ static int check_dims(const diffab_dims* d, const char* who) {
 
 struct StepBuffers {
   float *cat2, *h1, *hA, *hB, *cat3, *t1, *t2, *vbuf, *logits, *ipa, *emb_tab, *beta_tab;
-  char* planes;  // split bf16 planes of the dense weights (MFMA path): NL x ipa_layer_planes_bytes(), then 8 MLP matrices
+  char* planes;  // split bf16 planes of the dense weights (MFMA path): NL x ipa_layer_planes_bytes(), then 11 MLP matrices
   float* pair;   // fp16 planes of the pair embedding (launch_pair_split), null when the fused kernel cannot take them
   size_t bytes;
 };
@@ -80,7 +80,7 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
   size_t ipa_floats = ipa_generic_workspace_floats(d);
   if (fast_path_supported(d)) ipa_floats = ipa_floats > ipa_fast_workspace_floats(d) ? ipa_floats : ipa_fast_workspace_floats(d);
   b.ipa = c.take<float>(ipa_floats);
-  b.planes = fast_path_supported(d) ? c.take<char>(d->NL * ipa_layer_planes_bytes() + 8 * mlp_planes_bytes()) : nullptr;
+  b.planes = fast_path_supported(d) ? c.take<char>(d->NL * ipa_layer_planes_bytes() + 11 * mlp_planes_bytes()) : nullptr;
   b.pair = pair_planes_supported(d) ? c.take<float>(pair_planes_floats(d)) : nullptr;
   b.bytes = c.bytes();
   return b;
@@ -134,6 +134,9 @@ static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* 
   for (int hd = 0; hd < 3; ++hd) {                                                              // slots 2 + 2 hd, 3 + 2 hd
     if (int rc = launch_wsplit128(hw[hd]->w0, D + 3, D, mlp + (2 + 2 * hd) * mlp_planes_bytes(), st)) return rc;
     if (int rc = launch_wsplit128(hw[hd]->w2, D, D, mlp + (3 + 2 * hd) * mlp_planes_bytes(), st)) return rc;
+    DIFFAB_REQUIRE(hw[hd]->w4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
+    const int nout = hd == 2 ? d->V : 3;                                                          // slot 8 + hd: the narrow last layer
+    if (int rc = launch_wsplit128(hw[hd]->w4, D, D, mlp + (8 + hd) * mlp_planes_bytes(), st, nout)) return rc;
   }
   return DIFFAB_OK;
 }
@@ -170,7 +173,17 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     if (b6) return launch_rowgemm128_b6p(X, D, mlp + slot * mlp_planes_bytes(), bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
     return launch_rowgemm128(X, D, W, ldw, bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
   };
-  if (fold) {
+  // DIFFAB_MLP_UNFUSED=1: one launch per dense layer (A/B timing); default: each MLP as one row-resident kernel (mlp_chain_b6_kernel)
+  static const bool chain_env = [] {
+    const char* e = getenv("DIFFAB_MLP_UNFUSED");
+    return e == nullptr || atoi(e) == 0;
+  }();
+  const bool chain = b6 && chain_env && d->V <= 128;
+  if (fold && chain) {
+    const void* pl[2] = {mlp, mlp + mlp_planes_bytes()};
+    const float* bs[2] = {b.emb_tab, w->res_b2};
+    if (int rc = launch_mlp_chain_b6(res_ctx, D, pl, bs, seq_t, 0, 2, D, b.hA, D, rows, st)) return rc;
+  } else if (fold) {
     if (int rc = dense128(0, res_ctx, w->res_w0, 2 * D, b.emb_tab, seq_t, 0, b.h1, true)) return rc;
     if (int rc = dense128(1, b.h1, w->res_w2, D, w->res_b2, nullptr, 0, b.hA, false)) return rc;
   } else {
@@ -193,6 +206,12 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     const int nout[3] = {3, 3, d->V};
     for (int hd = 0; hd < 3; ++hd) {
       DIFFAB_REQUIRE(hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
+      if (chain) {
+        const void* pl[3] = {mlp + (2 + 2 * hd) * mlp_planes_bytes(), mlp + (3 + 2 * hd) * mlp_planes_bytes(), mlp + (8 + hd) * mlp_planes_bytes()};
+        const float* bs[3] = {b.beta_tab + static_cast<size_t>(hd) * d->B * D, hw[hd]->b2, hw[hd]->b4};
+        if (int rc = launch_mlp_chain_b6(cur, D, pl, bs, nullptr, d->K, 3, nout[hd], outs[hd], nout[hd], rows, st)) return rc;
+        continue;
+      }
       if (int rc = dense128(2 + 2 * hd, cur, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, true))
         return rc;
       if (int rc = dense128(3 + 2 * hd, b.t1, hw[hd]->w2, D, hw[hd]->b2, nullptr, 0, b.t2, true)) return rc;

@@ -40,7 +40,11 @@ int launch_rowgemm128(const float* X, int ldx, const float* W, int ldw, const fl
 // once per trajectory by the reverse sampler) and the ...p launchers take the planes.
 size_t rowgemm128_b6_scratch_bytes(int Kd);
 bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd);
-int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st);
+int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st, int nrows = 128);  // rows >= nrows: zero planes
+// X[M x 128] through 2 or 3 dense 128-wide layers in ONE kernel (ReLU between them, the last layer n_out <= 128 columns wide,
+// activations stay in LDS); layer 0's bias may be a table indexed per row like launch_rowgemm128's
+int launch_mlp_chain_b6(const float* X, int ldx, const void* const* planes, const float* const* bias, const int64_t* bias_idx0, int bias_div0,
+                        int nlayers, int n_out, float* Y, int ldy, int M, hipStream_t st);
 int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, int k0, void* planes, hipStream_t st);  // (n, k) = W[n sn + k sk]
 int launch_wsplit128_segs(const float* const* W, const int* k_end, int nseg, void* planes, hipStream_t st);  // W_q[k][n] stacked along k
 int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,

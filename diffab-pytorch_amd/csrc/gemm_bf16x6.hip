@@ -37,12 +37,12 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 
 // W[128 x Kd] fp32 (rows ldw floats apart) -> three bf16 planes, chunk-major:  out[((chunk * 3 + s) * 128 + n) * 32 + kk],
 // chunk = k / 32, kk = k % 32.  One chunk = 24 KiB contiguous: the GEMM stages it with full-line loads and no address arithmetic.
-__global__ void wsplit128_kernel(const float* __restrict__ W, int ldw, int Kd, __bf16* __restrict__ out) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (n, k)
+__global__ void wsplit128_kernel(const float* __restrict__ W, int ldw, int Kd, __bf16* __restrict__ out, int nrows) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (n, k); rows n >= nrows of the 128-row operand are zero (narrow last layers)
   if (gid >= 128 * Kd) return;
   const int n = gid / Kd, k = gid % Kd;
   __bf16 h, m, l;
-  split3(W[static_cast<int64_t>(n) * ldw + k], h, m, l);
+  split3(n < nrows ? W[static_cast<int64_t>(n) * ldw + k] : 0.0f, h, m, l);
   const int chunk = k / BK, kk = k % BK;
   const size_t base = (static_cast<size_t>(chunk) * 3 * 128 + n) * BK + kk;
   out[base] = h;
@@ -238,6 +238,176 @@ __global__ __launch_bounds__(ROWS * 4) void rowgemm128_b6_kernel(const float* __
   }
 }
 
+// ================================================================== a chain of two or three 128-wide dense layers in one kernel
+// Y = L3(relu(L2(relu(L1(X))))) (or two layers) for 128 rows per work-group, every layer K = 128 -> 128 columns (the last one n_out <=
+// 128 wide, its missing weight rows zero planes).  The denoiser's MLPs (embedding: 2 layers; the three heads: 3 layers each) were
+// nine + two launches of 10-19 us, each latency-bound (four 32-k chunks per work-group between a cold start and a 64 KiB store);
+// here the activations never leave the CU: X is staged ONCE as split bf16 planes into a [4 chunks][3 planes][128 rows][32 k] LDS image
+// (96 KiB, the same swizzled rows as rowgemm128_b6_kernel), a layer reads its A fragments from the image and streams its weight planes
+// through the usual two-buffer ring, and its output (bias, ReLU) is split and written back INTO the image for the next layer.
+struct MlpChain {
+  const __bf16* planes[3];  // wsplit128 planes of each layer (K = 128)
+  const float* bias[3];     // layer 0: vector, or table rows of 128 selected by bias_idx0[row] / row / bias_div0; layers 1, 2: vectors
+  const int64_t* bias_idx0;
+  int bias_div0;
+  int nlayers;  // 2 or 3
+  int n_out;    // columns of the last layer that exist
+};
+constexpr int kChainLdsBytes = 2 * 3 * 128 * BK * 2 + 4 * 3 * 128 * BK * 2;  // 49 152 + 98 304
+
+__global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restrict__ X, int ldx, MlpChain ch, float* __restrict__ Y, int ldy,
+                                                           int M) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 cl[];
+  __bf16* Ws = cl;                        // [2][3][128][32]
+  __bf16* img = cl + 2 * 3 * 128 * BK;    // [4][3][128][32]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, hk = lane >> 5, rw = wv & 3, cw = wv >> 2;  // wave tile 32 rows x 64 columns (32x32x16 MFMA)
+  const int m0 = blockIdx.x * 128;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  // ---- X -> image: thread (rows tid / 8 and 64 + tid / 8, 16-byte part tid % 8) of each of the four 32-k chunks
+  {
+    const int xa_row = tid >> 3, xa_part = tid & 7;
+    f32x4 xr[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int row = m0 + xa_row + 64 * j;
+      row = row < M ? row : M - 1;  // clamped (never stored)
+      const float* src = X + static_cast<int64_t>(row) * ldx + 4 * xa_part;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xr[c][j] = *reinterpret_cast<const f32x4*>(src + c * BK);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 hh, mm, ll;
+          split3(xr[c][j][e], hh, mm, ll);
+          h[e] = hh; m[e] = mm; l[e] = ll;
+        }
+        __bf16* dst = img + c * (3 * 128 * BK) + b6_off(xa_row + 64 * j, xa_part >> 1) + 4 * (xa_part & 1);
+        *reinterpret_cast<bf16x4*>(dst) = h;
+        *reinterpret_cast<bf16x4*>(dst + 128 * BK) = m;
+        *reinterpret_cast<bf16x4*>(dst + 2 * 128 * BK) = l;
+      }
+  }
+  // weight staging: a chunk is 1536 16-byte pieces = 3 per thread (plane p = pass, row tid / 4, part tid % 4)
+  int w_dst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) w_dst[i] = (i * 128) * BK + b6_off(tid >> 2, tid & 3);
+  f32x4 wreg[3];
+  auto load_w = [&](const __bf16* Wc, int c) {
+    const __bf16* src = Wc + static_cast<size_t>(c < 4 ? c : 3) * (3 * 128 * BK) + tid * 8;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wreg[i] = *reinterpret_cast<const f32x4*>(src + 512 * 8 * i);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(Ws + buf * (3 * 128 * BK) + w_dst[i]) = wreg[i];
+  };
+  const int fx = (l31 >> 2) & 3;
+  const int a_off = (32 * rw + l31) * BK, w_off = (64 * cw + l31) * BK;
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+  load_w(ch.planes[0], 0);
+  for (int L = 0; L < ch.nlayers; ++L) {
+    const __bf16* Wc = ch.planes[L];
+    const bool last = L == ch.nlayers - 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+    store_w(0);
+    load_w(Wc, 1);
+    MEM_FENCE();
+    __syncthreads();  // the image (X, or the previous layer's output) and the first weight chunk are in LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int buf = c & 1;
+      const __bf16* al = img + c * (3 * 128 * BK) + a_off;
+      const __bf16* wl = Ws + buf * (3 * 128 * BK) + w_off;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int so = 8 * ((2 * ks + hk) ^ fx);
+        bf16x8 a[3], b[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[p] = *reinterpret_cast<const bf16x8*>(al + (p * 128) * BK + so);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) b[tt][p] = *reinterpret_cast<const bf16x8*>(wl + (p * 128 + 32 * tt) * BK + so);
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[term]], b[tt][TB[term]], acc[tt], 0, 0, 0);
+      }
+      if (c < 3) {  // next chunk of this layer into the other buffer, then request the one after it (or the next layer's first chunk)
+        store_w(buf ^ 1);
+        if (c < 2) load_w(Wc, c + 2);
+        else if (!last) load_w(ch.planes[L + 1], 0);
+        MEM_FENCE();
+      }
+      __syncthreads();
+    }
+    // ---- epilogue.  D 32x32: column = lane & 31 (+ 32 tt + 64 cw), row = (r & 3) + 8 (r >> 2) + 4 hk (+ 32 rw)
+    const bool table = L == 0 && (ch.bias_idx0 != nullptr || ch.bias_div0 > 0);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int col = 64 * cw + 32 * tt + l31;
+      float bv = (ch.bias[L] && !table && (!last || col < ch.n_out)) ? ch.bias[L][col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = 32 * rw + (r & 3) + 8 * (r >> 2) + 4 * hk, row = m0 + lrow;
+        if (table) {
+          const int rc = row < M ? row : M - 1;
+          const int64_t bi = ch.bias_idx0 ? ch.bias_idx0[rc] : rc / ch.bias_div0;
+          bv = ch.bias[0][bi * 128 + col];
+        }
+        float o = acc[tt][r] + bv;
+        if (last) {
+          if (row < M && col < ch.n_out) Y[static_cast<int64_t>(row) * ldy + col] = o;
+        } else {
+          o = fmaxf(o, 0.f);  // every layer but the last is followed by a ReLU
+          __bf16 hh, mm, ll;
+          split3(o, hh, mm, ll);
+          // element (row lrow, k = col) of the next layer's input: chunk col / 32, slot (col % 32) / 8, element col % 8.  All reads of
+          // the image by this layer are behind the last barrier of the chunk loop.
+          __bf16* dst = img + (col >> 5) * (3 * 128 * BK) + b6_off(lrow, (col & 31) >> 3) + (col & 7);
+          dst[0] = hh;
+          dst[128 * BK] = mm;
+          dst[2 * 128 * BK] = ll;
+        }
+      }
+    }
+  }
+}
+
+// X[M x 128] through a chain of 2 or 3 dense layers (see mlp_chain_b6_kernel); planes from launch_wsplit128 (Kd = 128; the last layer's
+// with nrows = n_out)
+int launch_mlp_chain_b6(const float* X, int ldx, const void* const* planes, const float* const* bias, const int64_t* bias_idx0, int bias_div0,
+                        int nlayers, int n_out, float* Y, int ldy, int M, hipStream_t st) {
+  DIFFAB_REQUIRE(X && Y && M >= 1 && (nlayers == 2 || nlayers == 3) && n_out >= 1 && n_out <= 128 && ldx % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(X) & 15) == 0,
+                 DIFFAB_ERR_ARG, "mlp_chain_b6: unsupported operands");
+  MlpChain ch{};
+  for (int i = 0; i < nlayers; ++i) {
+    DIFFAB_REQUIRE(planes[i] && (reinterpret_cast<uintptr_t>(planes[i]) & 15) == 0, DIFFAB_ERR_ARG, "mlp_chain_b6: null / misaligned planes");
+    ch.planes[i] = static_cast<const __bf16*>(planes[i]);
+    ch.bias[i] = bias[i];
+  }
+  ch.bias_idx0 = bias_idx0;
+  ch.bias_div0 = bias_div0;
+  ch.nlayers = nlayers;
+  ch.n_out = n_out;
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_b6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+  hipLaunchKernelGGL(mlp_chain_b6_kernel, dim3((M + 127) / 128), dim3(512), kChainLdsBytes, st, X, ldx, ch, Y, ldy, M);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 size_t rowgemm128_b6_scratch_bytes(int Kd) { return static_cast<size_t>(3) * 128 * Kd * sizeof(__bf16); }
 
 bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd) {
@@ -246,9 +416,10 @@ bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, i
 }
 
 // W[128 x Kd] (rows ldw floats apart) -> split planes for rowgemm128_b6p (rowgemm128_b6_scratch_bytes(Kd) bytes, 16-byte aligned)
-int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st) {
-  DIFFAB_REQUIRE(W && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && Kd % BK == 0, DIFFAB_ERR_ARG, "wsplit128: bad operands");
-  hipLaunchKernelGGL(wsplit128_kernel, dim3((128 * Kd + 255) / 256), dim3(256), 0, st, W, ldw, Kd, static_cast<__bf16*>(planes));
+int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st, int nrows) {
+  DIFFAB_REQUIRE(W && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && Kd % BK == 0 && nrows >= 1 && nrows <= 128, DIFFAB_ERR_ARG,
+                 "wsplit128: bad operands");
+  hipLaunchKernelGGL(wsplit128_kernel, dim3((128 * Kd + 255) / 256), dim3(256), 0, st, W, ldw, Kd, static_cast<__bf16*>(planes), nrows);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
