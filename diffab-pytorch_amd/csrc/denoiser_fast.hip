@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   float* st_fac = S + TI * IS + 8 * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
   float* st_inv = st_fac + TI * AH;              // [TI][AH] 1 / L after the last chunk (1 before)
   float* wb_lds = st_inv + TI * AH;              // [4 sg][64 lanes][4]: B fragments of the bias product (same for every wave)
-  if (wv == 0) {  // Wb[h][16 sg + 4 q + s] for lane (h = l15 < 8, q), zero in the padding columns; first read is behind a barrier
+  if (wv == 0 && !PLANES) {  // Wb[h][16 sg + 4 q + s] for lane (h = l15 < 8, q), zero in the padding columns; first read is behind a barrier
     const int l15_ = lane0 & 15, q_ = lane0 >> 4;
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {
@@ -486,6 +486,8 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     asm volatile("" : "+v"(lane));
     const int l15 = lane & 15, q = lane >> 4;
     f32x4 ev[2][NT][4];
+    f32x4 wv4[2][2];  // PLANES: the bias weights of lane (head, channel group), requested in phase 1's tail AHEAD of the first pair tiles:
+                      // vmcnt retires in order, so loaded behind them they would cost every wave a pair-tile latency in front of the barrier
     auto load_e_tile = [&](int ii, int cc_, int jt) {
       if constexpr (PLANES) {  // four 1 KiB blocks per key tile, lane order: ev[ii][jt][2 p + ks] = fragment (plane p, k-step ks)
         const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii]) + (cc_ * NT + jt) * 256 + lane;
@@ -592,6 +594,15 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #endif
           load_keys(jt % SD, jt + SD);  // slot of tile jt (staged two iterations ago)
         } else if (jt + E_EARLY >= NT) {
+          if constexpr (PLANES) {
+            if (jt + E_EARLY == NT) {
+              const int hh = lane & 7, qq = lane >> 4;
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + hh * AC + 32 * ks + 8 * qq + 4 * hf);
+            }
+          }
           load_e_tile(0, c, jt + E_EARLY - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
         }
         MEM_FENCE();
@@ -659,16 +670,13 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       f16x8 wp[2][2];  // PLANES: bias B fragments as two fp16 planes, wp[plane][ks]: lane (head l15, channels 32 ks + 8 q ..), scaled by sw
       float bscale = scale_t, oscale = 1.0f;
       if constexpr (PLANES) {
-        f32x4 wv4[2][2];
         float wmax = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 32 * ks + 8 * q + 4 * hf);
+          for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int s = 0; s < 4; ++s) wmax = fmaxf(wmax, fabsf(wv4[ks][hf][s]));
-          }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
         // sw = 2^(7 - exponent(wmax)): the largest weight lands in [128, 256), far from fp16's subnormals and its overflow
