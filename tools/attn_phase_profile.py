@@ -54,5 +54,10 @@ if (s[..., 6] > 0).all():
     for nm, a, b_ in (("  P1 start -> end of key tile 0", 0, 6), ("  P1 key tiles 1..3", 6, 7), ("  P1 key tiles 4..7", 7, 1)):
         dlt = s[..., b_] - s[..., a]
         print(f"{nm:44s} mean {dlt.mean():9.0f}  min {dlt.min():9.0f}  max {dlt.max():9.0f}")
+e1 = s[..., 1] - s[..., 0].min(dim=1, keepdim=True).values  # end of phase 1 relative to the work-group's first stamp
+print(f"  within a work-group: phase-1 end of the slowest wave - mean over its waves: mean {(e1.max(dim=1).values - e1.mean(dim=1)).mean():.0f} cycles; "
+      f"start skew (last wave's first stamp - first wave's) mean {(s[..., 0].max(dim=1).values - s[..., 0].min(dim=1).values).mean():.0f}")
+for wvi in range(8):
+    print(f"    wave {wvi}: phase 1 mean {(s[:, wvi, 1] - s[:, wvi, 0]).mean():.0f}")
 span = s[..., 5].max() - s[..., 0].min()
 print(f"  kernel span (first stamp to last stamp): {span:.0f} cycles; 100 MHz-based? memtime ticks are shader cycles")
