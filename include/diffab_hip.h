@@ -24,9 +24,9 @@
  *     thread-safe and must not be left enabled in production; (b)
  *     DIFFAB_FLAG_GRAPH_SAMPLER makes diffab_sample_loop drain a private stream
  *     before it returns; (c) the environment variables DIFFAB_FP32_GEMM,
- *     DIFFAB_ATTN_FLASH, DIFFAB_FLASH_WAVES, DIFFAB_E_DEPTH0 select kernel
- *     variants for A/B timing, are read once per process, and change results
- *     only within rounding;
+ *     DIFFAB_PAIR_F32, DIFFAB_MLP_UNFUSED, DIFFAB_B6_ROWS, DIFFAB_ATTN_FLASH,
+ *     DIFFAB_FLASH_WAVES select kernel variants for A/B timing, are read once
+ *     per process, and change results only within rounding;
  *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
  *     diffab_last_error() gives the thread's last message.
  */
