@@ -34,6 +34,17 @@ def algorithmic_bytes_per_attention_launch(B, K, D, C):
     return B * K * K * C * 4
 
 
+def algorithmic_flops_per_residue_step(K, dims):
+    """FLOPs of one denoise call per residue, counted on the reference's formulation (2 per multiply-add):
+    per IPA layer and residue the six projections 2 D (3 H ds + 3 H P 3), logits 2 K H (ds + 3 P) + bias 2 K C H, the three
+    attention-weighted sums 2 K H (ds + C + 3 P), to_out 2 D (H ds + H C + 4 H P); plus the embedding and head MLPs."""
+    D, C, H, ds, P, NL = dims["D"], dims["C"], dims["H"], dims["DS"], dims["PQ"], dims["NL"]
+    layer = 2 * D * (3 * H * ds + 9 * H * P) + 2 * K * H * (ds + 3 * P) + 2 * K * C * H + 2 * K * H * (ds + C + 3 * P) \
+        + 2 * D * (H * ds + H * C + 4 * H * P)
+    mlps = 2 * (2 * D * D + D * D) + 3 * 2 * ((D + 3) * D + D * D) + 2 * D * (3 + 3 + 21)
+    return NL * layer + mlps
+
+
 def algorithmic_bytes_per_residue_step(K, D, C, NL, V=21):
     """NL*K^2*C*4 (pair stream) + K*D*4 (res ctx) + K*(8+12+36) in + K*(12+36+4V) out, per residue."""
     per_patch = NL * K * K * C * 4 + K * D * 4 + K * (8 + 12 + 36) + K * (12 + 36 + 4 * V)
@@ -397,6 +408,11 @@ def main():
                 "path": "generic" if args.generic else ("mfma-split-attention" if args.split_attention else ("mfma-external-logits" if args.external_logits else "mfma")),
             },
             "residue_steps_per_s_per_gpu": value / world,
+            # SURVEY 8(d) secondary figures: only the residues being generated (masks do not prune compute: every residue of a patch
+            # costs the same), and the same rate against the fp32 compute roof (7.1 MFLOP per residue-step at K = 128; 157 TFLOP/s
+            # vendor fp32 MFMA / VALU peak) - which lies BELOW the HBM roof for this path (22 M vs 40.5 M residue-steps/s per GPU)
+            "generated_residue_steps_per_s": value * float(gm.float().mean()),
+            "fp32_compute_frac": value / world * algorithmic_flops_per_residue_step(K, dims) / 157e12,
             "whole_path_hbm_frac": value / world * algorithmic_bytes_per_residue_step(K, dims["D"], dims["C"], dims["NL"]) / 1e9
                                    / HBM_PEAK_GBPS,
             "roofline": {
