@@ -963,7 +963,8 @@ int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C
   sg.nseg = nseg;
   for (int i = 0; i < nseg; ++i) { sg.p[i] = seg_ptrs[i]; sg.n_end[i] = seg_ends[i]; }
   const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128, tiles = t1 * t2;
-  int splits = (256 + tiles - 1) / tiles;  // one (tile, M chunk) work-group per CU
+  int splits = 256 / tiles;  // at most one (tile, M chunk) work-group per CU (one group per CU fits; 264 groups would run in two rounds)
+  if (splits < 1) splits = 1;
   int m_chunk = (M + splits - 1) / splits;
   m_chunk = ((m_chunk < 256 ? 256 : m_chunk) + 31) / 32 * 32;
   const int nchunks = (M + m_chunk - 1) / m_chunk;
