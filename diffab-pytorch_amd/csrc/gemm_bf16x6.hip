@@ -531,11 +531,15 @@ __global__ void pjsplit_kernel(const float* __restrict__ W0, const float* __rest
 // floats apart, frames applied to blocks >= frames_from (NB: none; R, t may then be null).  The same kernel is the input-gradient
 // product of to_out: dfeat[M x 1024] = dy[M x 128] Wo, with the planes of Wo^T (xsplit_kernel).
 // PROJ: the geometry of the six projections at compile time (runtime geometry costs this kernel 11 %: 70 vs 63 us)
-template <bool FULL, bool PROJ>  // FULL: M is a multiple of 128, no row guards
+// SPLIT: the blocks are shared by gridDim.y work-groups per row tile (each re-reads the x rows and streams its share of the weights):
+// twice the groups of half the length when 128-row tiles alone would leave CUs idle (B <= 128 patches of 128 residues per GPU)
+template <bool FULL, bool PROJ, bool SPLIT = false>  // FULL: M is a multiple of 128, no row guards
 __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __restrict__ X, const __bf16* __restrict__ Wc,
                                                              const float* __restrict__ R, const float* __restrict__ t,
                                                              float* __restrict__ Y, int M, int N_, int NB_, int ldy_, int frames_from_) {
   const int N = PROJ ? PJ_NP : N_, NB = PROJ ? PJ_NB : NB_, ldy = PROJ ? PJ_NP : ldy_, frames_from = PROJ ? PJ_GQ / PJ_B : frames_from_;
+  const int blk0 = SPLIT ? (NB * static_cast<int>(blockIdx.y)) / static_cast<int>(gridDim.y) : 0;
+  const int blk1 = SPLIT ? (NB * static_cast<int>(blockIdx.y + 1)) / static_cast<int>(gridDim.y) : NB;
   extern __shared__ __attribute__((aligned(16))) __bf16 pj_lds[];  // [2][3][96][PJ_LD] weights, then [128][12] frames (fp32)
   float* Rt = reinterpret_cast<float*>(pj_lds + 2 * PJ_STAGE_LDS);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     st_dst[i] = (pl * PJ_B + (rem >> 3)) * PJ_LD + (rem & 7) * 8;
   }
   f32x4 wreg[5];
-  const int NSTAGE = 2 * NB;
+  const int NSTAGE = 2 * blk1;
   auto load_w = [&](int stg) {
     stg = stg < NSTAGE ? stg : NSTAGE - 1;
     const __bf16* src = Wc + static_cast<size_t>(stg) * PJ_STAGE_ELEMS;
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 5; ++i) *reinterpret_cast<f32x4*>(pj_lds + buf * PJ_STAGE_LDS + st_dst[i]) = wreg[i];
   };
-  load_w(0);
+  load_w(2 * blk0);
   // A fragments (v_mfma_f32_16x16x32_bf16: lane = row l15, k group g): a[mt][q][plane] = split(x[m0 + 32 rw + 16 mt + l15][32 q + 8 g .. + 7])
   bf16x8 a[2][4][3];
 #pragma unroll
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     }
   MEM_FENCE();
   store_w(0);
-  load_w(1);
+  load_w(2 * blk0 + 1);
   MEM_FENCE();
   __syncthreads();
 
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt)
               cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2 * kh + ks][TA[term]], b[tt][TB[term]], cur[mt][tt], 0, 0, 0);
-          if (kh == 0 && blk > 0 && term >= 1 && term <= 4) {
+          if (kh == 0 && blk > blk0 && term >= 1 && term <= 4) {
             epilogue_piece(prev, blk - 1, 4 * ks + term - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -668,12 +672,19 @@ __global__ __launch_bounds__(512) void proj_frames_b6_kernel(const float* __rest
     }
   };
   f32x4 accA[2][3], accB[2][3];
-  for (int blk = 0; blk < NB; blk += 2) {  // NB is even (launcher)
+  int blk = blk0;
+  for (; blk + 1 < blk1; blk += 2) {
     run_block(accA, accB, blk);
     run_block(accB, accA, blk + 1);
   }
+  if (SPLIT && blk < blk1) {  // odd share (the 14 projection blocks over two groups: 7 each)
+    run_block(accA, accB, blk);
 #pragma unroll
-  for (int piece = 0; piece < 8; ++piece) epilogue_piece(accB, NB - 1, piece);
+    for (int piece = 0; piece < 8; ++piece) epilogue_piece(accA, blk, piece);
+  } else {
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) epilogue_piece(accB, blk1 - 1, piece);
+  }
 }
 
 size_t proj_frames_b6_scratch_bytes() { return static_cast<size_t>(2 * PJ_NB) * PJ_STAGE_ELEMS * sizeof(__bf16); }
@@ -695,20 +706,26 @@ static int launch_xstat(const float* x, const void* planes, const float* R, cons
   const __bf16* Wc = static_cast<const __bf16*>(planes);
   const dim3 grid((rows + PJ_ROWS - 1) / PJ_ROWS);
   const bool proj_geom = N == PJ_NP && NB == PJ_NB && ldy == PJ_NP && frames_from == PJ_GQ / PJ_B;
-#define XSTAT_LAUNCH(FULL_, PROJ_)                                                                                                       \
+  const int ntiles = (rows + PJ_ROWS - 1) / PJ_ROWS;
+  const bool split = ntiles <= 128;  // half the chip or less: two groups per row tile
+  const dim3 grid2(ntiles, split ? 2 : 1);
+#define XSTAT_LAUNCH(FULL_, PROJ_, SPLIT_)                                                                                               \
   do {                                                                                                                                   \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<FULL_, PROJ_>),                              \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<FULL_, PROJ_, SPLIT_>),                      \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, PJ_LDS_BYTES));                                      \
-    hipLaunchKernelGGL((proj_frames_b6_kernel<FULL_, PROJ_>), grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, Y, rows, N, NB, ldy,         \
-                       frames_from);                                                                                                     \
+    hipLaunchKernelGGL((proj_frames_b6_kernel<FULL_, PROJ_, SPLIT_>), grid2, dim3(512), PJ_LDS_BYTES, st, x, Wc, R, t, Y, rows, N, NB,    \
+                       ldy, frames_from);                                                                                                \
   } while (0)
-  if (rows % PJ_ROWS == 0) {
-    if (proj_geom) XSTAT_LAUNCH(true, true);
-    else XSTAT_LAUNCH(true, false);
-  } else {
-    if (proj_geom) XSTAT_LAUNCH(false, true);
-    else XSTAT_LAUNCH(false, false);
-  }
+#define XSTAT_PICK(FULL_)                                     \
+  do {                                                        \
+    if (proj_geom && split) XSTAT_LAUNCH(FULL_, true, true);  \
+    else if (proj_geom) XSTAT_LAUNCH(FULL_, true, false);     \
+    else if (split) XSTAT_LAUNCH(FULL_, false, true);         \
+    else XSTAT_LAUNCH(FULL_, false, false);                   \
+  } while (0)
+  if (rows % PJ_ROWS == 0) XSTAT_PICK(true);
+  else XSTAT_PICK(false);
+#undef XSTAT_PICK
 #undef XSTAT_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
