@@ -130,7 +130,7 @@ def context_state_dict(d_res: int, d_pair: int, n_atoms: int = 15, max_dist: int
     return {k: torch.from_numpy(v.astype(np.float32)) for k, v in sd.items()}
 
 
-def context_batch(B: int, K: int, n_atoms: int = 15, seed: int = 0) -> Dict[str, torch.Tensor]:
+def context_batch(B: int, K: int, n_atoms: int = 15, seed: int = 0, with_distmat: bool = True) -> Dict[str, torch.Tensor]:
     """Synthetic inputs of DiffAb.encode_context (reference batch dict): atoms scattered around each
     residue's CA, real pairwise atom distances, random angles, chains 1..3, a contiguous generated segment per patch."""
     out = {k: [] for k in ("seq_idx", "xyz", "orientations", "backbone_dihedrals", "distmat", "pairwise_dihedrals", "atom_mask",
@@ -143,7 +143,8 @@ def context_batch(B: int, K: int, n_atoms: int = 15, seed: int = 0) -> Dict[str,
         am = (rng.random((K, n_atoms)) < 0.8)
         am[:, :4] = True
         am[K - 1, 1] = False  # one residue without CA: exercises the residue-pair mask
-        d = np.linalg.norm(xyz[:, None, :, None, :] - xyz[None, :, None, :, :], axis=-1)
+        # (the 14.7 MB / patch distance tensor takes ~0.1 s per patch on the host: skipped when the caller takes distances from xyz)
+        d = np.linalg.norm(xyz[:, None, :, None, :] - xyz[None, :, None, :, :], axis=-1) if with_distmat else np.zeros((1,), np.float32)
         out["seq_idx"].append(rng.integers(0, 20, size=K, dtype=np.int64))
         out["xyz"].append(xyz.astype(np.float32))
         out["orientations"].append(random_rotations(rng, K).astype(np.float32))

@@ -150,7 +150,7 @@ class PatchSource:
             if self.args.patch_dir:
                 yield collate([load_patch(self.files[i], self.args.cdr_mask_key) for i in mine])
             else:
-                parts = [self._syn.context_batch(1, self.args.k, seed=self.args.seed + self.offset + i) for i in mine]
+                parts = [self._syn.context_batch(1, self.args.k, seed=self.args.seed + self.offset + i, with_distmat=False) for i in mine]
                 for p_ in parts:
                     p_.pop("distmat")  # as in the reference's batches (data.py:93-94): distances are taken from xyz on the device
                 yield collate(parts)
