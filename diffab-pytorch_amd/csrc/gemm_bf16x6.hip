@@ -707,8 +707,11 @@ static int launch_xstat(const float* x, const void* planes, const float* R, cons
   const dim3 grid((rows + PJ_ROWS - 1) / PJ_ROWS);
   const bool proj_geom = N == PJ_NP && NB == PJ_NB && ldy == PJ_NP && frames_from == PJ_GQ / PJ_B;
   const int ntiles = (rows + PJ_ROWS - 1) / PJ_ROWS;
-  const bool split = ntiles <= 128;  // half the chip or less: two groups per row tile
-  const dim3 grid2(ntiles, split ? 2 : 1);
+  // half the chip or less: several groups per row tile, each with its share of the column blocks (B = 1: one block per group)
+  int nsplit = 256 / ntiles;
+  nsplit = nsplit < 1 ? 1 : (nsplit > NB ? NB : nsplit);
+  const bool split = nsplit > 1;
+  const dim3 grid2(ntiles, nsplit);
 #define XSTAT_LAUNCH(FULL_, PROJ_, SPLIT_)                                                                                               \
   do {                                                                                                                                   \
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_b6_kernel<FULL_, PROJ_, SPLIT_>),                      \
