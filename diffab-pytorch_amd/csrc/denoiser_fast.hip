@@ -658,9 +658,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #define DIFFAB_E_DEPTH0 3  // tiles of the first row in flight before its bias loop starts; the rest follow one per consumed tile (all 8 at once:
                            // 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it builds delays every other CU's loads)
 #endif
-      // PLANES: RT = pair tiles of the wave's 2 NT-tile stream held in registers (requested RT tiles ahead of their use): a whole row
-      // in the single-chunk kernel, half a row in the chunked one (whose chunk loop leaves 64 registers less)
-      constexpr int RT = MULTI ? NT / 2 : NT;
+      // PLANES: RT = pair tiles of the wave's 2 NT-tile stream held in registers (requested RT tiles ahead of their use): half a row.
+      // (A whole row spills in the chunked kernel, and in the single-chunk one its 24 loads per wave in front of the barrier take
+      // 4.6 k cycles to issue on the waves that finish phase 1 last: 0.326 ms against 0.321 with half a row.)
+      constexpr int RT = NT / 2;
       constexpr int E_DEPTH0 = PLANES ? RT : (DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT);
       if constexpr (!PLANES) {
 #pragma unroll
