@@ -36,6 +36,28 @@ __global__ __launch_bounds__(512) void rows_kernel(const f32x4* __restrict__ p, 
   if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
 }
 
+// the same pattern from a limited number of CUs: gridDim.x work-groups (one per CU) walk all 2048 tiles - what can ONE CU pull when
+// only some of the CUs stream at a time (the attention kernel: ~40 % of the CUs are in their streaming phase at any moment)?
+template <int DEPTH>
+__global__ __launch_bounds__(512) void rows_some_cus_kernel(const f32x4* __restrict__ p, float* out, int ntiles) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x4 acc = {0, 0, 0, 0};
+  for (size_t tile = blockIdx.x; tile < (size_t)ntiles; tile += gridDim.x)
+    for (int ii = 0; ii < 2; ++ii) {
+      const f32x4* row = p + (tile * 16 + 2 * wv + ii) * (32768 / 16) + lane;
+      f32x4 buf[DEPTH];
+#pragma unroll
+      for (int c0 = 0; c0 < 32; c0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) buf[d] = __builtin_nontemporal_load(row + (c0 + d) * 64);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) acc += buf[d];
+      }
+    }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
+}
+
 template <typename F>
 float time_ms(F f, int iters = 20) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -68,5 +90,10 @@ int main() {
   hipFuncSetAttribute((const void*)rows_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
   float t2 = time_ms([&] { hipLaunchKernelGGL((rows_kernel<32, true>), dim3(2048), dim3(512), lds2, 0, p, out, 0); });
   printf("rows pattern depth 32 nt=1, 2 WG/CU       : %.3f ms  %.0f GB/s\n", t2, bytes / t2 / 1e6);
+  for (int ncu : {16, 32, 64, 102, 128, 192, 256}) {
+    hipFuncSetAttribute((const void*)rows_some_cus_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float t = time_ms([&] { hipLaunchKernelGGL((rows_some_cus_kernel<16>), dim3(ncu), dim3(512), lds, 0, p, out, 2048); }, 5);
+    printf("rows pattern depth 16, %3d CUs streaming   : %.3f ms  %.0f GB/s total  %.1f GB/s per CU\n", ncu, t, bytes / t / 1e6, bytes / t / 1e6 / ncu);
+  }
   return 0;
 }
