@@ -312,6 +312,27 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
   return launch_rowgemm128_b6(X, Kd, W, Kd, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, scratch, st);
 }
 
+size_t diffab_debug_proj_planes_scratch_bytes(const diffab_dims* d) {
+  if (check_dims(d, "debug_proj_planes_scratch_bytes")) return 0;
+  return align_up(proj_planes_scratch_bytes(), 256) + align_up(static_cast<size_t>(d->B) * 16, 256);
+}
+
+int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* R, const float* t,
+                             float* qk_out, float* proj_out, void* scratch, size_t scratch_bytes, void* stream) {
+  if (int rc = check_dims(d, "debug_proj_planes")) return rc;
+  DIFFAB_REQUIRE(fast_path_supported(d), DIFFAB_ERR_UNSUPPORTED, "debug_proj_planes: benchmark geometry only");
+  DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && x && R && t && qk_out && proj_out && scratch,
+                 DIFFAB_ERR_ARG, "debug_proj_planes: null pointer");
+  DIFFAB_REQUIRE(scratch_bytes >= diffab_debug_proj_planes_scratch_bytes(d), DIFFAB_ERR_WORKSPACE, "debug_proj_planes: scratch too small");
+  hipStream_t st = as_stream(stream);
+  char* planes = static_cast<char*>(scratch);
+  float* cent = reinterpret_cast<float*>(planes + align_up(proj_planes_scratch_bytes(), 256));
+  const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
+  if (int rc = launch_ppsplit(W6, planes, st)) return rc;
+  if (int rc = launch_patch_centroids(t, d->B, d->K, cent, st)) return rc;
+  return launch_proj_planes_b6(x, planes, R, t, cent, w->gamma, qk_out, proj_out, d->B * d->K, d->K, st);
+}
+
 int diffab_debug_set_attn_stamps(void* device_buffer) {
   set_attn_stamps(device_buffer);
   return DIFFAB_OK;

@@ -387,15 +387,23 @@ constexpr int TI = 16;  // query residues per work-group
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
-template <int NT, bool MULTI, bool EXT_S = false, bool PLANES = false>
+// B6L (with PLANES): phase 1 does not read the fp32 projection buffer; the scalar AND point-distance logits of a (head, key tile) are
+// ONE 64-slot dot product of operand planes written by proj_planes_b6_kernel (proj_planes.hip: three bf16 planes per slot in the
+// fragment order of v_mfma_f32_16x16x32_bf16, six partial products, fp32 accumulation) plus 8 coef |t_i - t_j|^2 from a 16 x KC
+// table of direct differences that the work-group builds once per chunk: 12 MFMAs of 16 cycles and ~10 VALU instructions per key
+// tile against 8 f32 MFMAs of 32 cycles and 96 packed VALU instructions, no LDS staging, linear 1 KiB operand loads.
+// qkp = query-side operands (f32x4 units), key side kside_off further.
+template <int NT, bool MULTI, bool EXT_S = false, bool PLANES = false, bool B6L = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps,
-                                                            const float* __restrict__ Sg = nullptr, const float* __restrict__ esc = nullptr) {
+                                                            const float* __restrict__ Sg = nullptr, const float* __restrict__ esc = nullptr,
+                                                            const f32x4* __restrict__ qkp = nullptr, int64_t kside_off = 0) {
   static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
+  static_assert(!B6L || (PLANES && !EXT_S), "operand-plane logits: PLANES form only");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
   // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
@@ -517,6 +525,70 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       for (int k_ = 0; k_ < TI * AH * F4 / 512; ++k_) {
         const int idx = tid + 512 * k_, rh = idx / F4, c4 = idx % F4, il = rh / AH, hh = rh % AH;
         *reinterpret_cast<f32x4*>(S + il * IS + hh * HS + 4 * c4) = sreg[k_];
+      }
+    } else if constexpr (B6L) {
+      const int h = wv;
+      const float coef8 = -0.5f * 0.16666666666666666f * gamma[h] * 8.0f;  // 8 coef: the |t_i - t_j|^2 term of all eight points
+      // ---- |t_i - t_j|^2 of the 16 rows x KC keys, direct differences: wave w < NT takes key tile w; D2[key][row], stride 20
+      constexpr int D2LD = 20;
+      float* d2t = S + TI * IS;  // in the per-wave scratch area, which phase 1 does not otherwise use in this form
+      f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+      if (wv < NT) {
+        const float* tj = t + (krow0 + 16 * wv + l15) * 3;
+        const float tjx = tj[0], tjy = tj[1], tjz = tj[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* ti = t + (prow0 + i0 + 4 * q + r) * 3;
+          const float dx = ti[0] - tjx, dy = ti[1] - tjy, dz = ti[2] - tjz;
+          dd[r] = (dx * dx + dy * dy) + dz * dz;
+        }
+      }
+      // ---- operand planes: A = query side (rows i0 .. i0 + 15), B = key side (16 keys per tile); [k-step][plane], 1 KiB each
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      const f32x4* qsrc = qkp + ((static_cast<int64_t>(b) * AH + h) * ntile + tile) * (6 * 64) + lane;
+      const f32x4* ksrc = qkp + kside_off + ((static_cast<int64_t>(b) * AH + h) * ntile + c * NT) * (6 * 64) + lane;
+      constexpr int SD = 3;  // key tiles in flight
+      static_assert(E_EARLY <= SD, "the early pair tiles are requested in the last E_EARLY iterations, which must not request key tiles any more");
+      f32x4 qa[6], kb[SD][6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) qa[u] = qsrc[u * 64];
+#pragma unroll
+      for (int jt = 0; jt < SD && jt < NT; ++jt)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) kb[jt][u] = ksrc[(jt * 6 + u) * 64];
+      MEM_FENCE();
+      if (wv < NT) *reinterpret_cast<f32x4*>(d2t + (16 * wv + l15) * D2LD + 4 * q) = dd;
+      __syncthreads();  // the distance table is complete
+      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[3 * ks + TA[term]]),
+                                                          __builtin_bit_cast(bf16x8_t, kb[jt % SD][3 * ks + TB[term]]), acc, 0, 0, 0);
+        if (jt + SD < NT) {
+#pragma unroll
+          for (int u = 0; u < 6; ++u) kb[jt % SD][u] = ksrc[((jt + SD) * 6 + u) * 64];
+        } else if (jt + E_EARLY >= NT) {
+          if (jt + E_EARLY == NT) {
+            const int hh = lane & 7, qq = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + hh * AC + 32 * ks + 8 * qq + 4 * hf);
+          }
+          load_e_tile(0, c, jt + E_EARLY - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
+        }
+        MEM_FENCE();
+        const f32x4 d2v = *reinterpret_cast<const f32x4*>(d2t + (16 * jt + l15) * D2LD + 4 * q);
+        // acc[r] = ds^-1/2 q_s.k_s + coef (sum_p |gq_p - gk_p|^2 - 8 |t_i - t_j|^2) [- row terms], row i0 + 4 q + r, key 16 jt + l15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] + coef8 * d2v[r]);
+        if (c == 0 && jt == 0) stamp(6);
+        if (c == 0 && jt == 3) stamp(7);
       }
     } else {
       const int h = wv;
@@ -1398,24 +1470,47 @@ bool use_b6_gemm() {
   }();
   return v;
 }
+// DIFFAB_LOGITS_F32=1: keep phase 1 of the planes attention kernel on the fp32 projection buffer (A/B timing against the operand-plane form)
+static bool operand_planes_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("DIFFAB_LOGITS_F32");
+    return e == nullptr || atoi(e) == 0;
+  }();
+  return v;
+}
 static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
-size_t ipa_layer_planes_bytes() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
+size_t ipa_layer_planes_bytes() {
+  return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)) + round256(proj_planes_scratch_bytes());
+}
+static size_t pp_planes_offset() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st) {
   DIFFAB_REQUIRE(w && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && w->w_out, DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
   if (int rc = launch_pjsplit(W6, planes, st)) return rc;
+  if (int rc = launch_ppsplit(W6, static_cast<char*>(planes) + pp_planes_offset(), st)) return rc;  // operand-plane projections (proj_planes.hip)
   return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + round256(proj_frames_b6_scratch_bytes()), st);
 }
 static size_t b6_scratch_floats() { return (ipa_layer_planes_bytes() + 256) / sizeof(float); }
 
+// workspace of one layer: proj | feat | 128 | three-launch attention's logits (K = 64 / 128) | per-call weight planes | operand planes
+// of the logits product (proj_planes.hip) | patch centroids
+static size_t ipa_ws_operands_offset(const diffab_dims* d) {
+  const size_t rows = static_cast<size_t>(d->B) * d->K;
+  const size_t o = rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0) + b6_scratch_floats();
+  return (o + 63) & ~static_cast<size_t>(63);
+}
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
-  return rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0) + b6_scratch_floats();
+  return ipa_ws_operands_offset(d) + 64 + proj_planes_operand_floats(rows) + 4 * static_cast<size_t>(d->B) + 64;
+}
+float* ipa_fast_centroid_slot(const diffab_dims* d, float* ws) {
+  const size_t rows = static_cast<size_t>(d->B) * d->K;
+  return ws + ipa_ws_operands_offset(d) + 64 + proj_planes_operand_floats(rows);
 }
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep, const void* planes,
-                   const float* pair_planes) {
+                   const float* pair_planes, const float* cent) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1449,7 +1544,21 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   DIFFAB_LAUNCH_CHECK();
 #else
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
-  if (b6) {
+  // Operand-plane form (pair planes given, default attention mode, bf16x6 GEMMs): the projection kernel writes the query / key sides
+  // as MFMA operands of the attention kernel's logits product (proj_planes.hip) and only the value side into `proj`.
+  const bool b6l = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr && operand_planes_enabled();
+  float* qk_ops = nullptr;
+  if (b6l) {
+    float* base = ws + ipa_ws_operands_offset(d);
+    qk_ops = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(base) + 255) & ~static_cast<uintptr_t>(255));
+    if (cent == nullptr) {
+      float* own = ipa_fast_centroid_slot(d, ws);
+      if (int rc = launch_patch_centroids(t, d->B, d->K, own, st)) return rc;
+      cent = own;
+    }
+    if (int rc = launch_proj_planes_b6(x, static_cast<const char*>(planes) + pp_planes_offset(), R, t, cent, w->gamma, qk_ops, proj, rows, d->K, st))
+      return rc;
+  } else if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {
     const size_t pj_lds = (2 * PJB * PJLD + PJROWS * 12) * sizeof(float);
@@ -1518,6 +1627,22 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                        w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_planes + 1);                                     \
     timer_end(st);                                                                                                                    \
   } while (0)
+#define ATTN_LAUNCH_B6L(NT_, MULTI_)                                                                                                  \
+  do {                                                                                                                                \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, false, true, true>),         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
+    timer_begin(st);                                                                                                                  \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, false, true, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R,   \
+                       t, w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_planes + 1,                                   \
+                       reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
+    timer_end(st);                                                                                                                    \
+  } while (0)
+  if (b6l) {
+    if (nt == 8 && nc == 1) ATTN_LAUNCH_B6L(8, false);
+    else if (nt == 8) ATTN_LAUNCH_B6L(8, true);
+    else if (nc == 1) ATTN_LAUNCH_B6L(4, false);
+    else ATTN_LAUNCH_B6L(4, true);
+  } else
   // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores; single key chunk, attention default mode only
   if (pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d)) {
     if (nt == 8 && nc == 1) ATTN_LAUNCH_PLANES(8, false);
@@ -1533,6 +1658,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
 #undef ATTN_LAUNCH_X
 #undef ATTN_LAUNCH
 #undef ATTN_LAUNCH_PLANES
+#undef ATTN_LAUNCH_B6L
   DIFFAB_LAUNCH_CHECK();
   return to_out();
 }

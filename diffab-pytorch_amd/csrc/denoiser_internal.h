@@ -21,7 +21,16 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                    float* y, float* ws, hipStream_t st, int attn_mode = 0,  // 0 fused | 1 three launches | 2 logits launch + fused rest
                    float* sp_keep = nullptr, float* d2_keep = nullptr,  // training tape: three launches, P and d2 kept in these buffers
                    const void* planes = nullptr,  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
-                   const float* pair_planes = nullptr);  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
+                   const float* pair_planes = nullptr,  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
+                   const float* cent = nullptr);  // launch_patch_centroids() output for t (operand-plane form; nullptr: computed here)
+float* ipa_fast_centroid_slot(const diffab_dims* d, float* ws);  // where a caller may park the centroids of a step (B x 4 floats)
+// proj_planes.hip: the projections as MFMA operands of the attention kernel's logits product
+size_t proj_planes_scratch_bytes();
+size_t proj_planes_operand_floats(int64_t rows);
+int launch_ppsplit(const float* const* W6, void* planes, hipStream_t st);
+int launch_patch_centroids(const float* t, int B, int K, float* cent, hipStream_t st);
+int launch_proj_planes_b6(const float* x, const void* planes, const float* R, const float* t, const float* cent, const float* gamma,
+                          void* qk, float* proj, int rows, int K, hipStream_t st);
 // fp16 planes of the pair embedding for the fused attention kernel (K = 64 / 128): pair_planes_floats(d) floats, 256-byte aligned
 bool pair_planes_supported(const diffab_dims* d);
 size_t pair_planes_floats(const diffab_dims* d);

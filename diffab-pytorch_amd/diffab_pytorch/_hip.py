@@ -89,6 +89,8 @@ SYMBOLS = {
     "diffab_debug_set_attn_stamps": (C.c_int, [_fp]),
     "diffab_debug_linear128": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp]),
     "diffab_kernel_timer_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "diffab_debug_proj_planes_scratch_bytes": (_sz, [_PD]),
+    "diffab_debug_proj_planes": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "diffab_so3_log": (C.c_int, [_fp, _fp, _i64, _fp]),
     "diffab_so3_exp": (C.c_int, [_fp, _fp, _i64, _fp]),
     "diffab_so3_matrix_to_rotvec": (C.c_int, [_fp, _fp, _i64, _fp]),

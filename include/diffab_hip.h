@@ -155,6 +155,15 @@ int diffab_debug_set_attn_stamps(void* device_buffer);
 int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
                            size_t scratch_bytes, void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
+/* Diagnostics / accuracy tests: the projection kernel of the operand-plane attention path alone (csrc/proj_planes.hip;
+ * InvariantPointAttentionLayer.forward, diffab_pytorch.py:391-413 + the frame transform :324): from x (B K x 128), the frames
+ * (R, t) and one layer's weights it writes qk_out = the query / key operand planes of the logits product (B K x 1536 floats:
+ * three bf16 planes of 64 slots per residue and head, layout in the header of that file) and the v_s / global value-point
+ * columns of proj_out (B K x 1344 floats, the other columns untouched).  Benchmark geometry only (D=128, H=8, DS=32, P=8).
+ * diffab_debug_proj_planes_scratch_bytes() bytes of scratch, 256-byte aligned. */
+size_t diffab_debug_proj_planes_scratch_bytes(const diffab_dims* d);
+int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* R, const float* t,
+                             float* qk_out, float* proj_out, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- SO(3) maps, n matrices/vectors each --------------------------------- */
 /* so3.py:146-162  log R = theta/(2 sin theta) (R - R^T); NaN at theta = 0 like the reference */
