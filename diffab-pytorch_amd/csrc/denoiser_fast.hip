@@ -497,6 +497,9 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     f32x4 wv4[2][2];  // PLANES: the bias weights of lane (head, channel group), requested in phase 1's tail AHEAD of the first pair tiles:
                       // vmcnt retires in order, so loaded behind them they would cost every wave a pair-tile latency in front of the barrier
     auto load_e_tile = [&](int ii, int cc_, int jt) {
+#ifdef AT_ABL_NOE  // timing ablation (wrong results): only the first pair tile is ever loaded
+      if (ii > 0 || jt > 0) return;
+#endif
       if constexpr (PLANES) {  // four 1 KiB blocks per key tile, lane order: ev[ii][jt][2 p + ks] = fragment (plane p, k-step ks)
         const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii]) + (cc_ * NT + jt) * 256 + lane;
 #pragma unroll
@@ -558,7 +561,14 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int u = 0; u < 6; ++u) kb[jt][u] = ksrc[(jt * 6 + u) * 64];
       MEM_FENCE();
       if (wv < NT) *reinterpret_cast<f32x4*>(d2t + (16 * wv + l15) * D2LD + 4 * q) = dd;
+#ifdef AT_DIAG_P1  // diagnostic stamps: 6 = every initial load of this wave has landed, 7 = the distance-table barrier is behind it
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (c == 0) stamp(6);
+#endif
       __syncthreads();  // the distance table is complete
+#ifdef AT_DIAG_P1
+      if (c == 0) stamp(7);
+#endif
       constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
@@ -569,7 +579,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           for (int term = 0; term < 6; ++term)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[3 * ks + TA[term]]),
                                                           __builtin_bit_cast(bf16x8_t, kb[jt % SD][3 * ks + TB[term]]), acc, 0, 0, 0);
+#ifdef AT_ABL_NOK  // timing ablation (wrong results): the key tiles after the first three are not loaded
+        if (false) {
+#else
         if (jt + SD < NT) {
+#endif
 #pragma unroll
           for (int u = 0; u < 6; ++u) kb[jt % SD][u] = ksrc[((jt + SD) * 6 + u) * 64];
         } else if (jt + E_EARLY >= NT) {
@@ -587,8 +601,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         // acc[r] = ds^-1/2 q_s.k_s + coef (sum_p |gq_p - gk_p|^2 - 8 |t_i - t_j|^2) [- row terms], row i0 + 4 q + r, key 16 jt + l15
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] + coef8 * d2v[r]);
+#ifndef AT_DIAG_P1
         if (c == 0 && jt == 0) stamp(6);
         if (c == 0 && jt == 3) stamp(7);
+#endif
       }
     } else {
       const int h = wv;
@@ -1085,7 +1101,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int stp = jt * 4 + r;
+#ifdef AT_ABL_NOV  // timing ablation (wrong results): the value side after the first 16 key steps is not loaded
+          if (false) {
+#else
           if (stp + PFV < NS) {
+#endif
             load_vals(stp + PFV);
             MEM_FENCE();
           }
@@ -1142,7 +1162,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
-void set_attn_stamps(void* p) { g_attn_stamps = static_cast<unsigned long long*>(p); }
+void set_attn_stamps(void* p) {
+  g_attn_stamps = static_cast<unsigned long long*>(p);
+  set_attn_b6p_stamps(p);
+}
 
 // in-place local -> global for the three point blocks of the projection buffer (row-vector convention, :324)
 __global__ void points_to_global_fast_kernel(float* __restrict__ proj, const float* __restrict__ R, const float* __restrict__ t, int rows) {
@@ -1470,14 +1493,17 @@ bool use_b6_gemm() {
   }();
   return v;
 }
-// DIFFAB_LOGITS_F32=1: keep phase 1 of the planes attention kernel on the fp32 projection buffer (A/B timing against the operand-plane form)
-static bool operand_planes_enabled() {
-  static const bool v = [] {
-    const char* e = getenv("DIFFAB_LOGITS_F32");
-    return e == nullptr || atoi(e) == 0;
+// DIFFAB_OPERAND_PLANES: 1 = phase 1 of the planes attention kernel from the operand planes of proj_planes.hip (logits on the bf16 matrix
+// cores), 0 = from the fp32 projection buffer; unset = the measured default per shape (operand_planes_default)
+static int operand_planes_env() {
+  static const int v = [] {
+    const char* e = getenv("DIFFAB_OPERAND_PLANES");
+    return e == nullptr ? -1 : (atoi(e) != 0 ? 1 : 0);
   }();
   return v;
 }
+static bool operand_planes_default(const diffab_dims*) { return false; }  // measured (profiles/r03_operand_planes.md): not faster at K = 128 / 256
+static bool operand_planes_enabled(const diffab_dims* d) { return operand_planes_env() < 0 ? operand_planes_default(d) : operand_planes_env() == 1; }
 static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 size_t ipa_layer_planes_bytes() {
   return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)) + round256(proj_planes_scratch_bytes());
@@ -1546,7 +1572,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
   // Operand-plane form (pair planes given, default attention mode, bf16x6 GEMMs): the projection kernel writes the query / key sides
   // as MFMA operands of the attention kernel's logits product (proj_planes.hip) and only the value side into `proj`.
-  const bool b6l = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr && operand_planes_enabled();
+  const bool b6l = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr && operand_planes_enabled(d);
   float* qk_ops = nullptr;
   if (b6l) {
     float* base = ws + ipa_ws_operands_offset(d);
@@ -1637,6 +1663,15 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                        reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
     timer_end(st);                                                                                                                    \
   } while (0)
+  // DIFFAB_ATTN_ONE_TILE=1: one work-group per 16-row tile also at K = 64 / 128 (A/B timing against the persistent kernel)
+  static const bool env_one_tile = [] {
+    const char* v = getenv("DIFFAB_ATTN_ONE_TILE");
+    return v != nullptr && atoi(v) != 0;
+  }();
+  if (b6l && attention_b6p_supported(d) && !env_one_tile) {
+    if (int rc = launch_attention_b6p(d, proj, pair_planes, R, t, w->w_bias, w->gamma, feat, qk_ops, st)) return rc;
+    return to_out();
+  }
   if (b6l) {
     if (nt == 8 && nc == 1) ATTN_LAUNCH_B6L(8, false);
     else if (nt == 8) ATTN_LAUNCH_B6L(8, true);

@@ -99,6 +99,12 @@ int launch_attention_flash(const diffab_dims* d, const float* proj, const float*
                            const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st,
                            const float* pair_planes = nullptr);  // launch_pair_split() output: 16-wave form, producers on f16 MFMA
 
+// attention_b6.hip: the operand-plane attention kernel with persistent work-groups (K = 64 / 128)
+bool attention_b6p_supported(const diffab_dims* d);
+int launch_attention_b6p(const diffab_dims* d, const float* proj, const float* pair_planes, const float* R, const float* t, const float* Wb,
+                         const float* gamma, float* feat, const float* qk_ops, hipStream_t st);
+void set_attn_b6p_stamps(void* device_buffer);
+
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
 // api.hip: opt-in hipEvent bracket around the dominant (attention) kernel

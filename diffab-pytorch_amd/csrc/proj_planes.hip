@@ -47,11 +47,17 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int PP_NB = 16, PP_QKB = 11;       // 96-row weight blocks: [0, 11) query/key slot tiles (swapped operands), [11, 16) value side
 constexpr int PP_B = 96, PP_ROWS = 128;
-constexpr int PP_LD = 80;                    // bf16 per staged row: 64 k + 16 pad (160 bytes)
-constexpr int PP_STAGE_ELEMS = 3 * PP_B * 64;
-constexpr int PP_STAGE_LDS = 3 * PP_B * PP_LD;
+constexpr int PP_STAGE_ELEMS = 3 * PP_B * 64;  // bf16 per stage = (block, k half): 3 planes x 96 rows x 64 k = 36 x 1 KiB, the same image
+                                               // in global memory and in LDS (copied by LDS-DMA, no registers)
+constexpr int PP_STAGE_BYTES = PP_STAGE_ELEMS * 2;
+constexpr int PP_PIECES = PP_STAGE_BYTES / 1024;  // 36 wave-sized DMA pieces
 constexpr int PP_RT = 16;                    // floats per row of the frame table: R (9), t (3), t - centroid (3), pad
-constexpr int PP_LDS_BYTES = 2 * PP_STAGE_LDS * 2 + PP_ROWS * PP_RT * 4;
+constexpr int PP_XF = 2 * 4 * 64 * 8;         // bf16 per (row wave, plane) of the x fragments parked in LDS: [mt][q][lane][8]
+constexpr int PP_LDS_BYTES = 2 * PP_STAGE_BYTES + PP_ROWS * PP_RT * 4 + 4 * 2 * PP_XF * 2;
+// Rows are 128 bytes, unpadded (an LDS-DMA instruction writes 1 KiB contiguously: 8 whole rows); the 16-byte chunk c of row r sits
+// at position c ^ ((r >> 1) & 7), applied by ppsplit_kernel when it writes the planes: the 16-row ds_read_b128 fragment reads
+// (four 16-lane groups, each 16 rows at one or two chunk indices) then touch 16 different bank quads - conflict-free.
+__host__ __device__ inline int pp_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 constexpr int PP_NP = 1344, PP_VS = 512, PP_GV = 1152;  // column map of the fp32 projection buffer (denoiser_fast.hip: ANP, OFF_VS, OFF_GV)
 constexpr int PP_VPAD0 = 256, PP_VPAD1 = 288;           // virtual value columns: [0, 256) v_s | [256, 288) padding | [288, 480) value points
 struct __attribute__((packed, aligned(4))) pp_f3 { float x, y, z; };
@@ -96,7 +102,7 @@ __host__ __device__ inline PPSrc pp_source(int L) {
 }
 }  // namespace
 
-// stage-ordered split weights: out[((blk * 2 + kh) * 3 + plane) * 96 + l][kk], l = row of the block, k = 64 kh + kk
+// stage-ordered split weights: out[((blk * 2 + kh) * 3 + plane) * 96 + l][8 swz(l, kk / 8) + kk % 8], l = row of the block, k = 64 kh + kk
 __global__ void ppsplit_kernel(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
                                const float* __restrict__ W3, const float* __restrict__ W4, const float* __restrict__ W5,
                                __bf16* __restrict__ out) {
@@ -112,7 +118,7 @@ __global__ void ppsplit_kernel(const float* __restrict__ W0, const float* __rest
   __bf16 h, m, l;
   split3(v, h, m, l);
   const int blk = L / PP_B, lrow = L % PP_B, kh = k >> 6, kk = k & 63;
-  const size_t base = (static_cast<size_t>(blk * 2 + kh) * 3 * PP_B + lrow) * 64 + kk;
+  const size_t base = (static_cast<size_t>(blk * 2 + kh) * 3 * PP_B + lrow) * 64 + 8 * pp_swz(lrow, kk >> 3) + (kk & 7);
   out[base] = h;
   out[base + PP_B * 64] = m;
   out[base + 2 * PP_B * 64] = l;
@@ -147,35 +153,41 @@ __global__ __launch_bounds__(512) void proj_planes_b6_kernel(const float* __rest
                                                              int K) {
   const int blk0 = (PP_NB * static_cast<int>(blockIdx.y)) / static_cast<int>(gridDim.y);
   const int blk1 = (PP_NB * static_cast<int>(blockIdx.y + 1)) / static_cast<int>(gridDim.y);  // both even (gridDim.y in {1, 2, 4, 8})
-  extern __shared__ __attribute__((aligned(16))) __bf16 pp_lds[];  // [2][3][96][PP_LD] weights, then [128][16] frames (fp32)
-  float* Rt = reinterpret_cast<float*>(pp_lds + 2 * PP_STAGE_LDS);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) __bf16 pp_lds[];  // [2][3][96][64] weights, then [128][16] frames (fp32)
+  float* Rt = reinterpret_cast<float*>(pp_lds + 2 * PP_STAGE_ELEMS);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4, rw = wv & 3, cw = wv >> 2;
   const int m0 = blockIdx.x * PP_ROWS;
 
-  int st_src[5], st_dst[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int idx = i < 4 ? tid + 512 * i : 2048 + (tid & 255);
-    const int pl = idx / 768, rem = idx % 768;
-    st_src[i] = idx * 8;
-    st_dst[i] = (pl * PP_B + (rem >> 3)) * PP_LD + (rem & 7) * 8;
-  }
-  f32x4 wreg[5];
+  // Weight staging by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, straight into LDS): wave w copies pieces
+  // w, w + 8, .. of a stage.  The instruction is written in assembly: hipcc then neither waits for it nor drains it at a barrier,
+  // and its completion is counted by hand (s_waitcnt vmcnt(N) in front of the barrier that publishes the stage, N = the global
+  // stores this wave has issued behind it - vmcnt retires in order).  No staging registers, no ds_write pass.
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(pp_lds)));
   const int NSTAGE = 2 * blk1;
-  auto load_w = [&](int stg) {
+  auto dma_stage = [&](int stg, int buf) {
     stg = stg < NSTAGE ? stg : NSTAGE - 1;
-    const __bf16* src = Wc + static_cast<size_t>(stg) * PP_STAGE_ELEMS;
+    const char* src = reinterpret_cast<const char*>(Wc) + static_cast<size_t>(stg) * PP_STAGE_BYTES + lane * 16;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) wreg[i] = *reinterpret_cast<const f32x4*>(src + st_src[i]);
+    for (int i = 0; i < 5; ++i) {
+      const int pc = wv + 8 * i;
+      if (pc < PP_PIECES) {
+        const char* gsrc = src + pc * 1024;
+        const unsigned dst = lds0 + buf * PP_STAGE_BYTES + pc * 1024;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(dst)
+                     : "memory");
+      }
+    }
   };
-  auto store_w = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) *reinterpret_cast<f32x4*>(pp_lds + buf * PP_STAGE_LDS + st_dst[i]) = wreg[i];
-  };
-  load_w(2 * blk0);
-  // x fragments: a[mt][q][plane] = split(x[m0 + 32 rw + 16 mt + l15][32 q + 8 g .. + 7])
-  bf16x8 a[2][4][3];
+  dma_stage(2 * blk0, 0);
+  // x fragments: split(x[m0 + 32 rw + 16 mt + l15][32 q + 8 g .. + 7]); the hi plane stays in registers (a[mt][q]), the mid and lo
+  // planes are parked in LDS in fragment order (one copy per row wave, written by its cw = 0 wave; lane-linear 16-byte accesses)
+  // and re-read per k-step: 48 VGPRs that the operand epilogues need
+  __bf16* xf = reinterpret_cast<__bf16*>(Rt + PP_ROWS * PP_RT) + rw * (2 * PP_XF);  // [plane mid, lo][mt][q][lane][8]
+  bf16x8 a[2][4];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = m0 + 32 * rw + 16 * mt + l15;
@@ -187,11 +199,16 @@ __global__ __launch_bounds__(512) void proj_planes_b6_kernel(const float* __rest
         v0 = *reinterpret_cast<const f32x4*>(xp);
         v1 = *reinterpret_cast<const f32x4*>(xp + 4);
       }
+      bf16x8 am, al;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         __bf16 hh, mm, ll;
         split3(c < 4 ? v0[c & 3] : v1[c & 3], hh, mm, ll);
-        a[mt][q][0][c] = hh; a[mt][q][1][c] = mm; a[mt][q][2][c] = ll;
+        a[mt][q][c] = hh; am[c] = mm; al[c] = ll;
+      }
+      if (cw == 0) {
+        *reinterpret_cast<bf16x8*>(xf + ((mt * 4 + q) * 64 + lane) * 8) = am;
+        *reinterpret_cast<bf16x8*>(xf + PP_XF + ((mt * 4 + q) * 64 + lane) * 8) = al;
       }
     }
   }
@@ -205,10 +222,7 @@ __global__ __launch_bounds__(512) void proj_planes_b6_kernel(const float* __rest
     }
     Rt[idx] = v;
   }
-  MEM_FENCE();
-  store_w(0);
-  load_w(2 * blk0 + 1);
-  MEM_FENCE();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage 0 has landed (and the x loads above)
   __syncthreads();
 
   constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
@@ -341,36 +355,56 @@ __global__ __launch_bounds__(512) void proj_planes_b6_kernel(const float* __rest
       for (int tt = 0; tt < 3; ++tt) cur[mt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      store_w(kh ^ 1);
-      load_w(2 * blk + kh + 2);
-      MEM_FENCE();
-      const __bf16* wl = pp_lds + kh * PP_STAGE_LDS + (48 * cw + l15) * PP_LD + 8 * g;
+      // stage 2 blk + kh is in buffer kh; the next one goes to buffer kh ^ 1 (read during the previous stage, barrier since) - requested
+      // before this stage issues any global store
+      dma_stage(2 * blk + kh + 1, kh ^ 1);
+      const __bf16* wl = pp_lds + kh * PP_STAGE_ELEMS + (48 * cw + l15) * 64;
+      const int fz = l15 >> 1;  // = ((48 cw + 16 tt + l15) >> 1) & 7: the row's chunk swizzle
       // six (k-step, column tile) groups of 12 MFMAs; the weight fragments of the next group are read while this one runs
       bf16x8 bw[2][3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bw[0][pl] = *reinterpret_cast<const bf16x8*>(wl + (pl * PP_B) * PP_LD);
+      for (int pl = 0; pl < 3; ++pl) bw[0][pl] = *reinterpret_cast<const bf16x8*>(wl + (pl * PP_B) * 64 + 8 * (g ^ fz));
+      bf16x8 ax[2][3];  // the x fragments of this k-step: [mt][plane]
 #pragma unroll
       for (int grp = 0; grp < 6; ++grp) {
         const int ks = grp / 3, tt = grp % 3;
+        if (tt == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            ax[mt][0] = a[mt][2 * kh + ks];
+            ax[mt][1] = *reinterpret_cast<const bf16x8*>(xf + ((mt * 4 + 2 * kh + ks) * 64 + lane) * 8);
+            ax[mt][2] = *reinterpret_cast<const bf16x8*>(xf + PP_XF + ((mt * 4 + 2 * kh + ks) * 64 + lane) * 8);
+          }
+        }
         if (grp + 1 < 6) {
           const int ks1 = (grp + 1) / 3, tt1 = (grp + 1) % 3;
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            bw[(grp + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(wl + (pl * PP_B + 16 * tt1) * PP_LD + 32 * ks1);
+            bw[(grp + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(wl + (pl * PP_B + 16 * tt1) * 64 + 8 * ((4 * ks1 + g) ^ fz));
         }
 #pragma unroll
         for (int term = 0; term < 6; ++term)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
             if (SWAPPED)  // D[weight row 4 g + r][residue l15]: four consecutive slots of one residue per lane
-              cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[grp & 1][TB[term]], a[mt][2 * kh + ks][TA[term]], cur[mt][tt], 0, 0, 0);
+              cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[grp & 1][TB[term]], ax[mt][TA[term]], cur[mt][tt], 0, 0, 0);
             else          // D[residue 4 g + r][column l15]
-              cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2 * kh + ks][TA[term]], bw[grp & 1][TB[term]], cur[mt][tt], 0, 0, 0);
+              cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[mt][TA[term]], bw[grp & 1][TB[term]], cur[mt][tt], 0, 0, 0);
           }
         if (kh == 0 && blk > blk0 && (grp == 0 || grp == 1 || grp == 3 || grp == 4)) {
           epilogue_part(prev, blk - 1, grp < 3 ? grp : grp - 1);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      // the next stage's DMA pieces of this wave have landed once at most the stores issued behind them are outstanding (a lower
+      // bound of their number is safe: it only waits longer): 12 per slot block (6 for block 10), >= 8 per value block
+      if (kh == 0 && FULL && blk > blk0) {
+        const int pb = blk - 1;
+        if (pb < 10) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (pb == 10) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
     }

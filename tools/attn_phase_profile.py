@@ -61,3 +61,7 @@ for wvi in range(8):
     print(f"    wave {wvi}: phase 1 mean {(s[:, wvi, 1] - s[:, wvi, 0]).mean():.0f}")
 span = s[..., 5].max() - s[..., 0].min()
 print(f"  kernel span (first stamp to last stamp): {span:.0f} cycles; 100 MHz-based? memtime ticks are shader cycles")
+d06 = (s[..., 6] - s[..., 0])
+if (s[..., 6] > 0).all():
+    print(f"  stamp 0 -> 6: first 256 work-groups mean {d06[:256].mean():.0f}, the rest mean {d06[256:].mean():.0f}; "
+          f"percentiles 10/50/90 of all: {d06.flatten().quantile(torch.tensor([0.1, 0.5, 0.9], dtype=torch.float64)).tolist()}")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: rocprofv3 --kernel-trace --stats of a short bench run; prints the top kernels.  usage: tools/kstats.sh TAG [bench args...]
 R=$GRAFT_REPO_ROOT; tag=$1; shift
-O=$R/gpurun_out/r2; mkdir -p $O
+O=$R/gpurun_out/r3; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_$tag
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -o run -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs "$@" > $O/ks_$tag.log 2>&1 || { tail -5 $O/ks_$tag.log; exit 1; }
 cp /tmp/ks_$tag/run_kernel_stats.csv $O/kernel_stats_$tag.csv

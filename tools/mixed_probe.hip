@@ -1,0 +1,107 @@
+// Microbenchmark: does a CU's L2-hit traffic share its throughput limit with its HBM stream?
+// One 512-thread work-group per CU (forced by a large LDS request).  Per wave and iteration: NH loads of 1 KiB from a 1 GiB HBM-resident
+// stream (non-temporal, each byte once) and NL loads of 1 KiB from a small table (2 MiB, re-read by every CU: L2-resident after the
+// first pass).  Reports the time of the HBM-only, L2-only and mixed loops; if mixed ~ max(HBM, L2) the two paths are parallel, if
+// mixed ~ HBM + L2 they share one window.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NH, int NL>
+__global__ __launch_bounds__(512) void mixed(const f32x4* __restrict__ hbm, const f32x4* __restrict__ tab, float* out, int iters) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x4 acc = {0, 0, 0, 0};
+  // per CU: iters * 8 waves * NH KiB of the stream, contiguous per wave
+  const f32x4* hp = hbm + (static_cast<size_t>(blockIdx.x) * 8 + wv) * static_cast<size_t>(iters) * NH * 64 + lane;
+  const f32x4* tp = tab + lane;
+  for (int it = 0; it < iters; ++it) {
+    f32x4 hb[NH > 0 ? NH : 1], lb[NL > 0 ? NL : 1];
+#pragma unroll
+    for (int d = 0; d < NH; ++d) hb[d] = __builtin_nontemporal_load(hp + (static_cast<size_t>(it) * NH + d) * 64);
+#pragma unroll
+    for (int d = 0; d < NL; ++d) lb[d] = tp[(((it * NL + d) * 8 + wv) * 37 % 2048) * 64];  // 2048 KiB-blocks = 2 MiB table
+#pragma unroll
+    for (int d = 0; d < NH; ++d) acc += hb[d];
+#pragma unroll
+    for (int d = 0; d < NL; ++d) acc += lb[d];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
+}
+
+// the two streams on DIFFERENT waves of the work-group (no in-order coupling inside a wave): waves < WH stream HBM (16 KiB per
+// iteration), the other waves read the table (16 KiB per iteration); MODE 1 = HBM waves only, 2 = table waves only, 3 = both
+template <int WH, int MODE>
+__global__ __launch_bounds__(512) void split(const f32x4* __restrict__ hbm, const f32x4* __restrict__ tab, float* out, int iters) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x4 acc = {0, 0, 0, 0};
+  if (wv < WH) {
+    if (MODE & 1) {
+      const f32x4* hp = hbm + (static_cast<size_t>(blockIdx.x) * 8 + wv) * static_cast<size_t>(iters) * 16 * 64 + lane;
+      for (int it = 0; it < iters; ++it) {
+        f32x4 hb[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) hb[d] = __builtin_nontemporal_load(hp + (static_cast<size_t>(it) * 16 + d) * 64);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc += hb[d];
+      }
+    }
+  } else if (MODE & 2) {
+    const f32x4* tp = tab + lane;
+    for (int it = 0; it < 4 * iters; ++it) {  // the table waves run 4x the iterations (they are ~4x faster per iteration)
+      f32x4 lb[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) lb[d] = tp[(((it * 16 + d) * 8 + wv) * 37 % 2048) * 64];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) acc += lb[d];
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
+}
+
+template <typename F>
+float time_ms(F f, int reps = 10) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) f();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / reps;
+}
+
+int main() {
+  const size_t bytes = 1ull << 30;
+  f32x4 *hbm, *tab; float* out;
+  hipMalloc(&hbm, bytes + (64 << 20)); hipMalloc(&tab, 2 << 20); hipMalloc(&out, 64);
+  hipMemset(hbm, 1, bytes); hipMemset(tab, 1, 2 << 20);
+  const int lds = 140 * 1024;
+#define RUN(NH, NL, NCU)                                                                                               \
+  do {                                                                                                                 \
+    const int iters = 16;  /* per wave: 16 x NH KiB of stream, 16 x NL KiB of table */                                 \
+    hipFuncSetAttribute((const void*)mixed<NH, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+    float t = time_ms([&] { hipLaunchKernelGGL((mixed<NH, NL>), dim3(NCU), dim3(512), lds, 0, hbm, tab, out, iters); }); \
+    const double hb = double(NCU) * 8 * iters * NH * 1024, lb = double(NCU) * 8 * iters * NL * 1024;                   \
+    printf("NH=%2d NL=%2d CUs=%3d: %.4f ms  stream %.0f GB/s (%.1f per CU)  table %.0f GB/s (%.1f per CU)\n", NH, NL, NCU, t, \
+           hb / t / 1e6, hb / t / 1e6 / NCU, lb / t / 1e6, lb / t / 1e6 / NCU);                                        \
+  } while (0)
+  for (int ncu : {64, 128, 256}) {
+    if (ncu == 64) { RUN(16, 0, 64); RUN(0, 16, 64); RUN(16, 16, 64); RUN(8, 8, 64); RUN(16, 8, 64); }
+    if (ncu == 128) { RUN(16, 0, 128); RUN(0, 16, 128); RUN(16, 16, 128); RUN(8, 8, 128); RUN(16, 8, 128); }
+    if (ncu == 256) { RUN(16, 0, 256); RUN(0, 16, 256); RUN(16, 16, 256); RUN(8, 8, 256); RUN(16, 8, 256); }
+  }
+#define RUNS(WH, MODE, NCU)                                                                                            \
+  do {                                                                                                                 \
+    const int iters = 16;                                                                                              \
+    hipFuncSetAttribute((const void*)split<WH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                \
+    float t = time_ms([&] { hipLaunchKernelGGL((split<WH, MODE>), dim3(NCU), dim3(512), lds, 0, hbm, tab, out, iters); }); \
+    const double hb = (MODE & 1) ? double(NCU) * WH * iters * 16 * 1024 : 0, lb = (MODE & 2) ? double(NCU) * (8 - WH) * 4 * iters * 16 * 1024 : 0; \
+    printf("split WH=%d mode=%d CUs=%3d: %.4f ms  stream %.0f GB/s (%.1f per CU)  table %.0f GB/s (%.1f per CU)\n", WH, MODE, NCU, t, \
+           hb / t / 1e6, hb / t / 1e6 / NCU, lb / t / 1e6, lb / t / 1e6 / NCU);                                        \
+  } while (0)
+  RUNS(4, 1, 128); RUNS(4, 2, 128); RUNS(4, 3, 128);
+  RUNS(4, 1, 256); RUNS(4, 2, 256); RUNS(4, 3, 256);
+  RUNS(6, 1, 128); RUNS(6, 2, 128); RUNS(6, 3, 128);
+  return 0;
+}
