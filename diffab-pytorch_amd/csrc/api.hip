@@ -446,6 +446,88 @@ int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w
                         res_mask, upstream3, d_res_ctx, d_pair_ctx, static_cast<float*>(workspace), as_stream(stream));
 }
 
+/* ---- Denoiser.forward / InvariantPointAttentionLayer.forward under autograd: taped forward + backward from arbitrary cotangents ---- */
+int diffab_denoise_step_fwd_taped(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
+                                  const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps,
+                                  float* out_O0, float* out_posterior, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
+  if (int rc = check_dims(d, "denoise_step_fwd_taped")) return rc;
+  if (int rc = check_denoiser_weights(d, w)) return rc;
+  DIFFAB_REQUIRE(d->NL <= kMaxLayers, DIFFAB_ERR_UNSUPPORTED, "denoise_step_fwd_taped: at most %d IPA layers", kMaxLayers);
+  DIFFAB_REQUIRE(seq_t && x_t && O_t && res_ctx && pair_ctx && beta && out_eps && out_O0 && out_posterior && tape, DIFFAB_ERR_ARG,
+                 "denoise_step_fwd_taped: null pointer");
+  DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "denoise_step_fwd_taped: tape %zu < %zu bytes",
+                 tape_bytes, train_tape_floats(d) * sizeof(float));
+  const TrainTape tp = carve_tape(d, static_cast<float*>(tape));
+  return denoise_step_taped(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, tp, flags, as_stream(stream));
+}
+
+int diffab_denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
+                            const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_posterior,
+                            const float* d_eps, const float* d_O0, const float* d_posterior, float* d_res_ctx, float* d_pair_ctx,
+                            const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_dims(d, "denoise_step_bwd")) return rc;
+  if (int rc = check_denoiser_weights(d, w)) return rc;
+  if (int rc = check_denoiser_weights(d, grads)) return rc;
+  DIFFAB_REQUIRE(d->NL <= kMaxLayers, DIFFAB_ERR_UNSUPPORTED, "denoise_step_bwd: at most %d IPA layers", kMaxLayers);
+  DIFFAB_REQUIRE(seq_t && x_t && O_t && pair_ctx && out_posterior && d_res_ctx && tape && workspace, DIFFAB_ERR_ARG,
+                 "denoise_step_bwd: null pointer");
+  DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "denoise_step_bwd: tape too small");
+  DIFFAB_REQUIRE(workspace_bytes >= train_bwd_workspace_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "denoise_step_bwd: workspace %zu < %zu",
+                 workspace_bytes, train_bwd_workspace_floats(d) * sizeof(float));
+  const TrainTape tp = carve_tape(d, static_cast<float*>(const_cast<void*>(tape)));
+  return denoise_step_bwd(d, w, grads, tp, seq_t, x_t, O_t, pair_ctx, out_posterior, d_eps, d_O0, d_posterior, d_res_ctx, d_pair_ctx,
+                          static_cast<float*>(workspace), as_stream(stream));
+}
+
+static diffab_dims one_layer(const diffab_dims* d) {
+  diffab_dims d1 = *d;
+  d1.NL = 1;
+  return d1;
+}
+size_t diffab_ipa_layer_tape_bytes(const diffab_dims* d) {
+  if (check_dims(d, "ipa_layer_tape_bytes")) return 0;
+  const diffab_dims d1 = one_layer(d);
+  return train_tape_floats(&d1) * sizeof(float);
+}
+size_t diffab_ipa_layer_bwd_workspace_bytes(const diffab_dims* d) {
+  if (check_dims(d, "ipa_layer_bwd_workspace_bytes")) return 0;
+  const diffab_dims d1 = one_layer(d);
+  return train_bwd_workspace_floats(&d1) * sizeof(float);
+}
+
+int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
+                               const float* t, float* y, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
+  if (int rc = check_dims(d, "ipa_layer_fwd_taped")) return rc;
+  DIFFAB_REQUIRE(x && e && R && t && y && tape, DIFFAB_ERR_ARG, "ipa_layer_fwd_taped: null pointer");
+  const diffab_dims d1 = one_layer(d);
+  DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(&d1) * sizeof(float), DIFFAB_ERR_WORKSPACE, "ipa_layer_fwd_taped: tape %zu < %zu bytes", tape_bytes,
+                 train_tape_floats(&d1) * sizeof(float));
+  const TrainTape tp = carve_tape(&d1, static_cast<float*>(tape));
+  hipStream_t st = as_stream(stream);
+  const size_t nb = sizeof(float) * static_cast<size_t>(d->B) * d->K * d->D;
+  DIFFAB_HIP_CHECK(hipMemcpyAsync(tp.x[0], x, nb, hipMemcpyDeviceToDevice, st));
+  const bool b6 = tp.planes && use_b6_gemm() && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(&d1);
+  if (b6)
+    if (int rc = ipa_layer_split_weights(w, tp.planes, st)) return rc;
+  if (int rc = ipa_layer_dispatch(&d1, w, tp.x[0], e, R, t, tp.x[1], tp.ipa_ws[0], flags, st, tp.sp[0], tp.d2[0], b6 ? tp.planes : nullptr))
+    return rc;
+  DIFFAB_HIP_CHECK(hipMemcpyAsync(y, tp.x[1], nb, hipMemcpyDeviceToDevice, st));
+  return DIFFAB_OK;
+}
+
+int diffab_ipa_layer_bwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const diffab_ipa_layer_weights* grads, const float* e,
+                         const float* R, const float* t, const float* dy, float* dx, float* d_e, const void* tape, size_t tape_bytes,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_dims(d, "ipa_layer_bwd")) return rc;
+  DIFFAB_REQUIRE(w && grads && e && R && t && dy && dx && tape && workspace, DIFFAB_ERR_ARG, "ipa_layer_bwd: null pointer");
+  const diffab_dims d1 = one_layer(d);
+  DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(&d1) * sizeof(float), DIFFAB_ERR_WORKSPACE, "ipa_layer_bwd: tape too small");
+  DIFFAB_REQUIRE(workspace_bytes >= train_bwd_workspace_floats(&d1) * sizeof(float), DIFFAB_ERR_WORKSPACE, "ipa_layer_bwd: workspace %zu < %zu",
+                 workspace_bytes, train_bwd_workspace_floats(&d1) * sizeof(float));
+  const TrainTape tp = carve_tape(&d1, static_cast<float*>(const_cast<void*>(tape)));
+  return ipa_layer_bwd(&d1, w, grads, tp, R, t, e, dy, dx, d_e, static_cast<float*>(workspace), as_stream(stream));
+}
+
 int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_sched* s, const diffab_igso3* rev_tab,
                        int64_t* seq, float* x, float* O, const float* res_ctx, const float* pair_ctx, const uint8_t* gen_mask, uint64_t seed,
                        int64_t first_patch, int32_t t_start, int32_t t_stop, void* workspace, size_t workspace_bytes, uint32_t flags,

@@ -323,6 +323,50 @@ __global__ void count_mask_kernel(const uint8_t* __restrict__ gm, const uint8_t*
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// d L / d v from G0 = d L / d O0 for O0 = O_t E, E = exp(hat(v)) = I + a S + b S^2 (diffab_pytorch.py:594-596, so3.py:219-237)
+__device__ __forceinline__ void rotvec_head_bwd(const float (&G0)[9], const float* __restrict__ Ot, const float* __restrict__ v3,
+                                                float* __restrict__ dv3) {
+  // G = dL/dE = O_t^T G0
+  float G[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) s += Ot[r * 3 + a] * G0[r * 3 + b];
+      G[a * 3 + b] = s;
+    }
+  // S = hat(v), n = |v|, a = sin n / n, b = (1 - cos n) / n^2
+  const float vx = v3[0], vy = v3[1], vz = v3[2];
+  const float n = sqrtf(vx * vx + vy * vy + vz * vz);
+  float sn, cn;
+  sincosf(n, &sn, &cn);
+  const float a = sn / n, b = (1.0f - cn) / (n * n);
+  const float da = (cn - a) / n, db = (a - 2.0f * b) / n;  // derivatives with respect to n
+  float S[9], S2[9];
+  so3_hat(vx, vy, vz, S);
+  mat3_mul(S, S, S2);
+  float gS = 0.f, gS2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { gS += G[k] * S[k]; gS2 += G[k] * S2[k]; }
+  // <G, dS S + S dS> = <G S^T + S^T G, dS>;   dS = hat(dv)
+  float H[9], ST[9], T1[9], T2[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ST[r * 3 + c] = S[c * 3 + r];
+  mat3_mul(G, ST, T1);
+  mat3_mul(ST, G, T2);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) H[k] = a * G[k] + b * (T1[k] + T2[k]);
+  const float vv[3] = {vx, vy, vz};
+  // <H, hat(e_x)> = H21 - H12, <H, hat(e_y)> = H02 - H20, <H, hat(e_z)> = H10 - H01
+  const float hk[3] = {H[7] - H[5], H[2] - H[6], H[3] - H[1]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dv3[k] = hk[k] + (da * gS + db * gS2) * vv[k] / n;
+}
+
 __global__ void losses_bwd_kernel(const float* __restrict__ post, const float* __restrict__ tpost, const float* __restrict__ eps,
                                   const float* __restrict__ teps, const float* __restrict__ O0, const float* __restrict__ tO,
                                   const float* __restrict__ O_t, const float* __restrict__ v, const uint8_t* __restrict__ gm,
@@ -366,45 +410,31 @@ __global__ void losses_bwd_kernel(const float* __restrict__ post, const float* _
       for (int k = 0; k < 3; ++k) s += 2.0f * D[j * 3 + k] * tO[i * 9 + r * 3 + k];
       G0[r * 3 + j] = g_o * invN * s;
     }
-  // O0 = O_t E  ->  G = dL/dE = O_t^T G0        (:596)
-  float G[9];
+  rotvec_head_bwd(G0, O_t + i * 9, v + i * 3, d_v + i * 3);
+}
+
+// Denoiser outputs -> head pre-activations for ARBITRARY upstream cotangents (diffab_denoise_step_bwd): d eps-hat passes through,
+// d posterior goes through the softmax of sequence_denoising (:555, :599), d O0-hat through O0 = O_t exp(hat(v)) (:594-596).
+// Null cotangent pointers stand for zeros.
+__global__ void heads_cotangent_kernel(const float* __restrict__ post, const float* __restrict__ c_post, const float* __restrict__ c_eps,
+                                       const float* __restrict__ c_O0, const float* __restrict__ O_t, const float* __restrict__ v, int V,
+                                       int64_t rows, float* __restrict__ d_logits, float* __restrict__ d_eps, float* __restrict__ d_v) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= rows) return;
+  float dot = 0.f;
+  if (c_post)
+    for (int c = 0; c < V; ++c) dot += post[i * V + c] * c_post[i * V + c];
+  for (int c = 0; c < V; ++c) d_logits[i * V + c] = c_post ? post[i * V + c] * (c_post[i * V + c] - dot) : 0.0f;
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int c = 0; c < 3; ++c) d_eps[i * 3 + c] = c_eps ? c_eps[i * 3 + c] : 0.0f;
+  if (c_O0 == nullptr) {
+    d_v[i * 3] = d_v[i * 3 + 1] = d_v[i * 3 + 2] = 0.0f;
+    return;
+  }
+  float G0[9];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float s = 0.f;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) s += O_t[i * 9 + r * 3 + a] * G0[r * 3 + b];
-      G[a * 3 + b] = s;
-    }
-  // E = I + a S + b S^2, S = hat(v), n = |v|, a = sin n / n, b = (1 - cos n) / n^2      (so3.py:219-237)
-  const float vx = v[i * 3], vy = v[i * 3 + 1], vz = v[i * 3 + 2];
-  const float n = sqrtf(vx * vx + vy * vy + vz * vz);
-  float sn, cn;
-  sincosf(n, &sn, &cn);
-  const float a = sn / n, b = (1.0f - cn) / (n * n);
-  const float da = (cn - a) / n, db = (a - 2.0f * b) / n;  // derivatives with respect to n
-  float S[9], S2[9];
-  so3_hat(vx, vy, vz, S);
-  mat3_mul(S, S, S2);
-  float gS = 0.f, gS2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { gS += G[k] * S[k]; gS2 += G[k] * S2[k]; }
-  // <G, dS S + S dS> = <G S^T + S^T G, dS>;   dS = hat(dv)
-  float H[9], ST[9], T1[9], T2[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) ST[r * 3 + c] = S[c * 3 + r];
-  mat3_mul(G, ST, T1);
-  mat3_mul(ST, G, T2);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) H[k] = a * G[k] + b * (T1[k] + T2[k]);
-  const float vv[3] = {vx, vy, vz};
-  // <H, hat(e_x)> = H21 - H12, <H, hat(e_y)> = H02 - H20, <H, hat(e_z)> = H10 - H01
-  const float hk[3] = {H[7] - H[5], H[2] - H[6], H[3] - H[1]};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) d_v[i * 3 + k] = hk[k] + (da * gS + db * gS2) * vv[k] / n;
+  for (int k = 0; k < 9; ++k) G0[k] = c_O0[i * 9 + k];
+  rotvec_head_bwd(G0, O_t + i * 9, v + i * 3, d_v + i * 3);
 }
 
 // ------------------------------------------------------------------ attention backward in two atomic-free passes
@@ -1326,11 +1356,18 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
          bwd_planes_floats(d);
 }
 
-int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
-                   const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* eps_hat,
-                   const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
-                   const uint8_t* gm, const uint8_t* rm, const float* upstream3, float* d_res_ctx, float* d_pair_ctx, float* ws,
-                   hipStream_t st) {
+// One backward driver, three roots:
+//   BWD_LOSSES      the three masked losses of diffab_pytorch.py:856-880 with upstream gradients upstream3 (the training step)
+//   BWD_COTANGENTS  arbitrary cotangents of the Denoiser outputs (cot_eps, cot_O0, cot_post; null = zero): Denoiser.forward under autograd
+//   BWD_LAYER       one IPA layer from d y (layer_dy) to d x (layer_dx): InvariantPointAttentionLayer.forward under autograd; `w` / `g`
+//                   then carry only layers[0] and `tp` is a one-layer tape
+enum { BWD_LOSSES = 0, BWD_COTANGENTS = 1, BWD_LAYER = 2 };
+static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
+                        const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* eps_hat,
+                        const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
+                        const uint8_t* gm, const uint8_t* rm, const float* upstream3, const float* cot_eps, const float* cot_O0,
+                        const float* cot_post, const float* layer_dy, float* layer_dx, float* d_res_ctx, float* d_pair_ctx, float* ws,
+                        hipStream_t st) {
   const int rows = d->B * d->K, D = d->D, H = d->H, DS = d->DS, PQ = d->PQ, PV = d->PV, C = d->C, V = d->V;
   const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
   const int F = H * DS + H * C + H * PV * 3 + H * PV;
@@ -1361,17 +1398,27 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
   if (bwd_planes_floats(d) > 0 && use_b6_gemm())
     planes = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(take(bwd_planes_floats(d))) + 255) & ~static_cast<uintptr_t>(255));
 
-  hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
-  DIFFAB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(losses_bwd_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, true_post, eps_hat, true_eps, O0_hat, true_O0,
-                     O_t, tp.vbuf, gm, rm, cnt, upstream3, V, static_cast<int64_t>(rows), d_logits, d_eps, d_v);
-  DIFFAB_LAUNCH_CHECK();
+  float* dcur = dxa;
+  float* dnxt = dxb;
+  if (mode == BWD_LOSSES) {
+    hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
+    DIFFAB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(losses_bwd_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, true_post, eps_hat, true_eps, O0_hat,
+                       true_O0, O_t, tp.vbuf, gm, rm, cnt, upstream3, V, static_cast<int64_t>(rows), d_logits, d_eps, d_v);
+    DIFFAB_LAUNCH_CHECK();
+  } else if (mode == BWD_COTANGENTS) {
+    hipLaunchKernelGGL(heads_cotangent_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, cot_post, cot_eps, cot_O0, O_t, tp.vbuf, V,
+                       static_cast<int64_t>(rows), d_logits, d_eps, d_v);
+    DIFFAB_LAUNCH_CHECK();
+  } else {
+    DIFFAB_HIP_CHECK(hipMemcpyAsync(dcur, layer_dy, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
+  }
   // ---- heads (Linear-ReLU-Linear-ReLU-Linear), gradients into cat3 accumulate over the three heads
   const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
   const diffab_mlp3_weights* hg[3] = {&g->coord, &g->orient, &g->seq};
   const float* dy[3] = {d_eps, d_v, d_logits};
   const int nout[3] = {3, 3, V};
-  for (int hd = 0; hd < 3; ++hd) {
+  for (int hd = 0; hd < 3 && mode != BWD_LAYER; ++hd) {
     if (int rc = linear_bwd(dy[hd], nout[hd], tp.t2[hd], D, hw[hd]->w4, const_cast<float*>(hg[hd]->w4), const_cast<float*>(hg[hd]->b4), dt2,
                             D, rows, nout[hd], D, false, st)) return rc;
     if (int rc = relu_mask(dt2, tp.t2[hd], static_cast<int64_t>(rows) * D, st)) return rc;
@@ -1382,10 +1429,9 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
                             D + 3, rows, D, D + 3, hd > 0, st)) return rc;
   }
   // dh = dcat3[:, :D] (leading dimension D+3)
-  float* dcur = dxa;
-  float* dnxt = dxb;
-  DIFFAB_HIP_CHECK(hipMemcpy2DAsync(dcur, sizeof(float) * D, dcat3, sizeof(float) * (D + 3), sizeof(float) * D, rows,
-                                    hipMemcpyDeviceToDevice, st));
+  if (mode != BWD_LAYER)
+    DIFFAB_HIP_CHECK(hipMemcpy2DAsync(dcur, sizeof(float) * D, dcat3, sizeof(float) * (D + 3), sizeof(float) * D, rows,
+                                      hipMemcpyDeviceToDevice, st));
   // ---- IPA layers, last to first
   for (int l = d->NL - 1; l >= 0; --l) {
     const diffab_ipa_layer_weights* lw = &w->layers[l];
@@ -1519,6 +1565,10 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
     }
     float* tmp = dcur; dcur = dnxt; dnxt = tmp;
   }
+  if (mode == BWD_LAYER) {
+    DIFFAB_HIP_CHECK(hipMemcpyAsync(layer_dx, dcur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
+    return DIFFAB_OK;
+  }
   // ---- to_res_emb (Linear-ReLU-Linear) and the sequence embedding
   if (int rc = linear_bwd(dcur, D, tp.h1, D, w->res_w2, const_cast<float*>(g->res_w2), const_cast<float*>(g->res_b2), dnxt, D, rows, D, D,
                           false, st)) return rc;
@@ -1529,6 +1579,35 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
                      const_cast<float*>(g->seq_emb));
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
+}
+
+int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
+                   const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* eps_hat,
+                   const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
+                   const uint8_t* gm, const uint8_t* rm, const float* upstream3, float* d_res_ctx, float* d_pair_ctx, float* ws,
+                   hipStream_t st) {
+  return run_backward(BWD_LOSSES, d, w, g, tp, seq_t, x_t, O_t, pair_ctx, eps_hat, O0_hat, post_hat, true_post, true_eps, true_O0, gm, rm,
+                      upstream3, nullptr, nullptr, nullptr, nullptr, nullptr, d_res_ctx, d_pair_ctx, ws, st);
+}
+
+// Denoiser.forward backward from arbitrary cotangents of (eps-hat, O0-hat, posterior); null cotangents are zeros
+int denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
+                     const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* post_hat,
+                     const float* cot_eps, const float* cot_O0, const float* cot_post, float* d_res_ctx, float* d_pair_ctx, float* ws,
+                     hipStream_t st) {
+  return run_backward(BWD_COTANGENTS, d, w, g, tp, seq_t, x_t, O_t, pair_ctx, nullptr, nullptr, post_hat, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, cot_eps, cot_O0, cot_post, nullptr, nullptr, d_res_ctx, d_pair_ctx, ws, st);
+}
+
+// One IPA layer backward: tp is the one-layer tape of the taped layer forward (x[0] = the layer input), dy -> dx, d pair_ctx += ..
+int ipa_layer_bwd(const diffab_dims* d1, const diffab_ipa_layer_weights* lw, const diffab_ipa_layer_weights* lg, const TrainTape& tp,
+                  const float* R, const float* t, const float* pair_ctx, const float* dy, float* dx, float* d_pair_ctx, float* ws,
+                  hipStream_t st) {
+  diffab_denoiser_weights w{}, g{};
+  w.layers = lw;
+  g.layers = lg;
+  return run_backward(BWD_LAYER, d1, &w, &g, tp, nullptr, t, R, pair_ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, dy, dx, nullptr, d_pair_ctx, ws, st);
 }
 
 }  // namespace diffab

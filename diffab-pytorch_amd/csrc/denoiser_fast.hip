@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);
-  set_attn_b6p_stamps(p);
+  set_attn_pipe_stamps(p);
 }
 
 // in-place local -> global for the three point blocks of the projection buffer (row-vector convention, :324)
@@ -1572,7 +1572,14 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
   // Operand-plane form (pair planes given, default attention mode, bf16x6 GEMMs): the projection kernel writes the query / key sides
   // as MFMA operands of the attention kernel's logits product (proj_planes.hip) and only the value side into `proj`.
-  const bool b6l = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr && operand_planes_enabled(d);
+  // DIFFAB_ATTN_PIPE=1: K = 64 / 128 through the sixteen-wave key-tile pipeline on the operand planes (attention_pipe.hip)
+  static const bool env_pipe = [] {
+    const char* v = getenv("DIFFAB_ATTN_PIPE");
+    return v != nullptr && atoi(v) != 0;
+  }();
+  const bool planes_ok = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr;
+  const bool pipe = planes_ok && env_pipe && attention_pipe_supported(d);
+  const bool b6l = planes_ok && (pipe || operand_planes_enabled(d));
   float* qk_ops = nullptr;
   if (b6l) {
     float* base = ws + ipa_ws_operands_offset(d);
@@ -1663,13 +1670,8 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                        reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
     timer_end(st);                                                                                                                    \
   } while (0)
-  // DIFFAB_ATTN_ONE_TILE=1: one work-group per 16-row tile also at K = 64 / 128 (A/B timing against the persistent kernel)
-  static const bool env_one_tile = [] {
-    const char* v = getenv("DIFFAB_ATTN_ONE_TILE");
-    return v != nullptr && atoi(v) != 0;
-  }();
-  if (b6l && attention_b6p_supported(d) && !env_one_tile) {
-    if (int rc = launch_attention_b6p(d, proj, pair_planes, R, t, w->w_bias, w->gamma, feat, qk_ops, st)) return rc;
+  if (b6l && pipe) {
+    if (int rc = launch_attention_pipe(d, proj, pair_planes, R, t, w->w_bias, w->gamma, feat, qk_ops, st)) return rc;
     return to_out();
   }
   if (b6l) {

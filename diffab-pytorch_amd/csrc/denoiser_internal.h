@@ -99,11 +99,11 @@ int launch_attention_flash(const diffab_dims* d, const float* proj, const float*
                            const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st,
                            const float* pair_planes = nullptr);  // launch_pair_split() output: 16-wave form, producers on f16 MFMA
 
-// attention_b6.hip: the operand-plane attention kernel with persistent work-groups (K = 64 / 128)
-bool attention_b6p_supported(const diffab_dims* d);
-int launch_attention_b6p(const diffab_dims* d, const float* proj, const float* pair_planes, const float* R, const float* t, const float* Wb,
-                         const float* gamma, float* feat, const float* qk_ops, hipStream_t st);
-void set_attn_b6p_stamps(void* device_buffer);
+// attention_pipe.hip: sixteen-wave key-tile pipeline on the operand planes (K = 64 / 128)
+bool attention_pipe_supported(const diffab_dims* d);
+int launch_attention_pipe(const diffab_dims* d, const float* proj, const float* pair_planes, const float* R, const float* t, const float* Wb,
+                          const float* gamma, float* feat, const float* qk_ops, hipStream_t st);
+void set_attn_pipe_stamps(void* device_buffer);
 
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
@@ -130,6 +130,14 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
                    const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
                    const uint8_t* gm, const uint8_t* rm, const float* upstream3, float* d_res_ctx, float* d_pair_ctx, float* ws,
                    hipStream_t st);
+// the same backward from arbitrary cotangents of the Denoiser outputs (null = zero), and one IPA layer's backward (one-layer tape)
+int denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
+                     const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* post_hat,
+                     const float* cot_eps, const float* cot_O0, const float* cot_post, float* d_res_ctx, float* d_pair_ctx, float* ws,
+                     hipStream_t st);
+int ipa_layer_bwd(const diffab_dims* d1, const diffab_ipa_layer_weights* lw, const diffab_ipa_layer_weights* lg, const TrainTape& tp,
+                  const float* R, const float* t, const float* pair_ctx, const float* dy, float* dx, float* d_pair_ctx, float* ws,
+                  hipStream_t st);
 // Y = act(X W^T + b) backward: dW += dY^T X (W is N x Kd, row-major), db += colsum dY (nullable), dX (+)= dY W (nullable).
 // dY must already carry the activation mask (bwd_relu_mask: dY *= act > 0, in place).  bwd_gemm_nn: C (+)= A[M,K] B[K,N].
 int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M, int N,

@@ -460,6 +460,94 @@ __global__ void orientation_loss_kernel(const float* __restrict__ pO, const floa
   if (threadIdx.x == 0 && sum1) sum1[0] = red[0];
 }
 
+// d pred / d target of the same loss: D = pred^T target - I, L_jk = D_jk^2 with cotangent c_jk (g_elems, or the scalar *g_total for
+// every element); d pred[i][j] = sum_k 2 c_jk D_jk target[i][k], d target[i][k] = sum_j 2 c_jk D_jk pred[i][j]
+__global__ void orientation_loss_bwd_kernel(const float* __restrict__ pO, const float* __restrict__ tO, int64_t n,
+                                            const float* __restrict__ g_elems, const float* __restrict__ g_total,
+                                            float* __restrict__ d_pred, float* __restrict__ d_target) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const float gt = g_total ? g_total[0] : 0.0f;
+  float P[9], T[9], G[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { P[k] = pO[i * 9 + k]; T[k] = tO[i * 9 + k]; }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float d = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) d += P[r * 3 + j] * T[r * 3 + k];
+      d -= (j == k) ? 1.0f : 0.0f;
+      G[j * 3 + k] = 2.0f * d * (g_elems ? g_elems[i * 9 + j * 3 + k] : gt);
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (d_pred) {  // d pred[r][c] = sum_k G[c][k] T[r][k]
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s += G[c * 3 + k] * T[r * 3 + k];
+        d_pred[i * 9 + r * 3 + c] = s;
+      }
+      if (d_target) {  // d target[r][c] = sum_j G[j][c] P[r][j]
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s += G[j * 3 + c] * P[r * 3 + j];
+        d_target[i * 9 + r * 3 + c] = s;
+      }
+    }
+}
+
+// ------------------------------------------------------------------ rigid frames applied to points (diffab_pytorch.py:315-336)
+// x (B, N, L, P, 3) points of N heads, R (B, L, 3, 3), t (B, L, 3) broadcast over the heads; row-vector convention.
+//   INVERT = false: out = x R + t        (euclidean_transform, :315-324)
+//   INVERT = true:  out = (x - t) R^T    (inverse_euclidean_transform, :327-336)
+// t == nullptr: the rotation alone (the x-gradient of the other direction).
+template <bool INVERT>
+__global__ void frames_kernel(const float* __restrict__ x, const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ out,
+                              int N, int L, int P, int64_t n_points) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;  // point (b, n, l, p)
+  if (i >= n_points) return;
+  const int64_t bnl = i / P;
+  const int64_t l = bnl % L, b = bnl / (static_cast<int64_t>(L) * N);
+  const float* Rr = R + (b * L + l) * 9;
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  if (t) {
+    const float* tr = t + (b * L + l) * 3;
+    tx = tr[0]; ty = tr[1]; tz = tr[2];
+  }
+  const float px = x[i * 3], py = x[i * 3 + 1], pz = x[i * 3 + 2];
+  if (INVERT) {
+    const float dx = px - tx, dy = py - ty, dz = pz - tz;
+    out[i * 3 + 0] = (dx * Rr[0] + dy * Rr[1]) + dz * Rr[2];
+    out[i * 3 + 1] = (dx * Rr[3] + dy * Rr[4]) + dz * Rr[5];
+    out[i * 3 + 2] = (dx * Rr[6] + dy * Rr[7]) + dz * Rr[8];
+  } else {
+    out[i * 3 + 0] = ((px * Rr[0] + py * Rr[3]) + pz * Rr[6]) + tx;
+    out[i * 3 + 1] = ((px * Rr[1] + py * Rr[4]) + pz * Rr[7]) + ty;
+    out[i * 3 + 2] = ((px * Rr[2] + py * Rr[5]) + pz * Rr[8]) + tz;
+  }
+}
+
+// AngularEncoding (diffab_pytorch.py:20-54): per input element x -> [x, sin(f_i x) (2 nf values), cos(f_i x) (2 nf values)],
+// f = [1, .., nf, 1/1, .., 1/nf] (the reference builds the band table in fp32: 1.0 / (i + 1.0) rounded once)
+__global__ void angular_encoding_kernel(const float* __restrict__ x, int64_t n, int nf, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const int w = 4 * nf + 1;
+  float* o = out + i * w;
+  o[0] = v;
+  for (int k = 0; k < 2 * nf; ++k) {
+    const float f = k < nf ? static_cast<float>(k + 1) : 1.0f / static_cast<float>(k - nf + 1);
+    const float a = f * v;
+    o[1 + k] = sinf(a);
+    o[1 + 2 * nf + k] = cosf(a);
+  }
+}
+
 // ------------------------------------------------------------------ reverse update
 __device__ inline void reverse_update_one(int64_t i, int t, float beta, float alpha, float omabs, int64_t* seq, float* x, float* O,
                                           const float* eps_hat, const float* O0_hat, const float* post, int V, float zx, float zy,
@@ -748,6 +836,41 @@ int diffab_losses_fwd(const float* pred_post, const float* true_post, const floa
 int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream) {
   DIFFAB_REQUIRE(pred && target && n > 0 && (elems || sum1), DIFFAB_ERR_ARG, "orientation_loss: bad argument");
   hipLaunchKernelGGL(orientation_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), pred, target, n, elems, sum1);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_orientation_loss_bwd(const float* pred, const float* target, int64_t n, const float* g_elems, const float* g_total,
+                                float* d_pred, float* d_target, void* stream) {
+  DIFFAB_REQUIRE(pred && target && n > 0 && (g_elems || g_total) && (d_pred || d_target), DIFFAB_ERR_ARG, "orientation_loss_bwd: bad argument");
+  hipLaunchKernelGGL(orientation_loss_bwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), pred, target, n, g_elems, g_total,
+                     d_pred, d_target);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_frames_apply(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream) {
+  DIFFAB_REQUIRE(x && R && out && B >= 0 && N > 0 && L > 0 && P > 0, DIFFAB_ERR_ARG, "frames_apply: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * N * L * P;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(frames_kernel<false>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, R, t, out, N, L, P, n);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_frames_invert(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream) {
+  DIFFAB_REQUIRE(x && R && out && B >= 0 && N > 0 && L > 0 && P > 0, DIFFAB_ERR_ARG, "frames_invert: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * N * L * P;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(frames_kernel<true>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, R, t, out, N, L, P, n);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float* out, void* stream) {
+  DIFFAB_REQUIRE(x && out && n >= 0 && num_funcs > 0, DIFFAB_ERR_ARG, "angular_encoding: bad argument");
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(angular_encoding_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, n, num_funcs, out);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

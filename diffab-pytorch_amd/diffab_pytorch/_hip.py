@@ -132,6 +132,17 @@ SYMBOLS = {
                                             _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "diffab_featurize_xyz": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
     "diffab_orientation_loss": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp]),
+    "diffab_orientation_loss_bwd": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp, _fp, _fp]),
+    "diffab_frames_apply": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "diffab_frames_invert": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "diffab_angular_encoding": (C.c_int, [_fp, _i64, _i32, _fp, _fp]),
+    "diffab_denoise_step_fwd_taped": (C.c_int, [_PD, C.POINTER(DenoiserWeights)] + [_fp] * 10 + [_sz, _u32, _fp]),
+    "diffab_denoise_step_bwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), C.POINTER(DenoiserWeights)] + [_fp] * 11 + [_sz, _fp, _sz, _fp]),
+    "diffab_ipa_layer_tape_bytes": (_sz, [_PD]),
+    "diffab_ipa_layer_bwd_workspace_bytes": (_sz, [_PD]),
+    "diffab_ipa_layer_fwd_taped": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _sz, _u32, _fp]),
+    "diffab_ipa_layer_bwd": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz,
+                                       _fp, _sz, _fp]),
     "diffab_reverse_update": (C.c_int, [_PS, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "diffab_sample_loop": (C.c_int, [_PD, C.POINTER(DenoiserWeights), _PS, _PI, _fp, _fp, _fp, _fp, _fp, _fp, _u64, _i64, _i32,
                                      _i32, _fp, _sz, _u32, _fp]),

@@ -46,25 +46,125 @@ def _named(module: nn.Module) -> Dict[str, torch.Tensor]:
     return dict(module.named_parameters())
 
 
-_warned_detached = set()
+def _wants_grad(module: Optional[nn.Module], *tensors) -> bool:
+    """True when the caller expects a differentiable result: autograd is on and an input or a parameter requires grad."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(torch.is_tensor(t_) and t_.requires_grad for t_ in tensors):
+        return True
+    return module is not None and any(p.requires_grad for p in module.parameters())
 
 
-def _warn_if_grad_expected(who: str, module: Optional[nn.Module], *tensors) -> None:
-    """The per-module forwards are inference calls into the HIP library: their outputs carry no grad_fn.  A caller who builds a
-    loss of their own from them under autograd would silently get no gradients, so say so once per module type; the
-    differentiable path is DiffAb.training_step / DiffAb.hotpath_train_losses (one taped HIP forward + one HIP backward)."""
-    if not torch.is_grad_enabled() or who in _warned_detached:
-        return
-    needs = any(torch.is_tensor(t_) and t_.requires_grad for t_ in tensors)
-    if not needs and module is not None and module.training:
-        needs = any(p.requires_grad for p in module.parameters())
-    if needs:
-        _warned_detached.add(who)
-        import warnings
+def _no_frame_grads(who: str, *tensors) -> None:
+    if any(torch.is_tensor(t_) and t_.requires_grad for t_ in tensors):
+        raise NotImplementedError(f"{who}: gradients with respect to the frames (orientations / translations) are not implemented on the "
+                                  "HIP path (the reference's training step never needs them); detach them or use torch.no_grad()")
 
-        warnings.warn(f"{who}.forward runs the HIP inference path: its outputs are detached from autograd (no grad_fn).  Use "
-                      "DiffAb.training_step / DiffAb.hotpath_train_losses for gradients, or torch.no_grad() to silence this.",
-                      stacklevel=3)
+
+class AngularEncoding(nn.Module):
+    """[x, sin(f x), cos(f x)] with f = [1..n, 1/1..1/n] per input value (reference diffab_pytorch.py:20-54); one HIP kernel.
+    Not differentiable here (the reference applies it to input features only)."""
+
+    def __init__(self, num_funcs=3):
+        super().__init__()
+        self.num_funcs = num_funcs
+        self.freq_bands = torch.tensor([i + 1.0 for i in range(num_funcs)] + [1.0 / (i + 1.0) for i in range(num_funcs)]).float()
+
+    def get_output_dimension(self, d_in):
+        return d_in * (self.num_funcs * 2 * 2 + 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lib = _hip.lib()
+        xd = _hip.dev_f32(x)
+        out = torch.empty(*xd.shape[:-1], xd.shape[-1] * (4 * self.num_funcs + 1), dtype=torch.float32, device=xd.device)
+        _hip.check(lib.diffab_angular_encoding(_hip.ptr(xd), xd.numel(), self.num_funcs, _hip.ptr(out), _hip.stream_ptr()),
+                   "diffab_angular_encoding")
+        return out.to(x.device)
+
+
+class _FramesFn(torch.autograd.Function):
+    """euclidean_transform / inverse_euclidean_transform on HIP; differentiable with respect to the points (the opposite rotation
+    of the cotangent, same kernel with t = NULL)."""
+
+    @staticmethod
+    def forward(ctx, x, r, t, invert: bool):
+        lib = _hip.lib()
+        xd, rd, td = _hip.dev_f32(x), _hip.dev_f32(r), _hip.dev_f32(t)
+        B, N, L, P = xd.shape[:4]
+        out = torch.empty_like(xd)
+        fn = lib.diffab_frames_invert if invert else lib.diffab_frames_apply
+        _hip.check(fn(_hip.ptr(xd), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(out), B, N, L, P, _hip.stream_ptr()), "diffab_frames")
+        ctx.invert, ctx.shape, ctx.dev = invert, (B, N, L, P), x.device
+        ctx.save_for_backward(rd)
+        return out.to(x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _hip.lib()
+        (rd,) = ctx.saved_tensors
+        gd = _hip.dev_f32(g)
+        B, N, L, P = ctx.shape
+        dx = torch.empty_like(gd)
+        fn = lib.diffab_frames_apply if ctx.invert else lib.diffab_frames_invert  # d x = g R^T (apply) | g R (invert)
+        _hip.check(fn(_hip.ptr(gd), _hip.ptr(rd), None, _hip.ptr(dx), B, N, L, P, _hip.stream_ptr()), "diffab_frames (backward)")
+        return dx.to(ctx.dev), None, None, None
+
+
+def euclidean_transform(x, r, t):
+    """global = x R + t for points x (b, n heads, l, p, 3), r (b, l, 3, 3), t (b, l, 3) (reference diffab_pytorch.py:315-324)."""
+    _no_frame_grads("euclidean_transform", r, t)
+    return _FramesFn.apply(x, r, t, False)
+
+
+def inverse_euclidean_transform(x, r, t):
+    """local = (x - t) R^T (reference diffab_pytorch.py:327-336)."""
+    _no_frame_grads("inverse_euclidean_transform", r, t)
+    return _FramesFn.apply(x, r, t, True)
+
+
+class _IpaLayerFn(torch.autograd.Function):
+    """InvariantPointAttentionLayer.forward under autograd: taped HIP forward + HIP backward from d y (diffab_ipa_layer_fwd_taped /
+    diffab_ipa_layer_bwd): gradients of the layer's ten parameters, of x and of the pair embedding."""
+
+    @staticmethod
+    def forward(ctx, layer, flags, x, e, r, t, *params):
+        lib = _hip.lib()
+        names = [n for n, _ in layer.named_parameters()]
+        xd, ed, rd, td = (_hip.dev_f32(a) for a in (x, e, r, t))
+        B, K = xd.shape[:2]
+        d = layer.dims
+        dims = _hip.make_dims(B, K, d["D"], d["C"], d["H"], d["DS"], d["PQ"], d["PV"], 1)
+        keep: list = []
+        w = _hip.ipa_layer_weights(dict(zip(names, params)), keep)
+        tape = _hip.workspace(lib.diffab_ipa_layer_tape_bytes(C.byref(dims)))
+        y = torch.empty_like(xd)
+        _hip.check(lib.diffab_ipa_layer_fwd_taped(C.byref(dims), C.byref(w), _hip.ptr(xd), _hip.ptr(ed), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(y),
+                                                  _hip.ptr(tape), tape.numel(), flags, _hip.stream_ptr()), "diffab_ipa_layer_fwd_taped")
+        ctx.layer, ctx.names, ctx.dims = layer, names, dims
+        ctx.need_e = ctx.needs_input_grad[3]
+        ctx.devs = (x.device, e.device, [p.device for p in params])
+        ctx.save_for_backward(ed, rd, td, tape, *params)
+        return y.to(x.device)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _hip.lib()
+        ed, rd, td, tape = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        dims = ctx.dims
+        keep: list = []
+        w = _hip.ipa_layer_weights(dict(zip(ctx.names, params)), keep)
+        grads, ctx.layer._flat_grad = _zero_grads_like(params)
+        g = _hip.ipa_layer_weights(dict(zip(ctx.names, grads)), keep)
+        dyd = _hip.dev_f32(dy)
+        dx = torch.empty_like(dyd)
+        de = torch.zeros_like(ed) if ctx.need_e else None
+        ws = _hip.workspace(lib.diffab_ipa_layer_bwd_workspace_bytes(C.byref(dims)))
+        _hip.check(lib.diffab_ipa_layer_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(ed), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(dyd),
+                                            _hip.ptr(dx), _hip.ptr(de), _hip.ptr(tape), tape.numel(), _hip.ptr(ws), ws.numel(),
+                                            _hip.stream_ptr()), "diffab_ipa_layer_bwd")
+        x_dev, e_dev, p_devs = ctx.devs
+        return (None, None, dx.to(x_dev), de.to(e_dev) if ctx.need_e else None, None, None) + tuple(gr.to(dv) for gr, dv in zip(grads, p_devs))
 
 
 class InvariantPointAttentionLayer(nn.Module):
@@ -94,7 +194,9 @@ class InvariantPointAttentionLayer(nn.Module):
 
     def forward(self, x, e, r, t, *, flags: int = 0):
         lib = _hip.lib()
-        _warn_if_grad_expected("InvariantPointAttentionLayer", self, x, e)
+        if _wants_grad(self, x, e, r, t):  # differentiable like the reference's forward (:389-465): taped HIP forward + HIP backward
+            _no_frame_grads("InvariantPointAttentionLayer", r, t)
+            return _IpaLayerFn.apply(self, flags & ~_hip.FLAG_PAIR_PLANES, x, e, r, t, *[p for _, p in self.named_parameters()])
         xd, ed, rd, td = (_hip.dev_f32(a) for a in (x, e, r, t))
         B, K = xd.shape[:2]
         d = self.dims
@@ -161,7 +263,13 @@ class Denoiser(nn.Module):
                 residue_mask=None, *, return_logits: bool = False, flags: int = 0) -> Dict[str, torch.Tensor]:
         # generation_mask / residue_mask are accepted and ignored, exactly like the reference (:566-567).
         lib = _hip.lib()
-        _warn_if_grad_expected("Denoiser", self, res_context_emb, pair_context_emb, translations_t)
+        if not return_logits and _wants_grad(self, res_context_emb, pair_context_emb, translations_t, orientations_t):
+            # differentiable like the reference's forward (:558-607): taped HIP forward + HIP backward from the outputs' cotangents
+            # (return_logits=True is an inference-only diagnostic of this package: detached outputs)
+            _no_frame_grads("Denoiser", translations_t, orientations_t)
+            eps, O0, post = _DenoiserFn.apply(self, flags & ~_hip.FLAG_PAIR_PLANES, seq_idx_t, translations_t, orientations_t, beta,
+                                              res_context_emb, pair_context_emb, *[p for _, p in self.named_parameters()])
+            return {"translations_eps": eps, "orientations_t0": O0, "seq_posterior": post}
         out_dev = translations_t.device
         seq = _hip.dev_i64(seq_idx_t)
         x, O, rc, pc, bt = (_hip.dev_f32(a) for a in (translations_t, orientations_t, res_context_emb, pair_context_emb, beta))
@@ -183,6 +291,88 @@ class Denoiser(nn.Module):
             out["aa_logits"] = logits.to(out_dev)
             out["res_emb"] = h.to(out_dev)
         return out
+
+
+class _DenoiserFn(torch.autograd.Function):
+    """Denoiser.forward under autograd: diffab_denoise_step_fwd_taped, then diffab_denoise_step_bwd from the cotangents of
+    (eps-hat, O0-hat, posterior): gradients of every denoiser parameter and of the two context embeddings."""
+
+    @staticmethod
+    def forward(ctx, denoiser, flags, seq_t, x_t, O_t, beta, res_ctx, pair_ctx, *params):
+        lib = _hip.lib()
+        names = [n for n, _ in denoiser.named_parameters()]
+        seq = _hip.dev_i64(seq_t)
+        x, O, bt, rc, pc = (_hip.dev_f32(a) for a in (x_t, O_t, beta, res_ctx, pair_ctx))
+        B, K = seq.shape
+        dims = denoiser.hip_dims(B, K)
+        w = _hip.DenoiserWeightsOnDevice(dict(zip(names, params)), denoiser.dims["NL"])
+        dev = seq.device
+        eps = torch.empty(B, K, 3, dtype=torch.float32, device=dev)
+        O0 = torch.empty(B, K, 3, 3, dtype=torch.float32, device=dev)
+        post = torch.empty(B, K, dims.V, dtype=torch.float32, device=dev)
+        tape = _hip.workspace(lib.diffab_train_tape_bytes(C.byref(dims)))
+        _hip.check(lib.diffab_denoise_step_fwd_taped(C.byref(dims), C.byref(w.struct), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(rc),
+                                                     _hip.ptr(pc), _hip.ptr(bt), _hip.ptr(eps), _hip.ptr(O0), _hip.ptr(post), _hip.ptr(tape),
+                                                     tape.numel(), flags, _hip.stream_ptr()), "diffab_denoise_step_fwd_taped")
+        ctx.denoiser, ctx.names, ctx.dims = denoiser, names, dims
+        ctx.need = (ctx.needs_input_grad[6], ctx.needs_input_grad[7])
+        ctx.devs = (res_ctx.device, pair_ctx.device, [p.device for p in params])
+        ctx.save_for_backward(seq, x, O, pc, post, tape, *params)
+        out_dev = x_t.device
+        return eps.to(out_dev), O0.to(out_dev), post.to(out_dev)
+
+    @staticmethod
+    def backward(ctx, g_eps, g_O0, g_post):
+        lib = _hip.lib()
+        seq, x, O, pc, post, tape = ctx.saved_tensors[:6]
+        params = ctx.saved_tensors[6:]
+        dims = ctx.dims
+        B, K = seq.shape
+        w = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, params)), ctx.denoiser.dims["NL"])
+        grads, ctx.denoiser._flat_grad = _zero_grads_like(params)
+        g = _hip.DenoiserWeightsOnDevice(dict(zip(ctx.names, grads)), ctx.denoiser.dims["NL"])
+        ce, cO, cp = (None if t_ is None else _hip.dev_f32(t_) for t_ in (g_eps, g_O0, g_post))
+        d_rc = torch.empty(B, K, dims.D, dtype=torch.float32, device=seq.device)
+        d_pc = torch.zeros_like(pc) if ctx.need[1] else None
+        ws = _hip.workspace(lib.diffab_train_workspace_bytes(C.byref(dims)))
+        _hip.check(lib.diffab_denoise_step_bwd(C.byref(dims), C.byref(w.struct), C.byref(g.struct), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O),
+                                               _hip.ptr(pc), _hip.ptr(post), _hip.ptr(ce), _hip.ptr(cO), _hip.ptr(cp), _hip.ptr(d_rc),
+                                               _hip.ptr(d_pc), _hip.ptr(tape), tape.numel(), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
+                   "diffab_denoise_step_bwd")
+        rc_dev, pc_dev, p_devs = ctx.devs
+        return (None,) * 6 + (d_rc.to(rc_dev) if ctx.need[0] else None, d_pc.to(pc_dev) if ctx.need[1] else None) + \
+            tuple(gr.to(dv) for gr, dv in zip(grads, p_devs))
+
+
+class _OrientationLossFn(torch.autograd.Function):
+    """OrientationLoss under autograd: diffab_orientation_loss, then diffab_orientation_loss_bwd."""
+
+    @staticmethod
+    def forward(ctx, pred, target, reduction):
+        lib = _hip.lib()
+        p, t = _hip.dev_f32(pred), _hip.dev_f32(target)
+        n = p.numel() // 9
+        elems = torch.empty_like(p) if reduction == "none" else None
+        total = torch.empty(1, dtype=torch.float32, device=p.device)
+        _hip.check(lib.diffab_orientation_loss(_hip.ptr(p), _hip.ptr(t), n, _hip.ptr(elems), _hip.ptr(total), _hip.stream_ptr()),
+                   "diffab_orientation_loss")
+        ctx.reduction, ctx.n = reduction, n
+        ctx.devs = (pred.device, target.device)
+        ctx.save_for_backward(p, t)
+        out = elems if reduction == "none" else (total[0] / float(9 * n) if reduction == "mean" else total[0])
+        return out.to(device=pred.device, dtype=pred.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _hip.lib()
+        p, t = ctx.saved_tensors
+        gd = _hip.dev_f32(g)
+        ge, gt = (gd, None) if ctx.reduction == "none" else (None, (gd / float(9 * ctx.n) if ctx.reduction == "mean" else gd).reshape(1))
+        dp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        dt = torch.empty_like(t) if ctx.needs_input_grad[1] else None
+        _hip.check(lib.diffab_orientation_loss_bwd(_hip.ptr(p), _hip.ptr(t), ctx.n, _hip.ptr(ge), _hip.ptr(gt), _hip.ptr(dp), _hip.ptr(dt),
+                                                   _hip.stream_ptr()), "diffab_orientation_loss_bwd")
+        return (None if dp is None else dp.to(ctx.devs[0]), None if dt is None else dt.to(ctx.devs[1]), None)
 
 
 class _HotpathTrainStep(torch.autograd.Function):
@@ -251,7 +441,8 @@ class OrientationLoss(nn.Module):
 
     def forward(self, pred_rotmat: torch.Tensor, target_rotmat: torch.Tensor) -> torch.Tensor:
         lib = _hip.lib()
-        _warn_if_grad_expected("OrientationLoss", None, pred_rotmat, target_rotmat)
+        if _wants_grad(None, pred_rotmat, target_rotmat):
+            return _OrientationLossFn.apply(pred_rotmat, target_rotmat, self.reduction)
         p, t = _hip.dev_f32(pred_rotmat), _hip.dev_f32(target_rotmat)
         n = p.numel() // 9
         elems = torch.empty_like(p) if self.reduction == "none" else None

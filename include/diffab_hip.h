@@ -262,6 +262,40 @@ int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w
 
 /* diffab_pytorch.py:610-625  OrientationLoss: elems (n,3,3) = (pred^T target - I)^2 and/or their total (either may be NULL) */
 int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream);
+/* its backward (autograd of :620-625): cotangent per element (g_elems, (n,3,3)) or one device scalar applied to every element
+ * (g_total: upstream / (9 n) for reduction "mean", upstream for "sum"); d_pred / d_target (n,3,3), either may be NULL */
+int diffab_orientation_loss_bwd(const float* pred, const float* target, int64_t n, const float* g_elems, const float* g_total,
+                                float* d_pred, float* d_target, void* stream);
+
+/* diffab_pytorch.py:315-324 euclidean_transform: out = x R + t, and :327-336 inverse_euclidean_transform: out = (x - t) R^T, for
+ * points x (B, N heads, L, P, 3), frames R (B, L, 3, 3), t (B, L, 3) broadcast over the heads (row-vector convention).  t may be
+ * NULL (rotation only: the x-gradient of the opposite direction). */
+int diffab_frames_apply(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream);
+int diffab_frames_invert(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream);
+/* diffab_pytorch.py:20-54 AngularEncoding.forward: n input values -> n x (4 num_funcs + 1) outputs [x, sin(f x), cos(f x)],
+ * f = [1 .. num_funcs, 1/1 .. 1/num_funcs] */
+int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float* out, void* stream);
+
+/* ---- Denoiser.forward / InvariantPointAttentionLayer.forward under autograd (reference :558-607, :389-465 are differentiable) ----
+ * Taped forwards (same outputs as diffab_denoise_step_fwd / diffab_ipa_layer_fwd, activations kept in `tape`) and backwards from
+ * ARBITRARY cotangents.  Gradient buffers in `grads` and d_pair_ctx / d_e must be zero-filled by the caller (they are accumulated
+ * into); NULL cotangents mean zero.  Tape: diffab_train_tape_bytes(d) / diffab_ipa_layer_tape_bytes(d); workspace:
+ * diffab_train_workspace_bytes(d) / diffab_ipa_layer_bwd_workspace_bytes(d).  Gradients with respect to x_t / O_t (R / t) are
+ * not produced (the training path never needs them). */
+int diffab_denoise_step_fwd_taped(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
+                                  const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps,
+                                  float* out_O0, float* out_posterior, void* tape, size_t tape_bytes, uint32_t flags, void* stream);
+int diffab_denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
+                            const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_posterior,
+                            const float* d_eps, const float* d_O0, const float* d_posterior, float* d_res_ctx, float* d_pair_ctx,
+                            const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
+size_t diffab_ipa_layer_tape_bytes(const diffab_dims* d);
+size_t diffab_ipa_layer_bwd_workspace_bytes(const diffab_dims* d);
+int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
+                               const float* t, float* y, void* tape, size_t tape_bytes, uint32_t flags, void* stream);
+int diffab_ipa_layer_bwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const diffab_ipa_layer_weights* grads, const float* e,
+                         const float* R, const float* t, const float* dy, float* dx, float* d_e, const void* tape, size_t tape_bytes,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- encode_context (reference diffab_pytorch.py:57-312, 680-724) -----------------------------------------
  * Runs once per sample.  atom_mask is float32 (B,K,A) (1 = atom present); context masks are 1 byte per residue, NULL = "not

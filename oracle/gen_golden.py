@@ -448,6 +448,98 @@ def main():
             gg["grad/" + k_] = npf(v_.grad)
     np.savez_compressed(os.path.join(GOLD, "encode_context_grads.npz"), **gg)
 
+    # ---------------------------------------------------------------- frames, AngularEncoding (module-level functions of the hot path)
+    print("euclidean_transform / inverse_euclidean_transform / AngularEncoding")
+    gf = torch.Generator().manual_seed(51)
+    xpts = 5.0 * torch.randn(2, 3, 5, 4, 3, generator=gf)
+    Rf = torch.from_numpy(syn.random_rotations(np.random.Generator(np.random.PCG64(52)), 10).astype(np.float32)).view(2, 5, 3, 3)
+    tf = 20.0 * torch.randn(2, 5, 3, generator=gf)
+    fwd = rmod.euclidean_transform(xpts, Rf, tf)
+    inv = rmod.inverse_euclidean_transform(xpts, Rf, tf)
+    check("euclidean_transform", orc.to_global(xpts, Rf, tf), fwd, 1e-6)
+    check("inverse_euclidean_transform", orc.to_local(xpts, Rf, tf), inv, 1e-6)
+    check("inverse o forward", rmod.inverse_euclidean_transform(fwd, Rf, tf), xpts, 2e-6)
+    xa = 3.0 * torch.randn(2, 5, 3, generator=gf)
+    enc = rmod.AngularEncoding(num_funcs=3)(xa)
+    check("AngularEncoding", orc.angular_encoding(xa, 3), enc, 0.0)
+    # autograd of the two transforms with respect to the points
+    xg = xpts.clone().requires_grad_(True)
+    cg = torch.randn(2, 3, 5, 4, 3, generator=gf)
+    (rmod.euclidean_transform(xg, Rf, tf) * cg).sum().backward()
+    g_fwd = xg.grad.clone()
+    xg.grad = None
+    (rmod.inverse_euclidean_transform(xg, Rf, tf) * cg).sum().backward()
+    np.savez_compressed(os.path.join(GOLD, "frames.npz"), x=npf(xpts), R=npf(Rf), t=npf(tf), fwd=npf(fwd), inv=npf(inv), xa=npf(xa), enc=npf(enc),
+                        cot=npf(cg), grad_fwd=npf(g_fwd), grad_inv=npf(xg.grad))
+
+    # ---------------------------------------------------------------- autograd through the module forwards from arbitrary cotangents
+    # (Denoiser.forward :558-607, InvariantPointAttentionLayer.forward :389-465, OrientationLoss :610-625 are differentiable upstream;
+    # a caller with a loss of their own on model.denoise() needs these gradients)
+    def subsample(name, gr, store, full):
+        flat = gr.detach().reshape(-1)
+        if full or flat.numel() <= 4096:
+            store["grad/" + name] = npf(gr)
+            return
+        n = flat.numel()
+        stride = max(1, n // 512)
+        off = (7 * len(name)) % stride
+        store["sub/" + name] = npf(flat[off::stride][:512])
+        store["info/" + name] = np.array([n, stride, off, float(flat.double().norm()), float(flat.abs().max())])
+
+    for tag, dims, B, K, seed, sigma in (("unit", dict(syn.UNIT_DIMS, NL=2), 2, 16, 61, 4.0), ("bench", dict(syn.BENCH_DIMS, NL=2), 1, 128, 62, 6.0)):
+        print(f"module autograd from cotangents ({tag} dims, reference autograd)")
+        full = tag == "unit"
+        den, sd = build_ref_denoiser(dims, seed)
+        den.train()
+        inp = syn.patches(B, K, dims, seed=seed, coord_sigma=sigma)
+        tt = torch.tensor([9, 63][:B])
+        beta = sched["beta"][tt]
+        gc = torch.Generator().manual_seed(seed)
+        c_eps = torch.randn(B, K, 3, generator=gc)
+        c_O0 = torch.randn(B, K, 3, 3, generator=gc)
+        c_post = torch.randn(B, K, 21, generator=gc)
+        res_ctx = inp["res_context_emb"].clone().requires_grad_(True)
+        pair_ctx = inp["pair_context_emb"].clone().requires_grad_(True)
+        out = den(inp["seq_idx"], inp["translations"], inp["orientations"], res_ctx, pair_ctx, beta, None, None)
+        ((out["translations_eps"] * c_eps).sum() + (out["orientations_t0"] * c_O0).sum() + (out["seq_posterior"] * c_post).sum()).backward()
+        g = dict(meta=np.array([B, K, seed, dims["D"], dims["C"], dims["NL"], dims["DS"], dims["H"], dims["PQ"], dims["PV"]]),
+                 coord_sigma=np.array(sigma), beta=npf(beta), c_eps=npf(c_eps), c_O0=npf(c_O0), c_post=npf(c_post),
+                 out_eps=npf(out["translations_eps"]), out_post=npf(out["seq_posterior"]))
+        subsample("res_ctx", res_ctx.grad, g, full)
+        subsample("pair_ctx", pair_ctx.grad, g, full)
+        for n_, p_ in den.named_parameters():
+            subsample(n_, p_.grad, g, full)
+        # one IPA layer alone: d y random -> d x, d e, parameter gradients
+        layer = den.ipa.layers[0]
+        for p_ in layer.parameters():
+            p_.grad = None
+        xl = inp["res_context_emb"].clone().requires_grad_(True)
+        el = inp["pair_context_emb"].clone().requires_grad_(True)
+        c_y = torch.randn(B, K, dims["D"], generator=gc)
+        yl = layer(xl, el, inp["orientations"], inp["translations"])
+        (yl * c_y).sum().backward()
+        g["layer/c_y"] = npf(c_y)
+        g["layer/y"] = npf(yl)
+        subsample("layer/x", xl.grad, g, full)
+        subsample("layer/e", el.grad, g, full)
+        for n_, p_ in layer.named_parameters():
+            subsample("layer/" + n_, p_.grad, g, full)
+        np.savez_compressed(os.path.join(GOLD, f"module_autograd_{tag}.npz"), **g)
+
+    print("OrientationLoss autograd")
+    go = torch.Generator().manual_seed(71)
+    Rp = torch.from_numpy(syn.random_rotations(np.random.Generator(np.random.PCG64(72)), 12).astype(np.float32)).view(3, 4, 3, 3)
+    Rp = Rp + 0.05 * torch.randn(3, 4, 3, 3, generator=go)  # a prediction is not exactly a rotation
+    Rt = torch.from_numpy(syn.random_rotations(np.random.Generator(np.random.PCG64(73)), 12).astype(np.float32)).view(3, 4, 3, 3)
+    ol = {}
+    for red in ("mean", "sum", "none"):
+        pr, tr = Rp.clone().requires_grad_(True), Rt.clone().requires_grad_(True)
+        val = rmod.OrientationLoss(reduction=red)(pr, tr)
+        cot = torch.randn(val.shape, generator=go) if red == "none" else torch.tensor(1.7)
+        (val * cot).sum().backward()
+        ol[f"{red}/value"], ol[f"{red}/cot"], ol[f"{red}/d_pred"], ol[f"{red}/d_target"] = npf(val), npf(cot), npf(pr.grad), npf(tr.grad)
+    np.savez_compressed(os.path.join(GOLD, "orientation_loss_grads.npz"), pred=npf(Rp), target=npf(Rt), **ol)
+
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print(f"wrote {len(os.listdir(GOLD))} fixtures, {tot/1024:.0f} KiB, under {GOLD}")
 

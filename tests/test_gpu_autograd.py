@@ -1,0 +1,137 @@
+"""Autograd through the module forwards, and the module-level functions of the hot path, against the REAL reference.
+
+Upstream, Denoiser.forward (diffab_pytorch.py:558-607), InvariantPointAttentionLayer.forward (:389-465), OrientationLoss (:610-625)
+and euclidean_transform / inverse_euclidean_transform (:315-336) are ordinary differentiable torch code: a caller may put a loss of
+their own on model.denoise().  Here each is a taped HIP forward plus a HIP backward from arbitrary cotangents
+(diffab_denoise_step_fwd_taped / _bwd, diffab_ipa_layer_fwd_taped / _bwd, diffab_orientation_loss_bwd, diffab_frames_*).  Goldens:
+oracle/gen_golden.py, autograd of the unmodified reference with seeded random cotangents (tests/golden/module_autograd_*.npz,
+orientation_loss_grads.npz, frames.npz).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxrel
+from diffab_pytorch import _hip, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+GTOL = 2e-4  # gradients: the bar of the training-step goldens (tests/test_gpu_parity.py)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    lib = _hip.lib()
+    assert lib.diffab_device_ok() == 1
+    return lib
+
+
+def check_grad(name, got, g, tol=GTOL):
+    """full gradient ("grad/<name>") or norm + strided subsample ("info/", "sub/") as written by gen_golden.py"""
+    got = got.detach().float().cpu()
+    if "grad/" + name in g:
+        want = T(g["grad/" + name])
+        assert got.shape == want.shape, name
+        assert maxrel(got, want) < tol, (name, maxrel(got, want))
+        return
+    n, stride, off, norm, amax = g["info/" + name]
+    flat = got.reshape(-1)
+    assert flat.numel() == int(n), name
+    sub = flat[int(off)::int(stride)][:512]
+    want = T(g["sub/" + name])
+    assert float((sub.double() - want.double()).abs().max()) < tol * amax, (name, float((sub - want).abs().max()), amax)
+    assert abs(float(flat.double().norm()) - norm) < tol * max(norm, 1e-30) * 10, (name, float(flat.double().norm()), norm)
+
+
+def test_frames_and_angular_encoding_vs_reference_goldens(hip, golden):
+    from diffab_pytorch.diffab_pytorch import AngularEncoding, euclidean_transform, inverse_euclidean_transform
+
+    g = golden("frames")
+    x, R, t = T(g["x"]).cuda(), T(g["R"]).cuda(), T(g["t"]).cuda()
+    assert maxrel(euclidean_transform(x, R, t), g["fwd"]) < 1e-6
+    assert maxrel(inverse_euclidean_transform(x, R, t), g["inv"]) < 1e-6
+    assert maxrel(inverse_euclidean_transform(euclidean_transform(x, R, t), R, t), g["x"]) < 2e-6
+    # CPU tensors in, CPU tensors out (reference callers never move tensors themselves)
+    assert not euclidean_transform(x.cpu(), R.cpu(), t.cpu()).is_cuda
+    # gradients with respect to the points
+    for fn, key in ((euclidean_transform, "grad_fwd"), (inverse_euclidean_transform, "grad_inv")):
+        xg = x.clone().requires_grad_(True)
+        (fn(xg, R, t) * T(g["cot"]).cuda()).sum().backward()
+        assert maxrel(xg.grad, g[key]) < 1e-6, key
+    with pytest.raises(NotImplementedError):
+        euclidean_transform(x, R.clone().requires_grad_(True), t)
+    # reference tests/test_modules.py:16-26
+    enc = AngularEncoding(num_funcs=3)
+    assert enc.get_output_dimension(3) == 3 * (3 * 2 * 2 + 1)
+    assert enc(torch.rand(32, 16, 3)).shape == (32, 16, 39)
+    out = enc(T(g["xa"]).cuda())
+    assert maxrel(out, g["enc"]) < 1e-6 and torch.equal(out[..., 0::13].cpu(), T(g["xa"]))  # the x column is copied, not recomputed
+    assert torch.equal(enc.freq_bands, torch.tensor([1.0, 2.0, 3.0, 1.0, 0.5, 1.0 / 3.0]))
+
+
+def test_orientation_loss_autograd_vs_reference_goldens(hip, golden):
+    from diffab_pytorch.diffab_pytorch import OrientationLoss
+
+    g = golden("orientation_loss_grads")
+    for red in ("mean", "sum", "none"):
+        p, t = T(g["pred"]).cuda().requires_grad_(True), T(g["target"]).cuda().requires_grad_(True)
+        val = OrientationLoss(reduction=red)(p, t)
+        assert val.grad_fn is not None
+        assert maxrel(val, g[f"{red}/value"]) < 1e-6
+        (val * T(g[f"{red}/cot"]).cuda()).sum().backward()
+        assert maxrel(p.grad, g[f"{red}/d_pred"]) < 1e-5, red
+        assert maxrel(t.grad, g[f"{red}/d_target"]) < 1e-5, red
+    # reference tests/test_loss.py:17-21
+    R = T(g["target"]).cuda()
+    assert float(OrientationLoss()(R, R)) < 1e-10
+
+
+@pytest.mark.parametrize("tag", ["unit", "bench"])
+def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
+    from diffab_pytorch.diffab_pytorch import Denoiser
+
+    g = golden("module_autograd_" + tag)
+    B, K, seed, D, C, NL, DS, H, PQ, PV = [int(v) for v in g["meta"]]
+    dims = dict(D=D, C=C, NL=NL, DS=DS, H=H, PQ=PQ, PV=PV, V=21)
+    den = Denoiser(D, C, NL, DS, PQ, PV, H, 21)
+    den.load_state_dict(syn.denoiser_state_dict(dims, seed=seed, prefix=""), strict=True)
+    den = den.cuda().train()
+    inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=seed, coord_sigma=float(g["coord_sigma"])).items()}
+    rc = inp["res_context_emb"].clone().requires_grad_(True)
+    pc = inp["pair_context_emb"].clone().requires_grad_(True)
+    out = den(inp["seq_idx"], inp["translations"], inp["orientations"], rc, pc, T(g["beta"]).cuda(), None, None)
+    for k in ("translations_eps", "orientations_t0", "seq_posterior"):
+        assert out[k].grad_fn is not None, k  # a caller's own loss on these reaches the parameters
+    assert maxrel(out["translations_eps"], g["out_eps"]) < 1e-4 and maxrel(out["seq_posterior"], g["out_post"]) < 1e-4
+    loss = (out["translations_eps"] * T(g["c_eps"]).cuda()).sum() + (out["orientations_t0"] * T(g["c_O0"]).cuda()).sum() + \
+        (out["seq_posterior"] * T(g["c_post"]).cuda()).sum()
+    loss.backward()
+    check_grad("res_ctx", rc.grad, g)
+    check_grad("pair_ctx", pc.grad, g)
+    for n_, p_ in den.named_parameters():
+        assert p_.grad is not None, n_
+        check_grad(n_, p_.grad, g)
+    # a single cotangent (the others None inside autograd): only the translation head and the trunk receive gradients
+    den.zero_grad(set_to_none=True)
+    out = den(inp["seq_idx"], inp["translations"], inp["orientations"], inp["res_context_emb"], inp["pair_context_emb"], T(g["beta"]).cuda())
+    out["translations_eps"].square().sum().backward()
+    assert den.coordinate_denoising[4].weight.grad.abs().max() > 0
+    assert float(den.sequence_denoising[4].weight.grad.abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        den(inp["seq_idx"], inp["translations"].clone().requires_grad_(True), inp["orientations"], rc, pc, T(g["beta"]).cuda())
+    # ---- one IPA layer: d y -> d x, d e, parameter gradients
+    layer = den.ipa.layers[0]
+    layer.zero_grad(set_to_none=True)
+    x = inp["res_context_emb"].clone().requires_grad_(True)
+    e = inp["pair_context_emb"].clone().requires_grad_(True)
+    y = layer(x, e, inp["orientations"], inp["translations"])
+    assert y.grad_fn is not None and maxrel(y, g["layer/y"]) < 1e-4
+    (y * T(g["layer/c_y"]).cuda()).sum().backward()
+    check_grad("layer/x", x.grad, g)
+    check_grad("layer/e", e.grad, g)
+    for n_, p_ in layer.named_parameters():
+        check_grad("layer/" + n_, p_.grad, g)
+    # under no_grad the same call is the inference kernel: detached output, same numbers
+    with torch.no_grad():
+        y0 = layer(x, e, inp["orientations"], inp["translations"])
+    assert y0.grad_fn is None and maxrel(y0, g["layer/y"]) < 1e-4

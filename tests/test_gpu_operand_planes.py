@@ -72,7 +72,7 @@ def test_operand_planes_vs_float64(hip, B, K, sigma, offset):
     layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"])
     with torch.no_grad():
         layer.gamma.copy_(layer.gamma + 0.1 * torch.randn(8))
-    layer = layer.cuda()
+    layer = layer.cuda().requires_grad_(False)
     sd = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
     inp = syn.patches(B, K, d, seed=11, coord_sigma=sigma)
     x, R, t = inp["res_context_emb"], inp["orientations"], inp["translations"] + offset

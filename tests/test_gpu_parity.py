@@ -281,7 +281,7 @@ def build_case(g):
     dims = dict(D=D, C=C, NL=NL, DS=DS, H=H, PQ=PQ, PV=PV, V=21)
     den = Denoiser(D, C, NL, DS, PQ, PV, H, 21)
     den.load_state_dict(syn.denoiser_state_dict(dims, seed=seed, prefix=""), strict=True)
-    den = den.cuda()
+    den = den.cuda().requires_grad_(False)  # inference kernels (the autograd route: tests/test_gpu_autograd.py)
     inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=seed, coord_sigma=float(g["coord_sigma"])).items()}
     return dims, den, inp
 
@@ -315,16 +315,16 @@ def test_denoiser_reference_test_shapes(hip):
     """reference tests/test_modules.py:143-248: unseeded random inputs, non-rotation 'orientations', shapes only."""
     from diffab_pytorch.diffab_pytorch import Denoiser, InvariantPointAttentionLayer, InvariantPointAttentionModule
 
-    ipa = InvariantPointAttentionLayer(32, 16, 16, 4, 4, 8).cuda()
+    ipa = InvariantPointAttentionLayer(32, 16, 16, 4, 4, 8).cuda().requires_grad_(False)
     x, e = torch.rand(32, 16, 32), torch.rand(32, 16, 16, 16)
     r, t = torch.rand(32, 16, 3, 3), torch.rand(32, 16, 3)
     y = ipa(x, e, r, t)
     assert y.shape == (32, 16, 32) and not y.is_cuda
     want = orc.ipa_layer(x, e, r, t, {k: v.cpu() for k, v in ipa.state_dict().items()}, "", 8)
     assert maxrel(y, want) < TOL
-    mod = InvariantPointAttentionModule(4, 32, 16, 16, 4, 4, 8).cuda()
+    mod = InvariantPointAttentionModule(4, 32, 16, 16, 4, 4, 8).cuda().requires_grad_(False)
     assert mod(x, torch.randn(32, 16, 16, 16), r, t).shape == (32, 16, 32)
-    den = Denoiser(32, 16, 4, 12, 4, 4, 8, aa_vocab_size=21).cuda()
+    den = Denoiser(32, 16, 4, 12, 4, 4, 8, aa_vocab_size=21).cuda().requires_grad_(False)
     out = den(torch.randint(0, 20, (32, 16)), t, r, x, torch.randn(32, 16, 16, 16), torch.rand(32), torch.randint(0, 2, (32, 16)),
               torch.randint(0, 2, (32, 16)))
     assert out["translations_eps"].shape == (32, 16, 3)
@@ -340,7 +340,7 @@ def test_denoiser_vs_oracle_batch_and_permutation(hip):
     den = Denoiser(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"], 21)
     sd = syn.denoiser_state_dict(dims, seed=5, prefix="")
     den.load_state_dict(sd)
-    den = den.cuda()
+    den = den.cuda().requires_grad_(False)
     inp = syn.patches(3, 128, dims, seed=5, coord_sigma=6.0)
     beta = torch.tensor([0.01, 0.3, 0.9])
     args = [inp[k] for k in ("seq_idx", "translations", "orientations", "res_context_emb", "pair_context_emb")]
@@ -364,7 +364,7 @@ def test_fast_path_key_chunks_vs_generic_and_oracle(hip, K):
     den = Denoiser(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"], 21)
     sd = syn.denoiser_state_dict(dims, seed=6, prefix="")
     den.load_state_dict(sd)
-    den = den.cuda()
+    den = den.cuda().requires_grad_(False)
     inp = syn.patches(2, K, dims, seed=60 + K, coord_sigma=5.0)
     beta = torch.tensor([0.02, 0.6])
     args = [inp[k] for k in ("seq_idx", "translations", "orientations", "res_context_emb", "pair_context_emb")]
@@ -391,7 +391,7 @@ def test_denoiser_translation_offset_robustness(hip):
     den = Denoiser(dims["D"], dims["C"], 1, dims["DS"], dims["PQ"], dims["PV"], dims["H"], 21)
     sd = syn.denoiser_state_dict(dims, seed=9, prefix="")
     den.load_state_dict(sd)
-    den = den.cuda()
+    den = den.cuda().requires_grad_(False)
     inp = syn.patches(1, 128, dims, seed=9, coord_sigma=8.0)
     x = inp["translations"] + torch.tensor([150.0, -90.0, 40.0])
     args = [inp["seq_idx"], x, inp["orientations"], inp["res_context_emb"], inp["pair_context_emb"]]
@@ -634,7 +634,7 @@ def test_full_size_properties_b256(hip):
     d = syn.BENCH_DIMS
     den = Denoiser(d["D"], d["C"], d["NL"], d["DS"], d["PQ"], d["PV"], d["H"], 21)
     den.load_state_dict(syn.denoiser_state_dict(d, seed=0, prefix=""))
-    den = den.cuda()
+    den = den.cuda().requires_grad_(False)
     B, K = 256, 128
     g = torch.Generator(device="cuda").manual_seed(0)
     rc = torch.randn(B, K, d["D"], device="cuda", generator=g)
@@ -994,7 +994,7 @@ def test_pair_planes_scale_robustness(hip, scale):
 
     d = syn.BENCH_DIMS
     torch.manual_seed(1)
-    layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda().requires_grad_(False)
     inp = {k: v.cuda() for k, v in syn.patches(2, 128, d, seed=9, coord_sigma=6.0).items()}
     e = inp["pair_context_emb"] * scale
     e[0, 3, 5, 7] = 37.0 * scale  # one element far above the rest: the scale is chosen for it, everything else sits 5 binades lower
