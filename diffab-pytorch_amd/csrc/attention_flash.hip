@@ -559,12 +559,17 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
           *reinterpret_cast<f16x8*>(lds + L_WB + ((1 * 2 + ks) * 64 + lane) * 4) = w2;
         }
       }
-      bscale = scale_t * esc[1] * isw;     // logits: bias = (sum e s w sw) / (s sw)
-      oscale = esc[1] * (1.0f / 256.0f);  // o_e: probabilities enter scaled by 256
+      bscale = scale_t * isw;          // logits: bias = (sum e s_i w sw) / (s_i sw), x 1 / s_i per row in the row-step
+      oscale = 1.0f / 256.0f;          // o_e: probabilities enter scaled by 256
     } else if (wv == 0) {
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg)
         *reinterpret_cast<f32x4*>(lds + L_WB + (sg * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(Wb + hl * AC + 16 * sg + 4 * q);
+    }
+    float inv_s2[2] = {1.0f, 1.0f};  // PLANES: 1 / s_i of this wave's two pair rows (per-row power-of-two scales of the planes)
+    if constexpr (PLANES) {
+      inv_s2[0] = esc[2 * (prow0 + i0 + 2 * wv) + 1];
+      inv_s2[1] = esc[2 * (prow0 + i0 + 2 * wv + 1) + 1];
     }
     float* escr = lds + L_SE + wv * (16 * ELD);
     // PLANES: per-wave [2 planes][16 keys][128 bytes] image of the current tile (4 KiB of the 4.5 KiB slot); 8-byte unit u of row r at
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
       float s_[4], mt = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s_[r] = sv[r] + bscale * accb[r];
+        s_[r] = sv[r] + (bscale * inv_s2[ii]) * accb[r];
         mt = fmaxf(mt, s_[r]);
       }
 #ifdef FLASH_ABL_NOSOFTMAX
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(1024) void ipa_attn_flash16_kernel(const float* __r
         if ((le & 15) < 8) {
           if constexpr (PLANES) {  // D rows 4 q + r <-> channels 16 ct + 4 q + r
             float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + he * AC + 4 * qe;
-            const float sc = inv * oscale;
+            const float sc = inv * oscale * inv_s2[ii];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
               const f32x4 v = {oe[ii][ct][0] * sc, oe[ii][ct][1] * sc, oe[ii][ct][2] * sc, oe[ii][ct][3] * sc};
@@ -1007,7 +1012,7 @@ int launch_attention_flash(const diffab_dims* d, const float* proj, const float*
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFlashLdsBytes)));          \
     timer_begin(st);                                                                                                              \
     hipLaunchKernelGGL((ipa_attn_flash16_kernel<NT_, true>), grid, dim3(1024), kFlashLdsBytes, st, proj, pair_planes + 64, R, t, Wb, \
-                       gamma, feat, d->B, stamps, pair_planes + 1);                                                               \
+                       gamma, feat, d->B, stamps, pair_row_scales(d, pair_planes));                                                               \
     timer_end(st);                                                                                                                \
   } while (0)
   if (pair_planes != nullptr) {  // launch_pair_split() output: producers on the f16 matrix cores (16-wave form only)

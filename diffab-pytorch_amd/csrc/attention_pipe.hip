@@ -142,9 +142,10 @@ __global__ __launch_bounds__(1024) void ipa_attn_pipe_kernel(const float* __rest
           *reinterpret_cast<f16x8*>(lds + L_WB + ((1 * 2 + ks) * 64 + lane) * 4) = w2;
         }
       }
-      bscale = scale_t * esc[1] * isw;     // logits: bias = (sum e s w sw) / (s sw)
-      oscale = esc[1] * (1.0f / 256.0f);  // o_e: probabilities enter scaled by 256
+      bscale = scale_t * isw;          // logits: bias = (sum e s_i w sw) / (s_i sw), x 1 / s_i per row in the row-step
+      oscale = 1.0f / 256.0f;          // o_e: probabilities enter scaled by 256
     }
+    const float inv_s2[2] = {esc[2 * (prow0 + i0 + 2 * wv) + 1], esc[2 * (prow0 + i0 + 2 * wv + 1) + 1]};  // 1 / s_i of the two pair rows
     // per-wave [2 planes][16 keys][128 bytes] image of the current tile; 8-byte unit u of row r at u ^ (4 ((r >> 1) & 3)): the
     // transposed reads of a 32-lane half touch 32 distinct bank pairs
     char* trt = reinterpret_cast<char*>(lds + L_SE + wv * 1152);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(1024) void ipa_attn_pipe_kernel(const float* __rest
       float s_[4], mt = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s_[r] = sv[r] + bscale * accb[r];
+        s_[r] = sv[r] + (bscale * inv_s2[ii]) * accb[r];
         mt = fmaxf(mt, s_[r]);
       }
       mt = xq_max(mt);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(1024) void ipa_attn_pipe_kernel(const float* __rest
         lds[L_LI + he * TI + il] = inv;
         if ((le & 15) < 8) {  // D rows 4 q + r <-> channels 16 ct + 4 q + r
           float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + he * AC + 4 * qe;
-          const float sc = inv * oscale;
+          const float sc = inv * oscale * inv_s2[ii];
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) {
             const f32x4 v = {oe[ii][ct][0] * sc, oe[ii][ct][1] * sc, oe[ii][ct][2] * sc, oe[ii][ct][3] * sc};
@@ -458,7 +459,7 @@ int launch_attention_pipe(const diffab_dims* d, const float* proj, const float* 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPipeLdsBytes)));               \
     timer_begin(st);                                                                                                                  \
     hipLaunchKernelGGL((ipa_attn_pipe_kernel<NT_>), grid, dim3(1024), kPipeLdsBytes, st, proj, pair_planes + 64, R, t, Wb, gamma,     \
-                       feat, d->B, g_pipe_stamps, pair_planes + 1, reinterpret_cast<const f32x4*>(qk_ops), kside);                    \
+                       feat, d->B, g_pipe_stamps, pair_row_scales(d, pair_planes), reinterpret_cast<const f32x4*>(qk_ops), kside);                    \
     timer_end(st);                                                                                                                    \
   } while (0)
   if (d->K == 128) PIPE_LAUNCH(8);

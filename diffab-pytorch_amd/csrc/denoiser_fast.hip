@@ -781,8 +781,8 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
             wp[0][ks][c8] = h1;
             wp[1][ks][c8] = static_cast<_Float16>(x - static_cast<float>(h1));
           }
-        bscale = scale_t * esc[1] * isw;          // logits: bias = (sum e s w sw) / (s sw)
-        oscale = esc[1] * (1.0f / 256.0f);       // o_e: probabilities enter scaled by 256
+        bscale = scale_t * isw;                   // logits: bias = (sum e s_i w sw) / (s_i sw), x 1 / s_i per row below
+        oscale = 1.0f / 256.0f;                   // o_e: probabilities enter scaled by 256
         // the rest of the first row, requested AFTER the weight loads above have been consumed: vmcnt retires in order, a wait for a
         // load issued behind these tiles would wait for all of them (measured: 9 k cycles in front of the barrier)
         asm volatile("" ::"v"(wp[0][0]), "v"(wp[1][0]), "v"(wp[0][1]), "v"(wp[1][1]));
@@ -821,6 +821,8 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int ii = 0; ii < 2; ++ii) {
           const int il = 2 * wv + ii;  // local row
           float* Srow = S + il * IS + h * HS;
+          const float inv_s = esc[2 * (prow0 + i0 + il) + 1];  // 1 / s_i: the power-of-two scale of this pair row's planes
+          const float bscale_r = bscale * inv_s, oscale_r = oscale * inv_s;
           float m_run = -INFINITY, l_run = 0.f, m_hist[NT / 2];
           f32x4 oe[4];
 #pragma unroll
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
               const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                v[4 * tl + r] = sv[r] + bscale * (acc[tl][0][r] + acc[tl][1][r]);
+                v[4 * tl + r] = sv[r] + bscale_r * (acc[tl][0][r] + acc[tl][1][r]);
                 smax = fmaxf(smax, v[4 * tl + r]);
               }
             }
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           // D: column = head l15, row 4 q + r <-> channel 16 ct + 4 q + r
           if (l15 < 8) {
             float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 4 * q;
-            const float sc = cf * oscale;
+            const float sc = cf * oscale_r;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
               f32x4 o = oe[ct];
@@ -1418,29 +1420,36 @@ bool fast_path_supported(const diffab_dims* d) {
 }
 
 // ================================================================== fp16 planes of the pair embedding (PLANES attention kernel)
-// e s = h1 + h2 with h1 = fp16(e s), h2 = fp16(e s - h1), s = the power of two that puts max |e| into [128, 256): two fp16 planes
-// hold e to 2^-23 of the tensor maximum in the same bytes as fp32.  Layout per (patch, query row i): [key tile jt][plane][k-step
+// e s_i = h1 + h2 with h1 = fp16(e s_i), h2 = fp16(e s_i - h1), s_i = the power of two that puts the maximum |e| of PAIR ROW (b, i)
+// - the K x 64 values one query residue sees - into [128, 256): two fp16 planes hold e to 2^-23 of its row's maximum in the same
+// bytes as fp32.  The scale is per row, not per tensor: an outlier anywhere in the (B, K, K, 64) tensor costs precision only in the
+// softmax row that contains it (where it dominates the fp32 sums of the reference just the same); with one scale per tensor a
+// single 1e4 x element would leave every other row ~10 good bits.  Layout per (patch, query row i): [key tile jt][plane][k-step
 // ks][lane = key % 16 + 16 g][8 channels 32 ks + 8 g ..] - each 1 KiB block is one MFMA A fragment of the bias product, so the
 // attention kernel loads fragments with linear 1 KiB wave loads.  Built once per trajectory (the pair embedding does not change
-// between reverse steps) or once per call.
-__global__ void pair_absmax_kernel(const float* __restrict__ e, int64_t n4, unsigned* __restrict__ out_bits) {
+// between reverse steps) or once per call.  Row scales: rs[2 row] = s_i, rs[2 row + 1] = 1 / s_i.
+__global__ __launch_bounds__(256) void pair_rowscale_kernel(const float* __restrict__ e, int row_f4, float* __restrict__ rs) {
+  const int64_t row = blockIdx.x;
+  const f32x4* p = reinterpret_cast<const f32x4*>(e) + row * row_f4;
   float m = 0.f;
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(e)[i];
+  for (int i = threadIdx.x; i < row_f4; i += 256) {
+    const f32x4 v = p[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned b = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));  // NaN rows: fmaxf drops NaNs -> scale of the finite part
+    const int ex = static_cast<int>((b >> 23) & 255u);
+    const bool ok = ex > 0 && ex < 231 && b < 0x7f800000u;  // zero / subnormal / huge / inf maximum: no scaling (inf / nan propagate as in fp32)
+    rs[2 * row] = ok ? __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ex) << 23) : 1.0f;
+    rs[2 * row + 1] = ok ? __uint_as_float(static_cast<unsigned>(ex - 7) << 23) : 1.0f;
+  }
 }
-__global__ void pair_scale_kernel(const unsigned* __restrict__ max_bits, float* __restrict__ esc) {
-  const unsigned b = *max_bits;
-  const int ex = static_cast<int>((b >> 23) & 255u);
-  const bool ok = ex > 0 && ex < 231 && b < 0x7f800000u;  // zero / subnormal / huge / inf-nan maximum: no scaling (inf / nan propagate as in fp32)
-  esc[0] = ok ? __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ex) << 23) : 1.0f;
-  esc[1] = ok ? __uint_as_float(static_cast<unsigned>(ex - 7) << 23) : 1.0f;
-}
-__global__ void pair_split_kernel(const float* __restrict__ e, const float* __restrict__ esc, int K, int64_t n_groups,
+__global__ void pair_split_kernel(const float* __restrict__ e, const float* __restrict__ rs, int K, int64_t n_groups,
                                   _Float16* __restrict__ out) {
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;  // (row (b, i), key j, 8-channel group cg)
   if (gid >= n_groups) return;
@@ -1448,7 +1457,7 @@ __global__ void pair_split_kernel(const float* __restrict__ e, const float* __re
   const int64_t rj = gid >> 3;
   const int j = static_cast<int>(rj % K);
   const int64_t row = rj / K;
-  const float s = esc[0];
+  const float s = rs[2 * row];
   const f32x4 v0 = reinterpret_cast<const f32x4*>(e)[gid * 2], v1 = reinterpret_cast<const f32x4*>(e)[gid * 2 + 1];
   f16x8 h1, h2;
 #pragma unroll
@@ -1464,20 +1473,20 @@ __global__ void pair_split_kernel(const float* __restrict__ e, const float* __re
   *reinterpret_cast<f16x8*>(base + 1024) = h2;   // plane 1: blocks (1, ks)
 }
 bool pair_planes_supported(const diffab_dims* d) { return fast_path_supported(d); }  // any K the fused kernel takes (K % 64 == 0)
-size_t pair_planes_floats(const diffab_dims* d) {  // planes + {max bits, s, 1 / s} (64 floats)
-  return pair_planes_supported(d) ? static_cast<size_t>(d->B) * d->K * d->K * AC + 64 : 0;
+size_t pair_planes_floats(const diffab_dims* d) {  // 64 (alignment) | planes | row scales {s, 1 / s} per pair row
+  return pair_planes_supported(d) ? static_cast<size_t>(d->B) * d->K * d->K * AC + 64 + 2 * static_cast<size_t>(d->B) * d->K + 64 : 0;
 }
-// planes: pair_planes_floats(d) floats, 256-byte aligned; afterwards PairPlanes{planes + 64, planes + 1} feeds ipa_layer_fast
+// the row scales inside a launch_pair_split() buffer (the planes themselves start at planes + 64)
+const float* pair_row_scales(const diffab_dims* d, const float* planes) { return planes + 64 + static_cast<size_t>(d->B) * d->K * d->K * AC; }
+// planes: pair_planes_floats(d) floats, 256-byte aligned
 int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipStream_t st) {
   DIFFAB_REQUIRE(pair_planes_supported(d) && e && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(e) & 15) == 0,
                  DIFFAB_ERR_ARG, "pair_split: unsupported operands");
   const int64_t n = static_cast<int64_t>(d->B) * d->K * d->K * AC;
-  unsigned* bits = reinterpret_cast<unsigned*>(planes);
-  DIFFAB_HIP_CHECK(hipMemsetAsync(bits, 0, 4, st));
-  hipLaunchKernelGGL(pair_absmax_kernel, dim3(2048), dim3(256), 0, st, e, n / 4, bits);
-  hipLaunchKernelGGL(pair_scale_kernel, dim3(1), dim3(1), 0, st, bits, planes + 1);
-  hipLaunchKernelGGL(pair_split_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, st, e, planes + 1, d->K, n / 8,
+  float* rs = const_cast<float*>(pair_row_scales(d, planes));
+  hipLaunchKernelGGL(pair_rowscale_kernel, dim3(d->B * d->K), dim3(256), 0, st, e, d->K * AC / 4, rs);
+  hipLaunchKernelGGL(pair_split_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, st, e, rs, d->K, n / 8,
                      reinterpret_cast<_Float16*>(planes + 64));
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
@@ -1657,7 +1666,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
     hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, false, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R, t,      \
-                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_planes + 1);                                     \
+                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_row_scales(d, pair_planes));                                     \
     timer_end(st);                                                                                                                    \
   } while (0)
 #define ATTN_LAUNCH_B6L(NT_, MULTI_)                                                                                                  \
@@ -1666,7 +1675,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
     hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, false, true, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R,   \
-                       t, w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_planes + 1,                                   \
+                       t, w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_row_scales(d, pair_planes),                                   \
                        reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
     timer_end(st);                                                                                                                    \
   } while (0)

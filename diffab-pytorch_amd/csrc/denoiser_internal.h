@@ -35,6 +35,7 @@ int launch_proj_planes_b6(const float* x, const void* planes, const float* R, co
 bool pair_planes_supported(const diffab_dims* d);
 size_t pair_planes_floats(const diffab_dims* d);
 int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipStream_t st);
+const float* pair_row_scales(const diffab_dims* d, const float* planes);  // {s_i, 1 / s_i} per pair row (b, i) of a launch_pair_split() buffer
 // Y = act(X W^T + b) on MFMA; requires Kd % 4 == 0 (falls back to the generic kernel otherwise)
 int launch_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int Kd, bool relu,
                   hipStream_t st);

@@ -3,7 +3,8 @@ size-independent properties of the domain - finiteness, context preservation, or
 invariance under sharding of the batch (what makes the N > 1 runs correct by construction) - on the MFMA path.
 
   config 2: B = 256, K = 128, 100 reverse steps (T = 100)            -> test_config2_...
-  config 3: B = 2048 over 8 GPUs = 256 per GPU: config 2's shape; the shard test keys noise by the global patch id
+  config 3: B = 2048 over 8 GPUs = 256 per GPU, SAbDab-shaped RAW batch (15 atoms, chain ids, no distmat, no contexts):
+            encode_context + 100 steps at the per-GPU share                 -> test_config3_...
   config 4: training step, B = 1024 over 8 GPUs = 128 per GPU, NL = 6 -> test_config4_...
   config 5: B = 512, K = 256, 200 reverse steps on the T = 200 schedule -> test_config5_...
 """
@@ -58,10 +59,12 @@ def bench_model(T_steps, NL=None):
     return d, model
 
 
-def check_trajectory(model, inp, seed, shard, n_steps_expected):
-    """Full reverse trajectory + the properties listed in the module docstring; `shard` = (lo, hi) patches re-run alone."""
-    kw = lambda sl: dict(res_context_emb=inp["res_context_emb"][sl], pair_context_emb=inp["pair_context_emb"][sl],
-                         generation_mask=inp["generation_mask"][sl])
+def check_trajectory(model, inp, seed, shard, n_steps_expected, kw=None):
+    """Full reverse trajectory + the properties listed in the module docstring; `shard` = (lo, hi) patches re-run alone.
+    kw(slice) -> the keyword arguments of DiffAb.sample for those patches (default: precomputed contexts)."""
+    if kw is None:
+        kw = lambda sl: dict(res_context_emb=inp["res_context_emb"][sl], pair_context_emb=inp["pair_context_emb"][sl],
+                             generation_mask=inp["generation_mask"][sl])
     all_ = slice(None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -72,11 +75,13 @@ def check_trajectory(model, inp, seed, shard, n_steps_expected):
     assert model.T == n_steps_expected
     gm = inp["generation_mask"]
     assert torch.isfinite(full["translations"]).all() and torch.isfinite(full["orientations"]).all()
-    assert torch.equal(full["translations"][~gm], inp["translations"][~gm])  # context residues are never touched
+    x_ctx = inp["translations"] if inp["translations"].dim() == 3 else inp["translations"][:, :, 1]
+    assert torch.equal(full["translations"][~gm], x_ctx[~gm])  # context residues are never touched
     assert torch.equal(full["orientations"][~gm], inp["orientations"][~gm])
     assert torch.equal(full["seq_idx"][~gm], inp["seq_idx"][~gm])
     assert ((full["seq_idx"] >= 0) & (full["seq_idx"] < 21)).all()
-    assert not torch.equal(full["translations"][gm], inp["translations"][gm])
+    x_in = inp["translations"] if inp["translations"].dim() == 3 else inp["translations"][:, :, 1]  # CA of an all-atom batch
+    assert not torch.equal(full["translations"][gm], x_in[gm])
     Og = full["orientations"][gm]
     err = (Og.transpose(-1, -2) @ Og - torch.eye(3, device=Og.device)).abs().max()
     assert err < 1e-3, float(err)  # every step re-derives O from exp maps: stays a rotation over the whole trajectory
@@ -135,3 +140,38 @@ def test_config4_training_step_b128_nl6(hip):
         assert not torch.equal(p.detach(), before[n]), n
     print(f"config 4 (per-GPU share): B=128 K=128 NL=6 training step {1e3 * min(times):.2f} ms = "
           f"{128 * 128 / min(times) / 1e6:.2f} M residue-steps/s")
+
+
+def test_config3_share_raw_sabdab_batch_b256_k128(hip):
+    """Per-GPU share of config 3 (2048 SAbDab-shaped patches over 8 GPUs): the RAW batch of the reference's data module - all-atom
+    xyz (A = 15), chain ids in {1, 2, 3}, atom mask, no distance tensor, no precomputed contexts (data.py:82-96) - at B = 256,
+    K = 128: DiffAb.sample runs encode_context itself (features from xyz on the device), then 100 reverse steps.  Trajectory
+    properties as for config 2, shard invariance included (what the 8-GPU all-gather relies on), and encode_context at K = 128
+    against the oracle on a 4-patch slice."""
+    from conftest import maxrel
+
+    dims, model = bench_model(100)
+    csd = syn.context_state_dict(dims["D"], dims["C"], 15, 32, seed=3)
+    model.load_state_dict(csd, strict=False)
+    B, K = 256, 128
+    cb = syn.context_batch(B, K, 15, seed=3, with_distmat=False)
+    dev = {k: v.cuda() for k, v in cb.items() if k != "distmat"}
+    inp = {"seq_idx": dev["seq_idx"], "translations": dev["xyz"], "orientations": dev["orientations"], "generation_mask": dev["generation_mask"]}
+    kw = lambda sl: dict(generation_mask=dev["generation_mask"][sl], atom_mask=dev["atom_mask"][sl], chain_idx=dev["chain_idx"][sl],
+                         residue_mask=dev["residue_mask"][sl])
+    rate, dt = check_trajectory(model, inp, seed=13, shard=(96, 100), n_steps_expected=100, kw=kw)
+    print(f"config 3 (per-GPU share): raw batch B=256 K=128 -> encode_context + 100 steps in {dt:.3f} s = {rate / 1e6:.2f} M residue-steps/s")
+    # encode_context at K = 128 against the oracle (4 patches; the oracle takes the distance tensor, built here on the host)
+    sl = slice(8, 12)
+    xyz4 = cb["xyz"][sl].double()
+    dist4 = (xyz4[:, :, None, :, None, :] - xyz4[:, None, :, None, :, :]).norm(dim=-1).float()
+    feats = __import__("diffab_pytorch").features.featurize(dev["xyz"][sl], dev["chain_idx"][sl], dev["residue_mask"][sl], orientations=False)
+    b4 = {k: (v if k == "residue_idx" else v[sl]) for k, v in cb.items() if k != "distmat"}
+    b4["distmat"] = dist4
+    b4["backbone_dihedrals"], b4["pairwise_dihedrals"] = feats["backbone_dihedrals"].cpu(), feats["pairwise_dihedrals"].cpu()
+    with torch.no_grad():
+        res, pair = model.encode_context(dev["seq_idx"][sl], dev["xyz"][sl], dev["orientations"][sl], feats["backbone_dihedrals"], None,
+                                         feats["pairwise_dihedrals"], dev["atom_mask"][sl], dev["chain_idx"][sl], dev["residue_idx"],
+                                         dev["generation_mask"][sl], dev["residue_mask"][sl])
+    res_o, pair_o = orc.encode_context(csd, b4, True, True)
+    assert maxrel(res, res_o) < 2e-5 and maxrel(pair, pair_o) < 2e-5, (maxrel(res, res_o), maxrel(pair, pair_o))

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import diffab_oracle as orc
-from conftest import elemrel, maxrel
+from conftest import elemrel, elemrel_by_decade, maxrel
 from diffab_pytorch import _hip, synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -299,10 +299,13 @@ def test_denoiser_vs_reference_goldens(hip, golden, name, flags):
     for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
         assert torch.isfinite(out[k]).all(), k
         assert maxrel(out[k], g[k]) < TOL, (name, k, maxrel(out[k], g[k]))
-    # element-wise form of the bar (north_star: "aa-type logits and translations within 1e-4 rel"): every element above 1e-3 of
-    # the tensor's maximum individually, not only the tensor-global norm
+    # element-wise form of the bar (north_star: "aa-type logits and translations within 1e-4 rel"): every element above 1 % of the
+    # tensor's maximum individually (conftest.elemrel: below that the reference's own fp32-vs-fp64 noise exceeds 1e-4 of the
+    # element), not only the tensor-global norm; the worst element-wise error per decade of magnitude is printed
     for k in ("aa_logits", "translations_eps"):
         assert elemrel(out[k], g[k]) < TOL, (name, k, elemrel(out[k], g[k]))
+        print(f"{name} flags={flags} {k}: worst element-wise relative error per decade of |ref| / max|ref|:",
+              {f"1e-{d_}": f"{v_:.1e}" for d_, v_ in elemrel_by_decade(out[k], g[k]).items()})
     l0 = den.ipa.layers[0](inp["res_context_emb"], inp["pair_context_emb"], inp["orientations"], inp["translations"], flags=flags)
     assert maxrel(l0, g["ipa_layer0"]) < TOL
     # masks are ignored by the denoiser exactly like the reference (diffab_pytorch.py:566-567)
@@ -490,9 +493,66 @@ def test_reverse_step_teacher_forced_vs_oracle(hip):
         s1, x1, O1 = orc.reverse_update(t, inp["seq_idx"], inp["translations"], inp["orientations"], den, gm, sched, z, rotvec, us)
         assert maxrel(got["translations"], x1) < TOL, t
         assert maxrel(got["orientations"], O1) < TOL, t
-        assert (got["seq_idx"] == s1).float().mean() > 0.97, t  # a draw can flip only when u sits on a CDF edge
+        diff = got["seq_idx"] != s1  # a draw can flip only when u sits on an edge of the posterior's CDF
+        if diff.any():
+            edge = (den["seq_posterior"].double().cumsum(-1) - us.double()[..., None]).abs().min(dim=-1).values
+            assert float(edge[diff].max()) < 1e-5, (t, int(diff.sum()), float(edge[diff].max()))
         assert torch.equal(got["translations"][~gm], inp["translations"][~gm])
         assert torch.equal(got["seq_idx"][~gm], inp["seq_idx"][~gm])
+
+
+@pytest.mark.parametrize("K", [128, 256])
+def test_reverse_step_teacher_forced_at_benchmark_geometry(hip, K):
+    """The path bench.py times - diffab_sample_loop on the MFMA kernels with prepared weight planes, the fp16 pair planes and
+    reverse_update_philox - teacher-forced against the oracle at the benchmark dims: K = 128 (single-chunk planes kernel) and
+    K = 256 (chunked planes kernel), B = 2, NL = 2, t in {100, 57, 8, 2, 1}.  x and O within 1e-4; every sequence draw that differs
+    from the oracle's must sit on an edge of the posterior's CDF (the draw is u < cumsum(p): a 1e-6 difference in p flips it only
+    there), and their number is printed."""
+    from diffab_pytorch import DiffAb
+
+    dims = dict(syn.BENCH_DIMS, NL=2)
+    torch.manual_seed(0)
+    model = DiffAb(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"]).cuda()
+    sd0 = syn.denoiser_state_dict(dims, seed=19, prefix="")
+    model.denoiser.load_state_dict(sd0)
+    sd = {"denoiser." + k: v for k, v in sd0.items()}
+    sched = orc.cosine_variance_schedule(100, s=0.01, beta_max=0.999)
+    B, seed = 2, 4242
+    inp = syn.patches(B, K, dims, seed=40 + K, coord_sigma=6.0)
+    gm = inp["generation_mask"].clone()
+    gm[:, : K // 2] = True  # half of every patch is generated: enough draws to see CDF-edge flips
+    rev = model._reverse_so3()
+    sig = sched["beta"].sqrt()
+    flips = 0
+    for t in (100, 57, 8, 2, 1):
+        got = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], res_context_emb=inp["res_context_emb"],
+                           pair_context_emb=inp["pair_context_emb"], generation_mask=gm, seed=seed, first_patch=3, t_start=t,
+                           t_stop=t - 1, init=False)
+        patch = (3 + np.arange(B))[:, None] + np.zeros((B, K), dtype=np.int64)
+        res = np.zeros((B, K), dtype=np.int64) + np.arange(K)[None, :]
+        z = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, orc.STREAM_TRANS)[:3], -1))
+        ax = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, orc.STREAM_AXIS)[:3], -1))
+        ua = orc.philox_uniform4(seed, patch, res, t, orc.STREAM_ANGLE)
+        na = orc.philox_normal4(seed, patch, res, t, orc.STREAM_ANGLE)
+        us = torch.from_numpy(orc.philox_uniform4(seed, patch, res, t, orc.STREAM_SEQ)[0])
+        cdf_row = rev._cdf[t].cpu()[None, None, :].expand(B, K, -1)
+        th_h = orc.igso3_theta_from_hist(orc.igso3_bin_from_cdf(cdf_row, torch.from_numpy(ua[0])), torch.from_numpy(ua[1]))
+        th_g = orc.igso3_theta_from_gaussian(sig[t].expand(B, K), torch.from_numpy(na[2]))
+        rotvec = orc.igso3_rotvec(ax, th_h, th_g, sig[t].expand(B))
+        den = orc.denoiser(sd, inp["seq_idx"], inp["translations"], inp["orientations"], inp["res_context_emb"], inp["pair_context_emb"],
+                           sched["beta"][t].expand(B), dims["NL"], dims["H"])
+        s1, x1, O1 = orc.reverse_update(t, inp["seq_idx"], inp["translations"], inp["orientations"], den, gm, sched, z, rotvec, us)
+        assert maxrel(got["translations"], x1) < TOL, (K, t, maxrel(got["translations"], x1))
+        assert maxrel(got["orientations"], O1) < TOL, (K, t, maxrel(got["orientations"], O1))
+        diff = (got["seq_idx"].cpu() != s1)
+        if diff.any():  # each flipped draw: u within 1e-5 of a cumulative-probability edge of the oracle's posterior
+            cdf = den["seq_posterior"].double().cumsum(-1)
+            edge = (cdf - us.double()[..., None]).abs().min(dim=-1).values
+            assert float(edge[diff].max()) < 1e-5, (K, t, float(edge[diff].max()))
+            flips += int(diff.sum())
+        assert torch.equal(got["translations"].cpu()[~gm], inp["translations"][~gm])
+        assert torch.equal(got["seq_idx"].cpu()[~gm], inp["seq_idx"][~gm])
+    print(f"teacher-forced reverse steps at the benchmark geometry, K={K}: {flips} of {5 * int(gm.sum())} sequence draws on a CDF edge")
 
 
 def test_explicit_noise_reverse_update_vs_oracle(hip):
@@ -1005,3 +1065,33 @@ def test_pair_planes_scale_robustness(hip, scale):
     got = layer(*args, flags=_hip.FLAG_PAIR_PLANES)
     assert torch.isfinite(got).all()
     assert maxrel(got, ref) < 2e-6, (scale, maxrel(got, ref))
+
+
+def test_pair_planes_outlier_stays_in_its_row(hip):
+    """A trained PairEmbedding has no norm layer: one element 1e4 x the rest must not cost the other rows their precision.  The planes
+    carry one power-of-two scale per PAIR ROW (b, i) (csrc/denoiser_fast.hip, pair_rowscale_kernel): rows that do not contain the
+    outlier keep the full 2^-23 of their own maximum.  Compared with the fp32-pair kernel on the same inputs: every output row of a
+    query residue whose pair row is outlier-free agrees to 2e-6 of the output maximum; the row that holds the outlier (query 3 of patch
+    0: its attention is one-hot on the outlier's key for the heads with a non-zero bias weight, in both kernels) is held to the 1e-4
+    bar."""
+    from diffab_pytorch.diffab_pytorch import InvariantPointAttentionLayer
+
+    d = syn.BENCH_DIMS
+    torch.manual_seed(1)
+    layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda().requires_grad_(False)
+    inp = {k: v.cuda() for k, v in syn.patches(2, 128, d, seed=9, coord_sigma=6.0).items()}
+    e = inp["pair_context_emb"].clone()
+    e[0, 3, 5, 7] = 1.0e4
+    args = (inp["res_context_emb"], e, inp["orientations"], inp["translations"])
+    ref = layer(*args)
+    got = layer(*args, flags=_hip.FLAG_PAIR_PLANES)
+    assert torch.isfinite(got).all()
+    clean = torch.ones(2, 128, dtype=torch.bool, device=got.device)
+    clean[0, 3] = False
+    scale = float(ref.abs().max())
+    err_clean = float((got - ref)[clean].abs().max()) / scale
+    err_row = float((got - ref)[~clean].abs().max()) / scale
+    print(f"pair planes with a 1e4 x outlier: outlier-free rows {err_clean:.2e}, the outlier's row {err_row:.2e} (of the output maximum)")
+    assert err_clean < 2e-6, err_clean
+    assert err_row < TOL, err_row
+
