@@ -425,6 +425,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None if args.split_attention else traffic,  # the PMC file under profiles/ is for the fused kernel
+                # not measured in this run: rocprofv3 --pmc passes of this same command (FETCH_SIZE x 2 + WRITE_SIZE per launch,
+                # tools/profile_round.sh), committed as profiles/roofline_traffic.json
+                "traffic_source": None if (args.split_attention or traffic is None) else "profiles/roofline_traffic.json (committed rocprofv3 --pmc passes, not this run)",
                 "launches": launches.value,
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg,

@@ -5,6 +5,9 @@
 
 #include "common.h"
 #include "denoiser_internal.h"
+#ifdef DIFFAB_EXPERIMENTAL
+#include "../../include/diffab_hip_experimental.h"
+#endif
 
 namespace diffab {
 
@@ -93,7 +96,7 @@ static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weigh
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
     return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : ((flags & DIFFAB_FLAG_FLASH_ATTENTION) ? 3 : 0)),
-                          sp_keep, d2_keep, planes, pair_planes);
+                          sp_keep, d2_keep, planes, pair_planes, nullptr, (flags & DIFFAB_FLAG_FP32_GEMM) != 0);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -107,23 +110,20 @@ static int mlp3(const diffab_dims* d, const diffab_mlp3_weights* w, const float*
 }
 
 static bool use_pair_planes(const diffab_dims* d, uint32_t flags, const float* pair_ctx, const StepBuffers& b) {
-  static const bool env_off = [] {
-    const char* e = getenv("DIFFAB_PAIR_F32");  // =1: keep the fp32 pair stream (A/B timing)
-    return e != nullptr && atoi(e) != 0;
-  }();
-  const uint32_t other = DIFFAB_FLAG_FORCE_GENERIC | DIFFAB_FLAG_SPLIT_ATTENTION | DIFFAB_FLAG_EXTERNAL_LOGITS | DIFFAB_FLAG_FLASH_ATTENTION;
-  return (flags & DIFFAB_FLAG_PAIR_PLANES) && !(flags & other) && !env_off && b.pair != nullptr && pair_planes_supported(d) &&
+  const uint32_t other = DIFFAB_FLAG_FORCE_GENERIC | DIFFAB_FLAG_SPLIT_ATTENTION | DIFFAB_FLAG_EXTERNAL_LOGITS | DIFFAB_FLAG_FLASH_ATTENTION |
+                         DIFFAB_FLAG_PAIR_F32;
+  return (flags & DIFFAB_FLAG_PAIR_PLANES) && !(flags & other) && b.pair != nullptr && pair_planes_supported(d) &&
          (reinterpret_cast<uintptr_t>(pair_ctx) & 15) == 0;
 }
 
 // Everything on the folded MFMA path that depends on the weights only: the sequence-embedding bias table and the split bf16 planes
 // of every dense weight matrix.  Once per denoise_step call - or once per trajectory (diffab_sample_loop).
-static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* w, const StepBuffers& b, hipStream_t st) {
+static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* w, const StepBuffers& b, uint32_t flags, hipStream_t st) {
   DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0 && w->coord.w2 && w->orient.w2 &&
                      w->seq.w2,
                  DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
   if (int rc = launch_fold_tables(d, w, nullptr, b.emb_tab, nullptr, st)) return rc;
-  if (!use_b6_gemm()) return DIFFAB_OK;
+  if (!use_b6_gemm(flags)) return DIFFAB_OK;
   const int D = d->D;
   for (int l = 0; l < d->NL; ++l)
     if (int rc = ipa_layer_split_weights(&w->layers[l], b.planes + l * ipa_layer_planes_bytes(), st)) return rc;
@@ -162,11 +162,11 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0, DIFFAB_ERR_ARG,
                    "denoiser head: null weight pointer");
     if (!weights_prepared)
-      if (int rc = prepare_weights(d, w, b, st)) return rc;
+      if (int rc = prepare_weights(d, w, b, flags, st)) return rc;
     if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, true)) return rc;
   }
   // dense N = 128 layers of the folded path: bf16x6 from the prepared planes (slot), or the fp32 kernel
-  const bool b6 = fold && use_b6_gemm() && rowgemm128_b6_ok(res_ctx, D, b.h1, D, rows, D);
+  const bool b6 = fold && use_b6_gemm(flags) && rowgemm128_b6_ok(res_ctx, D, b.h1, D, rows, D);
   const char* mlp = b6 ? b.planes + d->NL * ipa_layer_planes_bytes() : nullptr;
   auto dense128 = [&](int slot, const float* X, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                       bool relu) -> int {
@@ -174,10 +174,7 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     return launch_rowgemm128(X, D, W, ldw, bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
   };
   // DIFFAB_MLP_UNFUSED=1: one launch per dense layer (A/B timing); default: each MLP as one row-resident kernel (mlp_chain_b6_kernel)
-  static const bool chain_env = [] {
-    const char* e = getenv("DIFFAB_MLP_UNFUSED");
-    return e == nullptr || atoi(e) == 0;
-  }();
+  static const bool chain_env = env_int("DIFFAB_MLP_UNFUSED", 0) == 0;
   const bool chain = b6 && chain_env && d->V <= 128;
   if (fold && chain) {
     const void* pl[2] = {mlp, mlp + mlp_planes_bytes()};
@@ -193,7 +190,7 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   }
   float *cur = b.hA, *nxt = b.hB;
   for (int l = 0; l < d->NL; ++l) {
-    const void* planes = (fold && use_b6_gemm()) ? b.planes + l * ipa_layer_planes_bytes() : nullptr;
+    const void* planes = (fold && use_b6_gemm(flags)) ? b.planes + l * ipa_layer_planes_bytes() : nullptr;
     if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes, pair_planes))
       return rc;
     float* tmp = cur; cur = nxt; nxt = tmp;
@@ -234,7 +231,7 @@ static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weight
   if (int rc = launch_embed_concat(res_ctx, w->seq_emb, seq_t, D, rows, tp.cat2, st)) return rc;
   if (int rc = launch_linear(tp.cat2, 2 * D, w->res_w0, w->res_b0, tp.h1, D, rows, D, 2 * D, true, st)) return rc;
   if (int rc = launch_linear(tp.h1, D, w->res_w2, w->res_b2, tp.x[0], D, rows, D, D, false, st)) return rc;
-  const bool b6 = tp.planes && use_b6_gemm() && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d);
+  const bool b6 = tp.planes && use_b6_gemm(flags) && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d);
   for (int l = 0; l < d->NL; ++l) {
     if (b6)
       if (int rc = ipa_layer_split_weights(&w->layers[l], tp.planes, st)) return rc;
@@ -312,6 +309,7 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
   return launch_rowgemm128_b6(X, Kd, W, Kd, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, scratch, st);
 }
 
+#ifdef DIFFAB_EXPERIMENTAL  // include/diffab_hip_experimental.h
 size_t diffab_debug_proj_planes_scratch_bytes(const diffab_dims* d) {
   if (check_dims(d, "debug_proj_planes_scratch_bytes")) return 0;
   return align_up(proj_planes_scratch_bytes(), 256) + align_up(static_cast<size_t>(d->B) * 16, 256);
@@ -332,6 +330,7 @@ int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weight
   if (int rc = launch_patch_centroids(t, d->B, d->K, cent, st)) return rc;
   return launch_proj_planes_b6(x, planes, R, t, cent, w->gamma, qk_out, proj_out, d->B * d->K, d->K, st);
 }
+#endif
 
 int diffab_debug_set_attn_stamps(void* device_buffer) {
   set_attn_stamps(device_buffer);
@@ -506,7 +505,7 @@ int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weig
   hipStream_t st = as_stream(stream);
   const size_t nb = sizeof(float) * static_cast<size_t>(d->B) * d->K * d->D;
   DIFFAB_HIP_CHECK(hipMemcpyAsync(tp.x[0], x, nb, hipMemcpyDeviceToDevice, st));
-  const bool b6 = tp.planes && use_b6_gemm() && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(&d1);
+  const bool b6 = tp.planes && use_b6_gemm(flags) && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(&d1);
   if (b6)
     if (int rc = ipa_layer_split_weights(w, tp.planes, st)) return rc;
   if (int rc = ipa_layer_dispatch(&d1, w, tp.x[0], e, R, t, tp.x[1], tp.ipa_ws[0], flags, st, tp.sp[0], tp.d2[0], b6 ? tp.planes : nullptr))
@@ -547,9 +546,9 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
   const bool fold = !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d) &&
                     rowgemm128_ok(res_ctx, d->D, b0.h1, d->D, d->B * d->K, d->D);
   if (fold)
-    if (int rc = prepare_weights(d, w, b0, st)) return rc;
+    if (int rc = prepare_weights(d, w, b0, flags, st)) return rc;
   // the pair embedding is the same tensor in all T x NL attention launches of a trajectory: its fp16 planes are built once here
-  flags |= DIFFAB_FLAG_PAIR_PLANES;
+  if (!(flags & DIFFAB_FLAG_PAIR_F32)) flags |= DIFFAB_FLAG_PAIR_PLANES;
   const bool pair_ready = use_pair_planes(d, flags, pair_ctx, b0);
   if (pair_ready)
     if (int rc = launch_pair_split(d, pair_ctx, b0.pair, st)) return rc;

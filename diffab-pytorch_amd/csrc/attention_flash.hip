@@ -993,10 +993,7 @@ int launch_attention_flash(const diffab_dims* d, const float* proj, const float*
                        stamps);                                                                                                   \
     timer_end(st);                                                                                                                \
   } while (0)
-  static const int waves = [] {
-    const char* v = getenv("DIFFAB_FLASH_WAVES");
-    return v ? atoi(v) : 16;
-  }();
+  static const int waves = env_int("DIFFAB_FLASH_WAVES", 16);
 #define FLASH16_LAUNCH(NT_)                                                                                                       \
   do {                                                                                                                            \
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_flash16_kernel<NT_>),                             \

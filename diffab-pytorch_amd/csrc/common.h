@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/diffab_hip.h"
 
@@ -38,6 +39,18 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Kernel-variant switches for A/B timing are read from the environment in EXPERIMENTAL builds only (`make EXPERIMENTAL=1` ->
+// build_exp/libdiffab_hip.so, selected by tools/ through DIFFAB_HIP_LIB); the product library never calls getenv and has no
+// process-global configuration.
+#ifdef DIFFAB_EXPERIMENTAL
+static inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e != nullptr ? atoi(e) : dflt;
+}
+#else
+static inline int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

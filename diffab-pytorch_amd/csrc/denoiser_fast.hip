@@ -1166,7 +1166,9 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);
+#ifdef DIFFAB_EXPERIMENTAL
   set_attn_pipe_stamps(p);
+#endif
 }
 
 // in-place local -> global for the three point blocks of the projection buffer (row-vector convention, :324)
@@ -1493,36 +1495,35 @@ int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipSt
 }
 
 
-// DIFFAB_FP32_GEMM=1: the dense projections on the f32-input MFMA kernels of this file instead of the bf16x6 kernels
-// (gemm_bf16x6.hip; same results to fp32 rounding) - for A/B timing and as the plain-fp32 reference path
-bool use_b6_gemm() {
-  static const bool v = [] {
-    const char* e = getenv("DIFFAB_FP32_GEMM");
-    return e == nullptr || atoi(e) == 0;
-  }();
+// DIFFAB_FLAG_FP32_GEMM: the dense projections on the f32-input MFMA kernels of this file instead of the bf16x6 kernels
+// (gemm_bf16x6.hip; same results to fp32 rounding) - the plain-fp32 reference path (experimental builds: also DIFFAB_FP32_GEMM=1)
+bool use_b6_gemm(uint32_t flags) {
+  static const bool v = env_int("DIFFAB_FP32_GEMM", 0) == 0;
+  return v && !(flags & DIFFAB_FLAG_FP32_GEMM);
+}
+#ifdef DIFFAB_EXPERIMENTAL
+// DIFFAB_OPERAND_PLANES=1: phase 1 of the planes attention kernel from the operand planes of proj_planes.hip (logits on the bf16 matrix
+// cores) instead of the fp32 projection buffer.  Measured (profiles/r03_operand_planes.md): not faster at K = 128 / 256 - the
+// phases of the attention kernel are bound by the bytes a CU can pull, and the planes are 1.5 x the bytes - so it is not the default.
+static bool operand_planes_enabled(const diffab_dims*) {
+  static const bool v = env_int("DIFFAB_OPERAND_PLANES", 0) != 0;
   return v;
 }
-// DIFFAB_OPERAND_PLANES: 1 = phase 1 of the planes attention kernel from the operand planes of proj_planes.hip (logits on the bf16 matrix
-// cores), 0 = from the fp32 projection buffer; unset = the measured default per shape (operand_planes_default)
-static int operand_planes_env() {
-  static const int v = [] {
-    const char* e = getenv("DIFFAB_OPERAND_PLANES");
-    return e == nullptr ? -1 : (atoi(e) != 0 ? 1 : 0);
-  }();
-  return v;
-}
-static bool operand_planes_default(const diffab_dims*) { return false; }  // measured (profiles/r03_operand_planes.md): not faster at K = 128 / 256
-static bool operand_planes_enabled(const diffab_dims* d) { return operand_planes_env() < 0 ? operand_planes_default(d) : operand_planes_env() == 1; }
+#endif
 static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
-size_t ipa_layer_planes_bytes() {
-  return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)) + round256(proj_planes_scratch_bytes());
-}
+#ifdef DIFFAB_EXPERIMENTAL
 static size_t pp_planes_offset() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
+size_t ipa_layer_planes_bytes() { return pp_planes_offset() + round256(proj_planes_scratch_bytes()); }
+#else
+size_t ipa_layer_planes_bytes() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
+#endif
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st) {
   DIFFAB_REQUIRE(w && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && w->w_out, DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
   if (int rc = launch_pjsplit(W6, planes, st)) return rc;
+#ifdef DIFFAB_EXPERIMENTAL
   if (int rc = launch_ppsplit(W6, static_cast<char*>(planes) + pp_planes_offset(), st)) return rc;  // operand-plane projections (proj_planes.hip)
+#endif
   return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + round256(proj_frames_b6_scratch_bytes()), st);
 }
 static size_t b6_scratch_floats() { return (ipa_layer_planes_bytes() + 256) / sizeof(float); }
@@ -1534,6 +1535,7 @@ static size_t ipa_ws_operands_offset(const diffab_dims* d) {
   const size_t o = rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0) + b6_scratch_floats();
   return (o + 63) & ~static_cast<size_t>(63);
 }
+#ifdef DIFFAB_EXPERIMENTAL
 size_t ipa_fast_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
   return ipa_ws_operands_offset(d) + 64 + proj_planes_operand_floats(rows) + 4 * static_cast<size_t>(d->B) + 64;
@@ -1542,17 +1544,20 @@ float* ipa_fast_centroid_slot(const diffab_dims* d, float* ws) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
   return ws + ipa_ws_operands_offset(d) + 64 + proj_planes_operand_floats(rows);
 }
+#else
+size_t ipa_fast_workspace_floats(const diffab_dims* d) { return ipa_ws_operands_offset(d); }
+#endif
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep, const void* planes,
-                   const float* pair_planes, const float* cent) {
+                   const float* pair_planes, const float* cent, bool fp32_gemm) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
   // Dense projections on the bf16 matrix cores (gemm_bf16x6.hip) from split weight planes: the caller's (reverse sampler: split once
   // per trajectory) or, per call, the tail of the workspace.  sp_keep != nullptr (training tape): that workspace slot has no tail,
   // fp32 kernels there.
-  const bool b6 = use_b6_gemm() && (planes != nullptr || sp_keep == nullptr);
+  const bool b6 = use_b6_gemm(fp32_gemm ? DIFFAB_FLAG_FP32_GEMM : 0u) && (planes != nullptr || sp_keep == nullptr);
   if (b6 && planes == nullptr) {
     float* tail = ws + static_cast<size_t>(rows) * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0);
     void* own = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(tail) + 255) & ~static_cast<uintptr_t>(255));
@@ -1579,13 +1584,11 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   DIFFAB_LAUNCH_CHECK();
 #else
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
+#ifdef DIFFAB_EXPERIMENTAL
   // Operand-plane form (pair planes given, default attention mode, bf16x6 GEMMs): the projection kernel writes the query / key sides
   // as MFMA operands of the attention kernel's logits product (proj_planes.hip) and only the value side into `proj`.
   // DIFFAB_ATTN_PIPE=1: K = 64 / 128 through the sixteen-wave key-tile pipeline on the operand planes (attention_pipe.hip)
-  static const bool env_pipe = [] {
-    const char* v = getenv("DIFFAB_ATTN_PIPE");
-    return v != nullptr && atoi(v) != 0;
-  }();
+  static const bool env_pipe = env_int("DIFFAB_ATTN_PIPE", 0) != 0;
   const bool planes_ok = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr;
   const bool pipe = planes_ok && env_pipe && attention_pipe_supported(d);
   const bool b6l = planes_ok && (pipe || operand_planes_enabled(d));
@@ -1600,7 +1603,11 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     }
     if (int rc = launch_proj_planes_b6(x, static_cast<const char*>(planes) + pp_planes_offset(), R, t, cent, w->gamma, qk_ops, proj, rows, d->K, st))
       return rc;
-  } else if (b6) {
+  } else
+#else
+  (void)cent;
+#endif
+  if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {
     const size_t pj_lds = (2 * PJB * PJLD + PJROWS * 12) * sizeof(float);
@@ -1629,19 +1636,18 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
     return to_out();
   }
+#ifdef DIFFAB_EXPERIMENTAL  // (the product library ignores DIFFAB_FLAG_FLASH_ATTENTION: default kernel)
   // DIFFAB_FLAG_FLASH_ATTENTION (K = 64 / 128): the key-tile pipeline of attention_flash.hip - no logits image in LDS, the pair stream in
   // flight from the first instruction.  Parity-tested on the same goldens; measured 0.380 ms against 0.357 ms for the three-phase
   // kernel below at B = 256 (both leave the matrix pipe idle > 50 % of the time: DESIGN section 4.1), hence opt-in.
   // DIFFAB_ATTN_FLASH=1 in the environment selects it for every default-mode call (A/B timing with bench.py).
-  static const bool env_flash = [] {
-    const char* v = getenv("DIFFAB_ATTN_FLASH");
-    return v != nullptr && atoi(v) != 0;
-  }();
+  static const bool env_flash = env_int("DIFFAB_ATTN_FLASH", 0) != 0;
   if ((attn_mode == 3 || (attn_mode == 0 && env_flash)) && attention_flash_supported(d)) {
     const float* pp = (attn_mode == 0 && pair_planes_supported(d)) ? pair_planes : nullptr;
     if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st, pp)) return rc;
     return to_out();
   }
+#endif
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
   const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
@@ -1679,16 +1685,20 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                        reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
     timer_end(st);                                                                                                                    \
   } while (0)
+#ifdef DIFFAB_EXPERIMENTAL
   if (b6l && pipe) {
     if (int rc = launch_attention_pipe(d, proj, pair_planes, R, t, w->w_bias, w->gamma, feat, qk_ops, st)) return rc;
     return to_out();
   }
+#endif
+#ifdef DIFFAB_EXPERIMENTAL
   if (b6l) {
     if (nt == 8 && nc == 1) ATTN_LAUNCH_B6L(8, false);
     else if (nt == 8) ATTN_LAUNCH_B6L(8, true);
     else if (nc == 1) ATTN_LAUNCH_B6L(4, false);
     else ATTN_LAUNCH_B6L(4, true);
   } else
+#endif
   // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores; single key chunk, attention default mode only
   if (pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d)) {
     if (nt == 8 && nc == 1) ATTN_LAUNCH_PLANES(8, false);

@@ -22,7 +22,8 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                    float* sp_keep = nullptr, float* d2_keep = nullptr,  // training tape: three launches, P and d2 kept in these buffers
                    const void* planes = nullptr,  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
                    const float* pair_planes = nullptr,  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
-                   const float* cent = nullptr);  // launch_patch_centroids() output for t (operand-plane form; nullptr: computed here)
+                   const float* cent = nullptr,  // launch_patch_centroids() output for t (operand-plane form; nullptr: computed here)
+                   bool fp32_gemm = false);  // DIFFAB_FLAG_FP32_GEMM: dense products on the f32-input MFMA kernels
 float* ipa_fast_centroid_slot(const diffab_dims* d, float* ws);  // where a caller may park the centroids of a step (B x 4 floats)
 // proj_planes.hip: the projections as MFMA operands of the attention kernel's logits product
 size_t proj_planes_scratch_bytes();
@@ -61,7 +62,7 @@ int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const flo
                           int ldy, int M, int Kd, bool relu, hipStream_t st);
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                          int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st);
-bool use_b6_gemm();  // false with DIFFAB_FP32_GEMM=1 in the environment
+bool use_b6_gemm(uint32_t flags = 0);  // false with DIFFAB_FLAG_FP32_GEMM (experimental builds: or DIFFAB_FP32_GEMM=1 in the environment)
 // the six IPA projections + frames; W6 = {wq_s, wk_s, wv_s, wq_p, wk_p, wv_p}
 size_t proj_frames_b6_scratch_bytes();
 int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st);

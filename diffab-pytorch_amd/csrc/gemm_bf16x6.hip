@@ -452,10 +452,7 @@ int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const flo
   const __bf16* Wc = static_cast<const __bf16*>(planes);
   // 128-row work-groups when they fill the chip (measured at 256 groups: 47 us against 53 for 64-row groups, K = 1024), 64-row
   // groups below that (B <= 128 patches of 128 residues per GPU: twice the groups); DIFFAB_B6_ROWS=64|128 forces one
-  static const int rows_force = [] {
-    const char* e = getenv("DIFFAB_B6_ROWS");
-    return e ? atoi(e) : 0;
-  }();
+  static const int rows_force = env_int("DIFFAB_B6_ROWS", 0);
   const int rows_env = rows_force ? rows_force : ((M + 127) / 128 >= 256 ? 128 : 64);
 #define B6_LAUNCH(RELU_, ROWS_)                                                                                                         \
   do {                                                                                                                                  \

@@ -17,16 +17,15 @@
  *     (torch.bool);
  *   - the caller owns every buffer including the workspace (size from the
  *     matching *_workspace_bytes query); kernels are enqueued on `stream` and
- *     never synchronise; no hidden global state; re-entrant across streams.
- *     Exceptions, all opt-in and off by default: (a) the two DIAGNOSTIC entry points
- *     diffab_kernel_timer_enable/read and diffab_debug_set_attn_stamps keep
- *     process-global state (an event list, a stamp-buffer pointer), are not
- *     thread-safe and must not be left enabled in production; (b)
+ *     never synchronise; no hidden global state; re-entrant across streams; the
+ *     library never reads the environment.  Two DIAGNOSTIC entry points keep
+ *     process-global state and are off by default: diffab_kernel_timer_enable/read
+ *     (an event list) and diffab_debug_set_attn_stamps (a stamp-buffer pointer);
+ *     they are not thread-safe and must not be left enabled in production.
  *     DIFFAB_FLAG_GRAPH_SAMPLER makes diffab_sample_loop drain a private stream
- *     before it returns; (c) the environment variables DIFFAB_FP32_GEMM,
- *     DIFFAB_PAIR_F32, DIFFAB_MLP_UNFUSED, DIFFAB_B6_ROWS, DIFFAB_ATTN_FLASH,
- *     DIFFAB_FLASH_WAVES select kernel variants for A/B timing, are read once
- *     per process, and change results only within rounding;
+ *     before it returns.  (Kernel variants that were measured and not adopted, and
+ *     the environment switches used to A/B them, exist only in the EXPERIMENTAL
+ *     build of this library - `make EXPERIMENTAL=1`, include/diffab_hip_experimental.h.)
  *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
  *     diffab_last_error() gives the thread's last message.
  */
@@ -53,14 +52,19 @@ extern "C" {
 #define DIFFAB_FLAG_SPLIT_ATTENTION 2u /* K = 64 / 128: the attention of each layer as three launches (logits | pair stream | P x V)
                                           instead of the fused kernel; same results to rounding, see csrc/attention_split.hip */
 
-#define DIFFAB_FLAG_FLASH_ATTENTION 8u /* K = 64 / 128: the attention of each layer as a key-tile pipeline with an online softmax
-                                          (csrc/attention_flash.hip) instead of the three-phase kernel; same results to rounding */
+#define DIFFAB_FLAG_FLASH_ATTENTION 8u /* experimental builds only (csrc/attention_flash.hip: the attention as a key-tile pipeline with
+                                          an online softmax); the product library ignores it and runs the default kernel */
 
 #define DIFFAB_FLAG_PAIR_PLANES 32u /* K = 64 / 128, default attention kernel: the pair embedding is first rewritten as two fp16 planes (e s =
                                       h1 + h2 to 2^-23 of the tensor maximum, same bytes, in the workspace) and the two products on
                                       the pair tile run on the f16 matrix cores as three exact partial products each, fp32
                                       accumulation.  diffab_sample_loop always does this (once per trajectory); for single calls
                                       the flag adds the rewrite (2x the pair embedding in HBM traffic) to every call. */
+
+#define DIFFAB_FLAG_PAIR_F32 64u /* diffab_sample_loop: keep the fp32 pair stream (do not build the fp16 planes); for single calls simply
+                                    do not pass DIFFAB_FLAG_PAIR_PLANES.  The plain-fp32 reference form of the attention kernel. */
+#define DIFFAB_FLAG_FP32_GEMM 128u /* forward paths: the dense products (projections, to_out, MLPs) on the f32-input MFMA kernels instead
+                                      of the six-term bf16 split; same results to fp32 rounding (the plain-fp32 reference form) */
 
 #define DIFFAB_FLAG_GRAPH_SAMPLER 16u /* diffab_sample_loop: capture one reverse step into a hipGraph (timestep read from device memory)
                                          and replay it for the remaining steps - one host call per step instead of ~45.  Bitwise the
@@ -155,16 +159,6 @@ int diffab_debug_set_attn_stamps(void* device_buffer);
 int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
                            size_t scratch_bytes, void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
-/* Diagnostics / accuracy tests: the projection kernel of the operand-plane attention path alone (csrc/proj_planes.hip;
- * InvariantPointAttentionLayer.forward, diffab_pytorch.py:391-413 + the frame transform :324): from x (B K x 128), the frames
- * (R, t) and one layer's weights it writes qk_out = the query / key operand planes of the logits product (B K x 1536 floats:
- * three bf16 planes of 64 slots per residue and head, layout in the header of that file) and the v_s / global value-point
- * columns of proj_out (B K x 1344 floats, the other columns untouched).  Benchmark geometry only (D=128, H=8, DS=32, P=8).
- * diffab_debug_proj_planes_scratch_bytes() bytes of scratch, 256-byte aligned. */
-size_t diffab_debug_proj_planes_scratch_bytes(const diffab_dims* d);
-int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* R, const float* t,
-                             float* qk_out, float* proj_out, void* scratch, size_t scratch_bytes, void* stream);
-
 /* ---- SO(3) maps, n matrices/vectors each --------------------------------- */
 /* so3.py:146-162  log R = theta/(2 sin theta) (R - R^T); NaN at theta = 0 like the reference */
 int diffab_so3_log(const float* R, float* S, int64_t n, void* stream);

@@ -6,6 +6,7 @@ and check them slot by slot against a float64 restatement of the same algebra, a
 operands plus the direct |t_i - t_j|^2 term reproduces the oracle's logits up to the per-row constants softmax does not see.
 """
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -16,11 +17,20 @@ from diffab_pytorch import _hip, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffab-pytorch_amd", "build_exp", "libdiffab_hip.so")
+
 
 @pytest.fixture(scope="module")
 def hip():
-    lib = _hip.lib()
-    assert lib.diffab_device_ok() == 1
+    """The EXPERIMENTAL build of the library (`make EXPERIMENTAL=1`, built by __graft_entry__.build()): the operand-plane kernels are
+    a measured, unadopted variant and are not part of the product library."""
+    assert _hip.lib().diffab_device_ok() == 1
+    if not os.path.exists(EXP_LIB):
+        pytest.skip("experimental library not built (make -C diffab-pytorch_amd/csrc EXPERIMENTAL=1)")
+    lib = C.CDLL(EXP_LIB)
+    for name, (res, args) in _hip.EXPERIMENTAL_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
     return lib
 
 
@@ -84,8 +94,8 @@ def test_operand_planes_vs_float64(hip, B, K, sigma, offset):
     qk = torch.zeros(rows * 1536, dtype=torch.float32, device="cuda")
     proj = torch.full((rows, 1344), float("nan"), dtype=torch.float32, device="cuda")
     xd, Rd, td = _hip.dev_f32(x), _hip.dev_f32(R), _hip.dev_f32(t)
-    _hip.check(hip.diffab_debug_proj_planes(C.byref(dims), C.byref(w), _hip.ptr(xd), _hip.ptr(Rd), _hip.ptr(td), _hip.ptr(qk), _hip.ptr(proj),
-                                            _hip.ptr(scratch), scratch.numel(), _hip.stream_ptr()), "debug_proj_planes")
+    assert 0 == hip.diffab_debug_proj_planes(C.byref(dims), C.byref(w), _hip.ptr(xd), _hip.ptr(Rd), _hip.ptr(td), _hip.ptr(qk), _hip.ptr(proj),
+                                            _hip.ptr(scratch), scratch.numel(), _hip.stream_ptr())
     torch.cuda.synchronize()
     got, raw = decode_planes(qk, B, K)
     QA, KB, coef = expected_slots(sd, x, R, t)

@@ -5,6 +5,6 @@ set -e
 cd "$(dirname "$0")/../diffab-pytorch_amd/csrc"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  make -s OBJ=../build_abl/$name OUT=../build_abl/$name EXTRA="$flags" >/dev/null
+  make -s EXPERIMENTAL=1 OBJ=../build_abl/$name OUT=../build_abl/$name EXTRA="$flags" >/dev/null
   echo "built build_abl/$name ($flags)"
 done

@@ -34,7 +34,7 @@ layer(x, e, R, t, flags=FLAGS)
 torch.cuda.synchronize()
 lib.diffab_debug_set_attn_stamps(None)
 s = stamps.view(nwg, 8, 8).cpu().double()
-if os.environ.get("DIFFAB_ATTN_FLASH", "1") != "0" and K in (64, 128):
+if (os.environ.get("DIFFAB_ATTN_FLASH", "0") != "0" or os.environ.get("DIFFAB_ATTN_PIPE", "0") != "0") and K in (64, 128):
     # key-tile pipeline (attention_flash.hip): stamps 0 start | 1 prologue barrier | 2 step 0 | 3 step 1 | 4 step 4 | 6 step NT | 7 step NT+1 | 5 end
     tot = s[..., 5] - s[..., 0]
     print(f"B={B} K={K}: {nwg} work-groups; per-wave lifetime mean {tot.mean():.0f} (min {tot.min():.0f}, max {tot.max():.0f})")
