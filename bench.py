@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead of the sampling headline: training steps (noise + taped forward + 3 losses + HIP "
                          "backward + gradient all-reduce over RCCL + Adam), 128 patches per GPU unless --batch is given")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (tests/test_gpu_two_ranks.py); "
+                         "exercises the launch contract, sharding, gather and max-over-ranks timing - NOT a scaling measurement")
     args = ap.parse_args()
     if args.train and "--batch" not in sys.argv:
         args.batch = 128
@@ -298,12 +301,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     from diffab_pytorch import DiffAb, _hip, synthetic as syn
     from diffab_pytorch.distributed import gather_samples
@@ -404,7 +412,8 @@ def main():
             "config": {
                 "workload": f"batch={B}/GPU synthetic K={K} patches, reverse sampling steps (T=100 schedule), benchmark model "
                             "D=128 C=64 NL=6 H=8 ds=32 P=8 (reference train.py:62-70), random-init weights",
-                "patches_per_gpu": B, "K": K, "global_batch": world * B, "parallelism": f"patch-sharded x{world}",
+                "patches_per_gpu": B, "K": K, "global_batch": world * B,
+                "parallelism": f"patch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU over gloo, not a scaling measurement)" if args.rehearse_on_one_gpu else ""),
                 "path": "generic" if args.generic else ("mfma-split-attention" if args.split_attention else ("mfma-external-logits" if args.external_logits else "mfma")),
             },
             "residue_steps_per_s_per_gpu": value / world,

@@ -50,8 +50,12 @@ def gather_samples(local: Dict[str, torch.Tensor], dist=None, sizes: Optional[li
     Bmax = max(sizes)
     if B < Bmax:
         buf = torch.cat([buf, buf.new_zeros(Bmax - B, *buf.shape[1:])])
+    dev = buf.device
+    if buf.is_cuda and dist.get_backend() == "gloo":  # gloo has no device all-gather: stage through the host (CPU rehearsals of the N > 1 path)
+        buf = buf.cpu()
     out = buf.new_empty(world * Bmax, *buf.shape[1:])
     dist.all_gather_into_tensor(out, buf.contiguous())
+    out = out.to(dev)
     parts = [out[r * Bmax: r * Bmax + sizes[r]] for r in range(world)]
     return unpack_samples(torch.cat(parts))
 

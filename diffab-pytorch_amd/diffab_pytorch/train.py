@@ -64,6 +64,8 @@ def parse_argument(argv: Optional[List[str]] = None) -> argparse.Namespace:
     parser.add_argument("--cdr-mask-key", default="generation_mask",
                         help="Key of the boolean (1, K) CDR mask inside each patch file.  preprocess_pdb.py:67-80 stores none (upstream "
                              "derives it from the PDB numbering with protstruc, data.py:92), so patches must be augmented with one")
+    parser.add_argument("--rehearse-on-one-gpu", action="store_true",
+                        help="N > 1 rehearsal on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (tests/test_gpu_two_ranks.py)")
     return parser.parse_args(argv)
 
 
@@ -182,8 +184,12 @@ def main(argv: Optional[List[str]] = None) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("diffab_pytorch.train needs a gfx950 device: the hot path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.manual_seed(args.seed)  # reference: pl.seed_everything(args.seed), train.py:50
 
