@@ -1077,13 +1077,15 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       const int pp = l15 & 7;
       const float* vbase = proj + (krow0 + 4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;  // + (16 jt + r) rows; d = 2 l15 + dt
       const float* gbase = proj + (krow0 + 4 * q) * ANP + OFF_GV + h * 24 + 3 * pp;    // point pp, coords 0..2
+      // Point sums: columns 0..7 of ONE MFMA tile hold x of the 8 points, columns 8..15 y (z in a second tile, its upper half
+      // duplicates): 4 f32 MFMAs per key step instead of 5 - this phase is bound by exactly those (32 cycles each).
+      const int xy = l15 >> 3;  // 0: this lane's column is x of point pp, 1: y
       float2 vs[NS];
-      float gx[NS], gy[NS], gz[NS];
+      float gxy[NS], gz[NS];
       auto load_vals = [&](int stp) {
         const int64_t o = static_cast<int64_t>((stp >> 2) * 16 + (stp & 3)) * ANP;
         vs[stp] = *reinterpret_cast<const float2*>(vbase + o);
-        gx[stp] = gbase[o];
-        gy[stp] = gbase[o + 1];
+        gxy[stp] = gbase[o + xy];
         gz[stp] = gbase[o + 2];
       };
 #pragma unroll
@@ -1091,11 +1093,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       MEM_FENCE();
       __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS
       if (c == 0) stamp(4);
-      f32x4 os[2], og[3];
+      f32x4 os[2], og[2];  // og[0]: x | y of the points, og[1]: z
 #pragma unroll
       for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) og[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int cc = 0; cc < 2; ++cc) og[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 16 jt + 4 q + r]
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
@@ -1113,9 +1115,8 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           }
           os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[stp].x, os[0], 0, 0, 0);
           os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[stp].y, os[1], 0, 0, 0);
-          og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gx[stp], og[0], 0, 0, 0);
-          og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gy[stp], og[1], 0, 0, 0);
-          og[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz[stp], og[2], 0, 0, 0);
+          og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gxy[stp], og[0], 0, 0, 0);
+          og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz[stp], og[1], 0, 0, 0);
         }
       }
       // D rows i = 4 q + r, column n = l15; earlier chunks' sums are rescaled through the feature row
@@ -1135,9 +1136,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         o2.x *= inv;
         o2.y *= inv;
         *po = o2;
+        const float gy_lane = __shfl_xor(og[0][r], 8);  // lanes 0..7 hold x of point l15, lanes 8..15 y of point l15 - 8
         if (l15 < 8) {
           float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
-          float g0_ = og[0][r], g1_ = og[1][r], g2_ = og[2][r];
+          float g0_ = og[0][r], g1_ = gy_lane, g2_ = og[1][r];
           if (c > 0) {  // running (unnormalised, global-frame) sums are parked in the o_l slot between chunks
             g0_ += fo[0] * fac;
             g1_ += fo[1] * fac;

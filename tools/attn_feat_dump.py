@@ -17,7 +17,7 @@ B, K = 2, 128
 lib = _hip.lib()
 d = syn.BENCH_DIMS
 torch.manual_seed(0)
-layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda().requires_grad_(False)  # inference kernels
 inp = {k: v.cuda() for k, v in syn.patches(B, K, d, seed=3, coord_sigma=8.0).items()}
 x, e, R, t = inp["res_context_emb"], inp["pair_context_emb"], inp["orientations"], inp["translations"]
 dims = _hip.make_dims(B, K, d["D"], d["C"], d["H"], d["DS"], d["PQ"], d["PV"], 1)

@@ -14,7 +14,7 @@ B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(s
 lib = _hip.lib()
 d = syn.BENCH_DIMS
 torch.manual_seed(0)
-layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda().requires_grad_(False)  # inference kernels
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(B, K, d["D"], device="cuda", generator=g)
 e = torch.randn(B, K, K, d["C"], device="cuda", generator=g)
