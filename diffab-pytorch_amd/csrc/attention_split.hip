@@ -406,7 +406,9 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __res
 //   dA[h][j]  = dA_kv[h][j] (from ipa_attn_bwd_dakv_mfma_kernel) + do_e[h] . e[i][j]          (the bias-shaped MFMA product)
 //   g[h][j]   = 3^-1/2 P (dA - sum_j P dA)                     -> written over dA_kv ([b][h][i][j])
 //   d gamma_h partial = sum_j g scale_p d2,   d w_bias[h][c] partial = sum_j g e[i][j][c]       (the o_e-shaped MFMA product)
-// Partials go to wb_part[row][8 * 64 + 8]; one column sum over the rows finishes them.
+// Partials: each wave sums its RPW rows in registers, the work-group's eight waves are added through LDS in a fixed order, and ONE row
+// wb_part[work-group][8 * 64 + 8] is written per 32 query rows; one column sum over the work-groups finishes them (per-row partials
+// were 34 MB written and re-read per layer at B = 128, and 15 us per column sum).
 template <int NT, int RPW>
 __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* __restrict__ e, const float* __restrict__ P,
                                                                   float* __restrict__ G /* in: dA_kv, out: g */,
@@ -419,8 +421,7 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
   constexpr int K = 16 * NT;
   const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
   float* scr = lds + wv * (2 * 16 * ELD);
-  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 8 + wv) * RPW;
-  if (row_first >= rows_total) return;
+  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 8 + wv) * RPW;  // rows_total % (8 RPW) == 0 (launcher): every wave has rows
   const int l15 = lane0 & 15, q = lane0 >> 4;
   const int h = l15 & 7;
   const float scale_t = 0.57735026918962576f, scale_p = -0.5f * 0.16666666666666666f;
@@ -449,6 +450,10 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
   for (int jt = 0; jt < NT; ++jt) load_e_tile(0, row_first, jt);
   MEM_FENCE();
 
+  f32x4 oe_sum[4];   // d w_bias partial of this wave's rows: D column h = l15, row 4 q + r' <-> channel 16 q + 4 r' + ct
+  float dg_sum = 0.f;  // d gamma partial (head h)
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) oe_sum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto do_row = [&](auto slot_c, int64_t row, auto has_next_c) {
     constexpr int slot = decltype(slot_c)::value;
     constexpr bool has_next = decltype(has_next_c)::value;
@@ -513,8 +518,7 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
     }
     dg += __shfl_xor(dg, 16);
     dg += __shfl_xor(dg, 32);
-    float* wrow = wb_part + row * (AH * AC + AH);
-    if (l15 < 8 && q == 0) wrow[AH * AC + h] = dg * scale_p;
+    dg_sum += dg * scale_p;
     // d w_bias partial: sum_j g[h][j] e[row][j][c], g as the B operand straight from registers
     f32x4 oe[4];
 #pragma unroll
@@ -554,13 +558,8 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
         MEM_FENCE();
       }
     }
-    if (l15 < 8) {  // D: column h = l15, row m = 4 q + r' <-> channel 16 q + 4 r' + ct
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        f32x4 v = {oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
-        *reinterpret_cast<f32x4*>(wrow + h * AC + 16 * q + 4 * r) = v;
-      }
-    }
+    for (int ct = 0; ct < 4; ++ct) oe_sum[ct] += oe[ct];
   };
   static_assert(RPW == 4, "rows per wave");
   constexpr std::integral_constant<int, 0> s0{};
@@ -571,6 +570,19 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_bwd_kernel(const float* _
   do_row(s1, row_first + 1, more);
   do_row(s0, row_first + 2, more);
   do_row(s1, row_first + 3, done);
+  // the wave's sums -> its own (now idle) scratch, then the work-group's eight waves in a fixed order -> one row of partials
+  if (l15 < 8) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(scr + h * AC + 16 * q + 4 * r) = f32x4{oe_sum[0][r], oe_sum[1][r], oe_sum[2][r], oe_sum[3][r]};
+    if (q == 0) scr[AH * AC + h] = dg_sum;
+  }
+  __syncthreads();
+  for (int c = tid; c < AH * AC + AH; c += 512) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += lds[w * (2 * 16 * ELD) + c];
+    wb_part[static_cast<int64_t>(blockIdx.x) * (AH * AC + AH) + c] = sum;
+  }
 }
 
 int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P, float* G, const float* D2, const float* dfeat,
@@ -579,7 +591,8 @@ int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P,
   DIFFAB_REQUIRE(attention_split_supported(d), DIFFAB_ERR_UNSUPPORTED, "pair_stream_bwd: K must be 64 or 128");
   constexpr int RPW = 4;
   const size_t lds_b = static_cast<size_t>(8) * 2 * 16 * ELD * sizeof(float);
-  const dim3 grid_b((rows + 8 * RPW - 1) / (8 * RPW));
+  DIFFAB_REQUIRE(rows % (8 * RPW) == 0, DIFFAB_ERR_UNSUPPORTED, "pair_stream_bwd: B K must be a multiple of %d", 8 * RPW);
+  const dim3 grid_b(rows / (8 * RPW));
   if (K == 128) {
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_pair_stream_bwd_kernel<8, RPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b)));

@@ -1456,6 +1456,7 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
       DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     bool keys_done = false;  // the MFMA path below also does the key-side pass
+    int wb_rows = rows;       // rows of the d w_bias / d gamma partials (the MFMA path writes one per 32 query rows)
     constexpr int RRm = 4;  // query rows per work-group of the multi-row kernel
     const size_t slot = ((3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) + 3) & ~static_cast<size_t>(3);
     const size_t lds_mr = RRm * slot * sizeof(float);
@@ -1481,6 +1482,7 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
         // dAkv holds g afterwards; d pair_ctx is accumulated there too (MFMA), so the row pass below only writes the transposed copies
         if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, lw->w_bias, d_pair_ctx, st)) return rc;
         keys_done = true;
+        wb_rows = rows / 32;
         // key side straight from the [b][h][i][j] images (g in dAkv, P in Pn): no transposed copies, no VALU row pass at all
         hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<0, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf,
                            dproj, d->K);
@@ -1503,8 +1505,8 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     }
     DIFFAB_LAUNCH_CHECK();
     // d w_bias[h][c] += sum_rows partial, d gamma[h] += sum_rows partial (one column sum over the [rows][H*C + H] partials)
-    if (int rc = colsum(wb_part, H * C + H, rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
-    if (int rc = colsum(wb_part + H * C, H * C + H, rows, H, const_cast<float*>(lg->gamma), st)) return rc;
+    if (int rc = colsum(wb_part, H * C + H, wb_rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
+    if (int rc = colsum(wb_part + H * C, H * C + H, wb_rows, H, const_cast<float*>(lg->gamma), st)) return rc;
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
     constexpr int JJm = 4;  // keys per work-group of the multi-key kernel
     if (keys_done) {
@@ -1522,11 +1524,10 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     }
     DIFFAB_LAUNCH_CHECK();
     // global-point gradients -> local-point gradients (three point blocks)
-    const int cols[3] = {3 * H * DS, 3 * H * DS + H * PQ * 3, 3 * H * DS + 2 * H * PQ * 3};
-    const int npts[3] = {H * PQ, H * PQ, H * PV};
-    for (int q = 0; q < 3; ++q) {
-      const int64_t n = static_cast<int64_t>(rows) * npts[q];
-      hipLaunchKernelGGL(points_bwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, dproj, NP, cols[q], npts[q], O_t,
+    {  // the three point blocks (q, k, v) are adjacent columns of dproj: one launch over all of a row's points
+      const int npts = 2 * H * PQ + H * PV;
+      const int64_t n = static_cast<int64_t>(rows) * npts;
+      hipLaunchKernelGGL(points_bwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, dproj, NP, 3 * H * DS, npts, O_t,
                          static_cast<int64_t>(rows));
       DIFFAB_LAUNCH_CHECK();
     }

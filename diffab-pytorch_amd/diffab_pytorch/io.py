@@ -1,6 +1,7 @@
 """Output side of the path: backbone atoms from the sampled frames, a PDB writer and a
 round-trippable sample file.  The reference stops at frames (x, O) - it has no reconstruction or writer - so this is new,
-build-defined functionality; host-side numpy/torch only (nothing here is on the timed path).
+build-defined functionality (nothing here is on the timed path); the atom reconstruction of frames that live on the device runs on
+the HIP frame kernel, file writing is host code.
 
 Frame convention (the one the hot path uses everywhere: reference ``euclidean_transform`` diffab_pytorch.py:315-324,
 ``global = local @ R + t`` with row vectors): a residue's frame has its origin at CA, and in LOCAL coordinates
@@ -29,8 +30,24 @@ AA3 = ("ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE", "LE
 
 
 def backbone_from_frames(translations: torch.Tensor, orientations: torch.Tensor, atoms: Sequence[str] = BACKBONE_ATOMS) -> torch.Tensor:
-    """(…,3) CA positions and (…,3,3) orientations -> (…, len(atoms), 3) atom coordinates: local @ R + t."""
-    local = torch.tensor([IDEAL_BACKBONE[a] for a in atoms], dtype=translations.dtype, device=translations.device)  # (A,3)
+    """(…,3) CA positions and (…,3,3) orientations -> (…, len(atoms), 3) atom coordinates: local @ R + t.
+    Frames on the device (the sampler's output) go through the HIP frame kernel - the same `diffab_frames_apply` that implements
+    the reference's euclidean_transform (diffab_pytorch.py:315-324), with the ideal backbone as the local points; host tensors
+    (files being written) use the identical expression in torch."""
+    local = torch.tensor([IDEAL_BACKBONE[a] for a in atoms], dtype=torch.float32)  # (A,3)
+    if translations.is_cuda:
+        from . import _hip
+
+        lib = _hip.lib()
+        t = _hip.dev_f32(translations).reshape(-1, 3)
+        R = _hip.dev_f32(orientations).reshape(-1, 3, 3)
+        L, A = t.shape[0], len(atoms)
+        pts = local.to(t.device).expand(L, A, 3).contiguous()  # (B=1, N=1, L, A, 3)
+        out = torch.empty_like(pts)
+        _hip.check(lib.diffab_frames_apply(_hip.ptr(pts), _hip.ptr(R), _hip.ptr(t), _hip.ptr(out), 1, 1, L, A, _hip.stream_ptr()),
+                   "diffab_frames_apply")
+        return out.view(*translations.shape[:-1], A, 3).to(translations.dtype)
+    local = local.to(dtype=translations.dtype)
     return torch.einsum("ak,...kc->...ac", local, orientations) + translations.unsqueeze(-2)
 
 

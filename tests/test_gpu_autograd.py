@@ -135,3 +135,27 @@ def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
     with torch.no_grad():
         y0 = layer(x, e, inp["orientations"], inp["translations"])
     assert y0.grad_fn is None and maxrel(y0, g["layer/y"]) < 1e-4
+
+
+def test_backbone_from_sampled_frames_on_the_device(hip):
+    """Output side: backbone atoms of sampled frames through the HIP frame kernel against the host expression
+    (float64), the exact inverse on (N, CA, C), and a PDB written from device tensors."""
+    import os
+    import tempfile
+
+    from diffab_pytorch import io as dio
+
+    d = syn.UNIT_DIMS
+    inp = syn.patches(3, 24, d, seed=8, coord_sigma=12.0)
+    x, O = inp["translations"].cuda(), inp["orientations"].cuda()
+    bb = dio.backbone_from_frames(x, O)
+    assert bb.is_cuda and bb.shape == (3, 24, 5, 3)
+    local = torch.tensor([dio.IDEAL_BACKBONE[a] for a in dio.BACKBONE_ATOMS], dtype=torch.float64)
+    want = torch.einsum("ak,...kc->...ac", local, inp["orientations"].double()) + inp["translations"].double().unsqueeze(-2)
+    assert maxrel(bb, want) < 1e-6
+    assert maxrel(bb, dio.backbone_from_frames(inp["translations"], inp["orientations"])) < 1e-6  # host path, same numbers
+    t2, R2 = dio.frames_from_backbone(bb[..., 0, :], bb[..., 1, :], bb[..., 2, :])
+    assert maxrel(t2, x) < 1e-6 and maxrel(R2, O) < 1e-5
+    with tempfile.TemporaryDirectory() as tmp:
+        n = dio.write_pdb(os.path.join(tmp, "p.pdb"), inp["seq_idx"][0].cuda(), x[0], O[0])
+        assert n == 24 * 4
