@@ -60,6 +60,39 @@ __global__ __launch_bounds__(512) void split(const f32x4* __restrict__ hbm, cons
   if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
 }
 
+// roles by work-group: blocks < NS stream HBM (8 waves x 16 KiB in flight, `iters` x 128 KiB each), the others read the L2-resident
+// table in a loop of `titers` iterations (16 KiB per wave and iteration).  Each streaming block reports its own duration in 100 MHz
+// ticks (s_memrealtime): the HBM rate of a streaming CU while the REST of the chip does L2-hit traffic (the attention kernel's mix).
+__global__ __launch_bounds__(512) void roles(const f32x4* __restrict__ hbm, const f32x4* __restrict__ tab, float* out,
+                                             unsigned long long* __restrict__ ticks, int NS, int iters, int titers) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x4 acc = {0, 0, 0, 0};
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (static_cast<int>(blockIdx.x) < NS) {
+    const f32x4* hp = hbm + (static_cast<size_t>(blockIdx.x) * 8 + wv) * static_cast<size_t>(iters) * 16 * 64 + lane;
+    for (int it = 0; it < iters; ++it) {
+      f32x4 hb[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) hb[d] = __builtin_nontemporal_load(hp + (static_cast<size_t>(it) * 16 + d) * 64);
+#pragma unroll
+      for (int d = 0; d < 16; ++d) acc += hb[d];
+    }
+  } else {
+    const f32x4* tp = tab + lane;
+    for (int it = 0; it < titers; ++it) {
+      f32x4 lb[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) lb[d] = tp[(((it * 16 + d) * 8 + wv) * 37 % 2048) * 64];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) acc += lb[d];
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
+}
+
 template <typename F>
 float time_ms(F f, int reps = 10) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -100,6 +133,23 @@ int main() {
     printf("split WH=%d mode=%d CUs=%3d: %.4f ms  stream %.0f GB/s (%.1f per CU)  table %.0f GB/s (%.1f per CU)\n", WH, MODE, NCU, t, \
            hb / t / 1e6, hb / t / 1e6 / NCU, lb / t / 1e6, lb / t / 1e6 / NCU);                                        \
   } while (0)
+  {
+    unsigned long long* ticks; hipMalloc(&ticks, 256 * 8);
+    hipFuncSetAttribute((const void*)roles, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int ns : {64, 105, 128}) {
+      for (int titers : {0, 200, 400}) {
+        const int iters = 32;  // 4 MiB per streaming block
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(roles, dim3(256), dim3(512), lds, 0, hbm, tab, out, ticks, ns, iters, titers);
+        hipDeviceSynchronize();
+        unsigned long long h[256]; hipMemcpy(h, ticks, 256 * 8, hipMemcpyDeviceToHost);
+        double ts = 0, tt = 0; for (int i = 0; i < ns; ++i) ts += h[i]; for (int i = ns; i < 256; ++i) tt += h[i];
+        ts /= ns; tt /= (256 - ns);
+        const double sb = double(iters) * 8 * 16 * 1024, tb = double(titers) * 8 * 16 * 1024;
+        printf("roles: %3d CUs stream HBM, %3d CUs read the L2 table (%d iters): stream %.1f GB/s per CU (%.1f us), table %.1f GB/s per CU (%.1f us)\n",
+               ns, 256 - ns, titers, sb / (ts * 10.0), ts / 100.0, titers ? tb / (tt * 10.0) : 0.0, tt / 100.0);
+      }
+    }
+  }
   RUNS(4, 1, 128); RUNS(4, 2, 128); RUNS(4, 3, 128);
   RUNS(4, 1, 256); RUNS(4, 2, 256); RUNS(4, 3, 256);
   RUNS(6, 1, 128); RUNS(6, 2, 128); RUNS(6, 3, 128);
