@@ -418,7 +418,11 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   auto stamp = [&](int k) {
     if (stamps != nullptr) {
       __builtin_amdgcn_sched_barrier(0);
+#ifdef AT_STAMP_REALTIME  // the 100 MHz counter is the same on every CU (s_memtime is not comparable between CUs)
+      const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
+#else
       const unsigned long long tnow = __builtin_amdgcn_s_memtime();
+#endif
       if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -426,14 +430,22 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   stamp(0);
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
+  const unsigned bid = blockIdx.x;
   if ((B & 7) == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     b = (slot / ntile) * 8 + xcd;
     tile = slot % ntile;
   } else {
-    b = blockIdx.x / ntile;
-    tile = blockIdx.x % ntile;
+    b = bid / ntile;
+    tile = bid % ntile;
   }
+#ifdef AT_STAGGER_TICKS  // timing experiment (profiles/r03_lockstep.md): the first generation of work-groups starts staggered, AT_STAGGER_CLASSES
+                         // classes AT_STAGGER_TICKS (100 MHz) apart - the CUs' pair-stream phases stop coinciding
+  if (blockIdx.x < 256) {
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + static_cast<unsigned long long>((blockIdx.x >> 3) & (AT_STAGGER_CLASSES - 1)) * AT_STAGGER_TICKS;
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   const int i0 = tile * TI;
   const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
   constexpr int HS = KC + 8, IS = AH * (KC + 8) + 8;  // == 8 (mod 64): both ds_read_b128 patterns on the image are conflict-free
@@ -483,6 +495,14 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   erow[0] = e + ((prow0 + i0 + 2 * wv) * K) * AC;
   erow[1] = erow[0] + static_cast<int64_t>(K) * AC;
   float Mrun[2] = {-INFINITY, -INFINITY}, Lrun[2] = {0.f, 0.f};  // online-softmax state of (row 2 wv + ii, head l15 & 7)
+  // PLANES: 1 / s_i of the wave's two pair rows, fetched here through the scalar cache (wave-uniform address).  As a vector load at
+  // the top of each row its s_waitcnt - vmcnt retires in order - drained every pair tile in flight, twice per wave and phase 2.
+  float inv_s2[2] = {1.0f, 1.0f};
+  if constexpr (PLANES) {
+    const float* ep = esc + 2 * (prow0 + i0 + 2 * __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+    inv_s2[0] = ep[1];
+    inv_s2[1] = ep[3];
+  }
 
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
@@ -821,7 +841,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int ii = 0; ii < 2; ++ii) {
           const int il = 2 * wv + ii;  // local row
           float* Srow = S + il * IS + h * HS;
-          const float inv_s = esc[2 * (prow0 + i0 + il) + 1];  // 1 / s_i: the power-of-two scale of this pair row's planes
+          const float inv_s = inv_s2[ii];  // 1 / s_i: the power-of-two scale of this pair row's planes
           const float bscale_r = bscale * inv_s, oscale_r = oscale * inv_s;
           float m_run = -INFINITY, l_run = 0.f, m_hist[NT / 2];
           f32x4 oe[4];
@@ -829,6 +849,22 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int T = 0; T < NT / 2; ++T) {
+#ifdef AT_ABL_STREAMONLY  // timing ablation: phase 2 as a pure stream (the tiles are summed, nothing else happens to them)
+            {
+#pragma unroll
+              for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) oe[k4] += ev[ii][2 * T + tl][k4];
+              const int nx = ii * NT + 2 * T + RT;
+              if (nx < 2 * NT) {
+                load_e_tile(nx / NT, c, nx % NT);
+                load_e_tile((nx + 1) / NT, c, (nx + 1) % NT);
+                MEM_FENCE();
+              }
+              m_hist[T] = 0.f;
+              continue;
+            }
+#endif
             // ---- bias of the two tiles: A fragments straight from the loaded registers (lane = key l15, channels 32 ks + 8 q ..)
             f32x4 acc[2][2];
 #pragma unroll

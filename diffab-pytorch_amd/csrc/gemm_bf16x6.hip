@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
     load_w(Wc, 1);
     MEM_FENCE();
     __syncthreads();  // the image (X, or the previous layer's output) and the first weight chunk are in LDS
-#pragma unroll
+#pragma unroll 1  // (fully unrolled the kernel needs 260 VGPRs: 4 spilled)
     for (int c = 0; c < 4; ++c) {
       const int buf = c & 1;
       const __bf16* al = img + c * (3 * 128 * BK) + a_off;

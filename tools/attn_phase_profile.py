@@ -65,3 +65,18 @@ d06 = (s[..., 6] - s[..., 0])
 if (s[..., 6] > 0).all():
     print(f"  stamp 0 -> 6: first 256 work-groups mean {d06[:256].mean():.0f}, the rest mean {d06[256:].mean():.0f}; "
           f"percentiles 10/50/90 of all: {d06.flatten().quantile(torch.tensor([0.1, 0.5, 0.9], dtype=torch.float64)).tolist()}")
+# time series (wave 0 of every work-group): how many work-groups are inside phase 2 at a time, and how long phase 2 takes for the
+# work-groups that enter it in each slice of the launch - are the CUs' stream phases synchronised?
+if os.environ.get("ATTN_TIMESERIES", "0") != "0":
+    w0 = s[:, 0, :].clone()  # needs a build with -DAT_STAMP_REALTIME (100 MHz ticks, comparable between CUs; s_memtime is not)
+    w0 -= w0[:, 0].min()
+    a, b_ = w0[:, 2], w0[:, 3]
+    nb = 48
+    edges = torch.linspace(0, float(w0[:, 5].max()), nb + 1, dtype=torch.float64)
+    print("  slice of the launch [k cycles] | work-groups inside phase 2 (mean over the slice) | phase-2 duration of those entering it [k cycles]")
+    for k in range(nb):
+        lo, hi = edges[k], edges[k + 1]
+        inside = ((torch.minimum(b_, hi) - torch.maximum(a, lo)).clamp_min(0)).sum() / (hi - lo)
+        ent = (a >= lo) & (a < hi)
+        dur = (b_ - a)[ent].mean() / 1e3 if ent.any() else float("nan")
+        print(f"   {lo / 1e3:7.0f} .. {hi / 1e3:7.0f} | {inside:6.1f} | {dur:6.1f}  (n = {int(ent.sum())})")

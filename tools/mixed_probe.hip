@@ -93,6 +93,52 @@ __global__ __launch_bounds__(512) void roles(const f32x4* __restrict__ hbm, cons
   if (acc.x + acc.y + acc.z + acc.w == 123.456f) { out[0] = 1; smem[threadIdx.x] = acc.x; }
 }
 
+// the phase-2 loop shape of the attention kernel: a wave streams 8 KiB steps with two steps of lookahead (8..16 loads in flight);
+// per step NW ds_write_b128 of the loaded registers and NR ds_read_b128 from the wave's own LDS region, NM f16 MFMAs.
+// Does the LDS traffic of a CU slow its HBM stream?
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NW, int NR, int NM>
+__global__ __launch_bounds__(512) void stream_lds(const f32x4* __restrict__ hbm, float* out, unsigned long long* __restrict__ ticks,
+                                                  int steps) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  f32x4* my = reinterpret_cast<f32x4*>(smem) + wv * (16 * 64) + lane;  // 16 KiB per wave
+  f32x4 acc = {0, 0, 0, 0}, macc = {0, 0, 0, 0};
+  const f32x4* hp = hbm + (static_cast<size_t>(blockIdx.x) * 8 + wv) * static_cast<size_t>(steps) * 8 * 64 + lane;
+  f32x4 ev[2][8];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ev[s][d] = __builtin_nontemporal_load(hp + (static_cast<size_t>(s) * 8 + d) * 64);
+  for (int st = 0; st < steps; st += 2) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+        macc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ev[s][m & 7]), __builtin_bit_cast(f16x8, ev[s][(m + 1) & 7]), macc, 0, 0, 0);
+#pragma unroll
+      for (int d = 0; d < NW; ++d) my[(d & 15) * 64] = ev[s][d & 7];
+      if (NW == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc += ev[s][d];
+      }
+      asm volatile("" ::: "memory");
+      if (st + s + 2 < steps) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ev[s][d] = __builtin_nontemporal_load(hp + (static_cast<size_t>(st + s + 2) * 8 + d) * 64);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int d = 0; d < NR; ++d) acc += my[((d + 3) & 15) * 64];
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+  acc += macc;
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1;
+}
+
 template <typename F>
 float time_ms(F f, int reps = 10) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -150,6 +196,21 @@ int main() {
       }
     }
   }
+#define RUNL(NW, NR, NM, NCU)                                                                                          \
+  do {                                                                                                                 \
+    unsigned long long* ticks; hipMalloc(&ticks, 256 * 8);                                                             \
+    const int steps = 64; /* 512 KiB per wave, 4 MiB per work-group */                                                 \
+    hipFuncSetAttribute((const void*)stream_lds<NW, NR, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((stream_lds<NW, NR, NM>), dim3(NCU), dim3(512), lds, 0, hbm, out, ticks, steps); \
+    hipDeviceSynchronize();                                                                                            \
+    unsigned long long h[256]; hipMemcpy(h, ticks, NCU * 8, hipMemcpyDeviceToHost);                                    \
+    double ts = 0; for (int i = 0; i < NCU; ++i) ts += h[i]; ts /= NCU;                                                \
+    printf("stream_lds: %3d CUs, per 8 KiB step %2d ds_write_b128 + %2d ds_read_b128 + %2d MFMA: %.1f GB/s per CU (%.1f us)\n", NCU, NW, NR, NM, \
+           double(steps) * 8 * 8192 / (ts * 10.0), ts / 100.0);                                                        \
+    hipFree(ticks);                                                                                                    \
+  } while (0)
+  RUNL(0, 0, 0, 105); RUNL(8, 0, 0, 105); RUNL(0, 8, 0, 105); RUNL(8, 8, 0, 105); RUNL(10, 12, 0, 105); RUNL(10, 12, 24, 105); RUNL(0, 0, 24, 105);
+  RUNL(16, 16, 0, 105); RUNL(0, 0, 0, 64); RUNL(10, 12, 24, 64); RUNL(0, 0, 0, 256); RUNL(10, 12, 24, 256);
   RUNS(4, 1, 128); RUNS(4, 2, 128); RUNS(4, 3, 128);
   RUNS(4, 1, 256); RUNS(4, 2, 256); RUNS(4, 3, 256);
   RUNS(6, 1, 128); RUNS(6, 2, 128); RUNS(6, 3, 128);
