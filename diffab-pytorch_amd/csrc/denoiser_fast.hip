@@ -447,7 +447,9 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   }
 #endif
   const int i0 = tile * TI;
-  const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane0 = tid & 63, wv = EXT_S ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (the wave index as a scalar: the addresses built from it stay in SGPRs, which takes the chunked instantiations from 13 spilled VGPRs
+  // + 56 B of scratch to none; the external-logits form is the one instantiation that gets worse with it)
   constexpr int HS = KC + 8, IS = AH * (KC + 8) + 8;  // == 8 (mod 64): both ds_read_b128 patterns on the image are conflict-free
   const int64_t prow0 = static_cast<int64_t>(b) * K;  // first projection row of this patch
   const float scale_t = 0.57735026918962576f;         // 3^-1/2   (diffab_pytorch.py:387, :439)
