@@ -185,6 +185,34 @@ def other_configs(model, dims, flags):
         res["k256_sampling"] = f"failed: {type(ex).__name__}: {ex}"
     gc.collect()
     torch.cuda.empty_cache()
+    try:  # BASELINE config 1: ONE K=128 patch through the whole 100-step reverse loop (eager launches, and one captured step replayed)
+        B, K = 1, 128
+        inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=3).items()}
+        hd, w = model.denoiser.hip_dims(B, K), model.denoiser.hip_weights()
+        sd_dev, tab = model._sched_on_device(), model._reverse_so3().struct()
+        ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
+        c1 = {"patches": B, "K": K, "steps": model.T}
+        for name, fl in (("ms_per_trajectory", flags), ("ms_per_trajectory_graph", flags | _hip.FLAG_GRAPH_SAMPLER)):
+            best = None
+            for rep in range(3):
+                seq, x, O = inp["seq_idx"].clone(), inp["translations"].clone(), inp["orientations"].clone()
+                _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(inp["generation_mask"]), 9, 0, B, K, model.T,
+                                                  _hip.stream_ptr()), "sample_init")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _hip.check(lib.diffab_sample_loop(C.byref(hd), C.byref(w.struct), C.byref(sd_dev.struct), C.byref(tab), _hip.ptr(seq), _hip.ptr(x),
+                                                  _hip.ptr(O), _hip.ptr(inp["res_context_emb"]), _hip.ptr(inp["pair_context_emb"]),
+                                                  _hip.ptr(inp["generation_mask"]), 9, 0, model.T, 0, _hip.ptr(ws), ws.numel(), fl,
+                                                  _hip.stream_ptr()), "sample_loop")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            c1[name] = best * 1e3
+        c1["finite"] = bool(torch.isfinite(x).all())
+        res["config1_one_patch"] = c1
+        del inp, ws
+    except Exception as ex:  # noqa: BLE001
+        res["config1_one_patch"] = f"failed: {type(ex).__name__}: {ex}"
     try:
         B, K, steps = 128, 128, 3
         inp = syn.patches(B, K, dims, seed=2)
