@@ -221,6 +221,67 @@ __global__ void igso3_sample_kernel(const float* __restrict__ sigmas, const floa
   rotvec[i * 3 + 2] = zz * theta;
 }
 
+// so3.py:78: `torch.multinomial(probs, num_samples)` draws the K bins of ONE patch WITHOUT replacement (its default).  The exponential
+// race is that distribution exactly (and is how torch itself draws it on a GPU): with E_b ~ Exp(1) independent, the bins ordered by
+// key_b = p_b / E_b, largest first, are a sample without replacement in draw order.  One work-group per patch: the n_bins keys of the
+// patch's sigma row go through a bitonic sort in LDS (order: larger key first, equal keys by lower bin index - a total order, so the
+// result does not depend on the network), the first K bin indices are the draws.  Bins of zero mass have key 0 and can only be drawn
+// when the row has fewer than K bins of positive mass (the reference raises there).
+__global__ __launch_bounds__(1024) void igso3_race_kernel(const float* __restrict__ pdf, int n_bins, int n_pad,
+                                                          const int64_t* __restrict__ sigma_idx, int K, const float* __restrict__ race,
+                                                          int32_t* __restrict__ bins) {
+  extern __shared__ float race_lds[];
+  float* key = race_lds;                                    // [n_pad]
+  int* idx = reinterpret_cast<int*>(race_lds + n_pad);      // [n_pad]
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const float* prow = pdf + static_cast<int64_t>(sigma_idx[b]) * n_bins;
+  const float* erow = race + static_cast<int64_t>(b) * n_bins;
+  for (int i = tid; i < n_pad; i += nt) {
+    key[i] = i < n_bins ? prow[i] / erow[i] : -1.0f;  // IEEE division (no fast-math): the host restatement gets the same bits
+    idx[i] = i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n_pad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n_pad; i += nt) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float ka = key[i], kb = key[l];
+          const int ia = idx[i], ib = idx[l];
+          const bool a_first = ka > kb || (ka == kb && ia < ib);  // a sorts in front of b
+          const bool asc = (i & k) == 0;                          // this segment puts its "first" elements at the low indices
+          if (a_first != asc) {
+            key[i] = kb; key[l] = ka;
+            idx[i] = ib; idx[l] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int r = tid; r < K; r += nt) bins[static_cast<int64_t>(b) * K + r] = idx[r];
+}
+
+// igso3_sample_kernel with the histogram bin given (drawn by igso3_race_kernel) instead of found by inverse CDF
+__global__ void igso3_sample_bins_kernel(const float* __restrict__ sigmas, int n_bins, float thr, const int64_t* __restrict__ sigma_idx,
+                                         int B, int K, const float* __restrict__ axis_raw, const int32_t* __restrict__ bins,
+                                         const float* __restrict__ u_in, const float* __restrict__ z, float* __restrict__ rotvec) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * K) return;
+  const float sigma = sigmas[sigma_idx[i / K]];
+  float theta;
+  if (sigma < thr) {
+    const double width = kPiD / n_bins;
+    theta = static_cast<float>(bins[i] * width) + static_cast<float>(width) * u_in[i];
+  } else {
+    theta = floor_mod_pi(sigma * 2.0f + sigma * z[i]);
+  }
+  float x = axis_raw[i * 3 + 0], y = axis_raw[i * 3 + 1], zz = axis_raw[i * 3 + 2];
+  normalize3(x, y, zz);
+  rotvec[i * 3 + 0] = x * theta;
+  rotvec[i * 3 + 1] = y * theta;
+  rotvec[i * 3 + 2] = zz * theta;
+}
+
 // ------------------------------------------------------------------ sequence diffusion
 constexpr int kV = 21;  // diffusion.py:47
 
@@ -747,6 +808,32 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
   if (n == 0) return DIFFAB_OK;
   hipLaunchKernelGGL(igso3_sample_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), tab->sigmas, tab->cdf, tab->n_bins,
                      tab->sigma_threshold, sigma_idx, B, K, axis_raw, u_bin, u_in, z, rotvec);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, int32_t n_bins, const int64_t* sigma_idx, int32_t B, int32_t K,
+                                          const float* race, int32_t* bins, void* stream) {
+  DIFFAB_REQUIRE(pdf && sigma_idx && race && bins && n_sigmas > 0 && n_bins > 0 && n_bins <= 16384 && B >= 0 && K > 0 && K <= n_bins,
+                 DIFFAB_ERR_ARG, "igso3_bins_without_replacement: bad argument (n_bins <= 16384, K <= n_bins)");
+  if (B == 0) return DIFFAB_OK;
+  int n_pad = 2;
+  while (n_pad < n_bins) n_pad <<= 1;
+  const int lds = n_pad * 8;
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(igso3_race_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(igso3_race_kernel, dim3(B), dim3(1024), lds, as_stream(stream), pdf, n_bins, n_pad, sigma_idx, K, race, bins);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_igso3_sample_bins(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
+                             const int32_t* bins, const float* u_in, const float* z, float* rotvec, void* stream) {
+  DIFFAB_REQUIRE(tab && tab->sigmas && tab->n_bins > 0 && sigma_idx && axis_raw && bins && u_in && z && rotvec && B >= 0 && K > 0,
+                 DIFFAB_ERR_ARG, "igso3_sample_bins: bad argument");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  if (n == 0) return DIFFAB_OK;
+  hipLaunchKernelGGL(igso3_sample_bins_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), tab->sigmas, tab->n_bins,
+                     tab->sigma_threshold, sigma_idx, B, K, axis_raw, bins, u_in, z, rotvec);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

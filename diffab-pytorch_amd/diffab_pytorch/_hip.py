@@ -100,6 +100,8 @@ SYMBOLS = {
     "diffab_igso3_table_build_accurate": (C.c_int, [_fp, _i32, _i32, _i32, _fp, _fp]),
     "diffab_igso3_cdf_build": (C.c_int, [_fp, _i32, _i32, _fp, _fp]),
     "diffab_igso3_sample": (C.c_int, [_PI, _fp, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "diffab_igso3_bins_without_replacement": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
+    "diffab_igso3_sample_bins": (C.c_int, [_PI, _fp, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
     "diffab_weighted_multinomial": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i64, _fp, _fp]),
     "diffab_seq_forward_prob": (C.c_int, [_PS, C.c_int, _fp, _fp, _fp, _i32, _i32, _fp, _fp]),
     "diffab_seq_posterior": (C.c_int, [_PS, _fp, _fp, _fp, _fp, _i32, _i32, _fp, _fp]),

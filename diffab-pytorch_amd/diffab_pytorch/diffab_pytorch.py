@@ -631,7 +631,9 @@ class DiffAb(_ModuleBase):
 
     def __init__(self, d_residue_emb, d_pair_emb, n_ipa_layers, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head, n_head,
                  T=100, s=0.01, beta_max=0.999, n_atoms=15, aa_vocab_size=21, max_dist_to_consider=32, lr=1e-4, weight_decay=0.0,
-                 betas=(0.9, 0.999)):
+                 betas=(0.9, 0.999), *, igso3_without_replacement: bool = False):
+        """The reference's constructor (diffab_pytorch.py:629-660).  `igso3_without_replacement` (keyword-only, build-defined): the forward
+        orientation noise draws a patch's K histogram bins without replacement, as the reference's torch.multinomial does (so3.py:78)."""
         super().__init__()
         self.sched = cosine_variance_schedule(T=T, s=s, beta_max=beta_max)
         self.residue_context_embedding = ResidueEmbedding(n_atoms, d_residue_emb)
@@ -640,7 +642,7 @@ class DiffAb(_ModuleBase):
                                  n_head, aa_vocab_size)
         self.seq_diffuser = SequenceDiffuser(T, s, beta_max, aa_vocab_size)
         self.coordinate_diffuser = CoordinateDiffuser(T, s, beta_max)
-        self.orientation_diffuser = OrientationDiffuser(T, s, beta_max)
+        self.orientation_diffuser = OrientationDiffuser(T, s, beta_max, igso3_without_replacement=igso3_without_replacement)
         self.aa_loss = nn.KLDivLoss(reduction="none")
         self.coordinate_loss = nn.MSELoss(reduction="none")
         self.orientation_loss = OrientationLoss(reduction="none")

@@ -12,8 +12,11 @@ Differences from the reference, all documented in DESIGN.md:
     table (fp32 terms, see SO3.__init__), with the float64 series as the opt-in ``accurate=True``;
   * random draws come from a Philox stream seeded from torch's default generator
     (``torch.manual_seed`` still makes calls reproducible) - or from explicit noise tensors;
-  * histogram bins are drawn by inverse CDF, i.e. WITH replacement across the residues of a patch
-    (the reference's torch.multinomial draws the K bins of one patch without replacement, so3.py:78).
+  * histogram bins are drawn by inverse CDF by default, i.e. WITH replacement across the residues of a patch; the reference's
+    torch.multinomial draws the K bins of one patch WITHOUT replacement (so3.py:78) - ``SO3(..., without_replacement=True)`` (or
+    ``sample_*(..., without_replacement=True)``) draws them that way, by the exponential race torch itself uses on a GPU
+    (``diffab_igso3_bins_without_replacement``).  The default stays the inverse CDF: per residue it follows the tabulated
+    density, which a draw without replacement does not when a row's mass sits in fewer than ~K bins (small sigma).
 """
 from __future__ import annotations
 
@@ -130,12 +133,13 @@ class SO3:
     """IGSO3 angle table + axis-angle sampler (so3.py:9-126)."""
 
     def __init__(self, sigmas_to_consider, cache_prefix=".cache/so3_histograms", sigma_threshold=0.1, n_bins=8192, num_iters=1024, *,
-                 accurate: bool = False):
+                 accurate: bool = False, without_replacement: bool = False):
         """``accurate=False`` (what DiffAb uses): the reference's table - every series term with the reference's own fp32
         roundings, so its rectified rounding noise (~1e-4 of spurious tail mass on the small-sigma rows) is part of the table,
         as it is part of what the reference samples from.  ``accurate=True``: the series in float64, i.e. the exact density."""
         lib = _hip.lib()
         self.accurate = bool(accurate)
+        self.without_replacement = bool(without_replacement)  # so3.py:78 (see the module docstring)
         self.n_bins = int(n_bins)
         self.num_iters = int(num_iters)
         self.sigma_threshold = float(sigma_threshold)
@@ -167,10 +171,44 @@ class SO3:
         _hip.check(lib.diffab_philox_fill(seed, 0, n, s, 0, 3, 0, _hip.ptr(nz), _hip.stream_ptr()), "diffab_philox_fill")
         return ax[..., :3].contiguous(), un[..., 0].contiguous(), un[..., 1].contiguous(), nz[..., 2].contiguous()
 
-    def _sample(self, sigma_idx, num_samples, threshold, axis_raw=None, u_bin=None, u_in=None, z=None, seed=None):
+    def draw_bins_without_replacement(self, sigma_idx, num_samples, *, race=None, seed=None) -> torch.Tensor:
+        """(n, num_samples) int32 histogram bins of rows sigma_idx, each row's draws WITHOUT replacement, in draw order - the joint
+        distribution of `torch.multinomial(self.histograms[sigma_idx], num_samples)` (so3.py:78).  `race` (n, n_bins): Exp(1) draws
+        (default: -log of Philox uniforms)."""
         lib = _hip.lib()
         idx = _hip.dev_i64(torch.as_tensor(sigma_idx))
         n, s = int(idx.numel()), int(num_samples)
+        if race is None:
+            seed = _draw_seed() if seed is None else seed
+            u = torch.empty(n, (self.n_bins + 3) // 4, 4, dtype=torch.float32, device=_hip.device())
+            _hip.check(lib.diffab_philox_fill(seed, 0, n, u.shape[1], 0, 5, 1, _hip.ptr(u), _hip.stream_ptr()), "diffab_philox_fill")  # stream 5: the race
+            race = -torch.log(u.view(n, -1)[:, :self.n_bins].clamp_min(1e-38)).contiguous()
+        race = _hip.dev_f32(race)
+        bins = torch.empty(n, s, dtype=torch.int32, device=idx.device)
+        _hip.check(lib.diffab_igso3_bins_without_replacement(_hip.ptr(self.histograms), int(self._sigmas.numel()), self.n_bins, _hip.ptr(idx), n,
+                                                             s, _hip.ptr(race), _hip.ptr(bins), _hip.stream_ptr()),
+                   "diffab_igso3_bins_without_replacement")
+        return bins
+
+    def _sample(self, sigma_idx, num_samples, threshold, axis_raw=None, u_bin=None, u_in=None, z=None, seed=None, without_replacement=None,
+                race=None):
+        lib = _hip.lib()
+        idx = _hip.dev_i64(torch.as_tensor(sigma_idx))
+        n, s = int(idx.numel()), int(num_samples)
+        norepl = self.without_replacement if without_replacement is None else bool(without_replacement)
+        if norepl and u_bin is None:  # explicit u_bin (the parity tests' captured draws) always means inverse CDF
+            if axis_raw is None or u_in is None or z is None:
+                a0, _, c0, d0 = self._noise(n, s, seed)
+                axis_raw = a0 if axis_raw is None else axis_raw
+                u_in = c0 if u_in is None else u_in
+                z = d0 if z is None else z
+            bins = self.draw_bins_without_replacement(idx, s, race=race, seed=seed)
+            axis_raw, u_in, z = (_hip.dev_f32(t) for t in (axis_raw, u_in, z))
+            out = torch.empty(n, s, 3, dtype=torch.float32, device=idx.device)
+            tab = self.struct(threshold)
+            _hip.check(lib.diffab_igso3_sample_bins(C.byref(tab), _hip.ptr(idx), n, s, _hip.ptr(axis_raw), _hip.ptr(bins), _hip.ptr(u_in),
+                                                    _hip.ptr(z), _hip.ptr(out), _hip.stream_ptr()), "diffab_igso3_sample_bins")
+            return out
         if axis_raw is None or u_bin is None or u_in is None or z is None:
             a0, b0, c0, d0 = self._noise(n, s, seed)
             axis_raw = a0 if axis_raw is None else axis_raw
@@ -184,11 +222,12 @@ class SO3:
                                            _hip.ptr(z), _hip.ptr(out), _hip.stream_ptr()), "diffab_igso3_sample")
         return out
 
-    def sample_from_histogram(self, sigma_idx, num_samples, *, u_bin=None, u_in=None):
+    def sample_from_histogram(self, sigma_idx, num_samples, *, u_bin=None, u_in=None, without_replacement=None, race=None):
         """Angles (n, num_samples) from the histogram rows (so3.py:74-84)."""
         n = int(torch.as_tensor(sigma_idx).numel())
         ax = torch.tensor([1.0, 0.0, 0.0]).expand(n, int(num_samples), 3)
-        r = self._sample(sigma_idx, num_samples, float("inf"), axis_raw=ax, u_bin=u_bin, u_in=u_in)
+        r = self._sample(sigma_idx, num_samples, float("inf"), axis_raw=ax, u_bin=u_bin, u_in=u_in, without_replacement=without_replacement,
+                         race=race)
         return _back(r[..., 0], torch.as_tensor(sigma_idx))
 
     def sample_from_gaussian(self, sigma_idx, num_samples, *, z=None):
@@ -199,7 +238,7 @@ class SO3:
         return _back(r[..., 0], torch.as_tensor(sigma_idx))
 
     def sample_isotropic_gaussian(self, sigma_idx: torch.LongTensor, num_samples: int, *, axis_raw=None, u_bin=None, u_in=None, z=None,
-                                  seed=None) -> torch.FloatTensor:
+                                  seed=None, without_replacement=None, race=None) -> torch.FloatTensor:
         """Rotation vectors (n, num_samples, 3) ~ IGSO3(sigma[sigma_idx])  (so3.py:98-126)."""
-        r = self._sample(sigma_idx, num_samples, None, axis_raw, u_bin, u_in, z, seed)
+        r = self._sample(sigma_idx, num_samples, None, axis_raw, u_bin, u_in, z, seed, without_replacement, race)
         return _back(r, torch.as_tensor(sigma_idx))

@@ -187,6 +187,15 @@ int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, f
 int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
                         const float* u_bin, const float* u_in, const float* z, float* rotvec, void* stream);
 
+/* so3.py:78  `torch.multinomial(probs, num_samples)` draws the K bins of a patch WITHOUT replacement.  bins (B,K) int32 = the K
+ * bins of histogram row sigma_idx[b] with the largest pdf[bin] / race[b][bin], largest first, ties by lower bin: with race (B, n_bins)
+ * ~ Exp(1) this is a draw without replacement in draw order (the exponential race torch itself uses on a GPU).  n_bins <= 16384. */
+int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, int32_t n_bins, const int64_t* sigma_idx, int32_t B,
+                                          int32_t K, const float* race, int32_t* bins, void* stream);
+/* diffab_igso3_sample with the histogram bins given (bins (B,K) from diffab_igso3_bins_without_replacement) instead of u_bin */
+int diffab_igso3_sample_bins(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
+                             const int32_t* bins, const float* u_in, const float* z, float* rotvec, void* stream);
+
 /* ---- forward (noising) process, explicit noise ----------------------------- */
 /* diffusion.py:38-41  out[b, ...] = w1[b] p1[b, ...] + w2[b] p2[b, ...]; n elements in all, per_b of them per patch */
 int diffab_weighted_multinomial(const float* p1, const float* p2, const float* w1, const float* w2, int64_t n, int64_t per_b,

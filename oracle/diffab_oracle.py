@@ -238,6 +238,23 @@ def igso3_bin_from_cdf(cdf_rows: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     return idx.clamp_max(cdf_rows.shape[-1] - 1)
 
 
+def igso3_bins_without_replacement(pdf_rows: torch.Tensor, race: torch.Tensor, num_samples: int) -> torch.Tensor:
+    """The K bins of each row drawn WITHOUT replacement, in draw order - the joint distribution of
+    `torch.multinomial(probs, num_samples)` (so3.py:78; replacement=False is its default) - as the exponential race:
+    with race ~ Exp(1) i.i.d., the bins ordered by probs / race, largest first (ties: lower bin), are such a draw.
+    pdf_rows, race: (n, n_bins) float32; returns (n, num_samples) int64."""
+    import numpy as np
+
+    key = (pdf_rows.float().numpy() / race.float().numpy()).astype(np.float32)  # IEEE float32 division, as the HIP kernel
+    n, nb = key.shape
+    out = np.empty((n, num_samples), dtype=np.int64)
+    ar = np.arange(nb)
+    for r in range(n):
+        order = np.lexsort((ar, -key[r].astype(np.float64)))  # primary: key descending, secondary: bin ascending
+        out[r] = order[:num_samples]
+    return torch.from_numpy(out)
+
+
 def igso3_theta_from_gaussian(sigma, z):
     """(2 sigma + sigma z) mod pi, floor-mod.  (so3.py:86-96)"""
     return (2.0 * sigma + sigma * z) % torch.pi

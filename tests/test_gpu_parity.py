@@ -270,6 +270,49 @@ def test_igso3_angle_distribution(hip):
     assert ax.mean((0, 1)).abs().max() < 0.02
 
 
+def test_igso3_bins_without_replacement(hip):
+    """so3.py:78 draws the K bins of a patch with torch.multinomial's default, i.e. WITHOUT replacement.  The HIP race kernel against
+    the oracle's restatement on the same Exp(1) draws (bit-exact bin sequences), no bin twice in a patch, the first draw of a patch
+    distributed like the table row, and - the signature of a draw without replacement - a row whose mass sits in a few bins spreads
+    over more than those bins, as the reference's own torch.multinomial does."""
+    from diffab_pytorch.diffusion import OrientationDiffuser
+
+    od = OrientationDiffuser(T=100, s=0.01, beta_max=0.999)
+    so3 = od.so3
+    g = torch.Generator().manual_seed(5)
+    rows = torch.tensor([1, 2, 5, 9, 9, 30, 2, 1])
+    for K in (19, 128, 256):
+        race = -torch.log(torch.rand(len(rows), so3.n_bins, generator=g).clamp_min(1e-30))
+        bins = so3.draw_bins_without_replacement(rows, K, race=race).cpu().long()
+        want = orc.igso3_bins_without_replacement(so3.histograms[rows].cpu(), race, K)
+        assert torch.equal(bins, want), (K, int((bins != want).sum()))
+        for r in range(len(rows)):
+            assert len(set(bins[r].tolist())) == K  # no bin twice
+    # first draw of a row ~ the row's pmf (KS against the CDF); 4096 independent races of row 5
+    n = 4096
+    torch.manual_seed(11)
+    first = so3.draw_bins_without_replacement(torch.full((n,), 5), 4)[:, 0].cpu().long()
+    cdf = so3._cdf[5].double().cpu()
+    emp = torch.sort(first).values
+    ks = (cdf[emp] - torch.arange(1, n + 1) / n).abs().max()
+    assert ks < 0.035, float(ks)
+    # joint behaviour against torch.multinomial itself (the reference's call) on a peaked row: number of distinct bins among the K
+    # draws is K for both, and the spread (95 % quantile of the drawn angles) agrees - with replacement it would be far narrower
+    t, K = 1, 128
+    p = so3.histograms[t].cpu()
+    ref = torch.multinomial(p.expand(256, -1), K)  # (256, K), each row without replacement
+    mine = so3.draw_bins_without_replacement(torch.full((256,), t), K).cpu().long()
+    q_ref, q_mine = ref.double().quantile(0.95), mine.double().quantile(0.95)
+    with_repl = torch.multinomial(p.expand(256, -1), K, replacement=True).double().quantile(0.95)
+    assert abs(float(q_ref - q_mine)) < 0.05 * float(q_ref), (float(q_ref), float(q_mine))
+    assert float(q_ref) > 1.02 * float(with_repl) or float(q_ref - with_repl) >= 1.0, (float(q_ref), float(with_repl))
+    # the sampler entry with the bins given: theta inside the drawn bin
+    th = so3.sample_from_histogram(rows, 128, without_replacement=True)
+    assert th.shape == (len(rows), 128) and bool(((th >= 0) & (th < np.pi)).all())
+    rv = so3.sample_isotropic_gaussian(torch.tensor([2, 60]), 64, without_replacement=True)
+    assert rv.shape == (2, 64, 3) and bool(torch.isfinite(rv).all())
+
+
 # ------------------------------------------------------------------ denoiser
 CASES = ["unit_wide", "unit_tight", "unit_ragged", "bench_wide", "bench_tight", "bench_k256"]
 

@@ -205,3 +205,30 @@ def test_featurize_xyz_definitions():
             assert abs(float(pd[1, l, l + 1, 1]) - float(bd[1, l, 1])) < 1e-12
         if m[1, l + 1, 0]:
             assert abs(float(pd[1, l, l + 1, 0]) - float(bd[1, l + 1, 0])) < 1e-12
+
+
+def test_oracle_bins_without_replacement_is_multinomial_without_replacement():
+    """The exponential race of oracle.igso3_bins_without_replacement has the joint distribution of torch.multinomial(probs, K)
+    (replacement=False, the reference's call at so3.py:78): checked on a small pmf where the inclusion probabilities are far from
+    K * p - the frequency of every bin among the K draws, and of every bin as FIRST draw, against torch.multinomial's own."""
+    import torch
+
+    import diffab_oracle as orc
+
+    torch.manual_seed(0)
+    p = torch.tensor([0.5, 0.2, 0.1, 0.1, 0.05, 0.03, 0.02, 0.0])
+    n, K = 40000, 3
+    race = -torch.log(torch.rand(n, len(p)).clamp_min(1e-30))
+    mine = orc.igso3_bins_without_replacement(p.expand(n, -1), race, K)
+    ref = torch.multinomial(p.expand(n, -1), K)
+    assert int((mine == 7).sum()) == 0  # a zero-mass bin is never drawn while enough positive ones exist
+    for r in range(n // 1000):
+        assert len(set(mine[r].tolist())) == K
+    inc_m = torch.bincount(mine.flatten(), minlength=8).double() / n
+    inc_r = torch.bincount(ref.flatten(), minlength=8).double() / n
+    assert (inc_m - inc_r).abs().max() < 0.012, (inc_m, inc_r)
+    first_m = torch.bincount(mine[:, 0], minlength=8).double() / n
+    assert (first_m - p.double()).abs().max() < 0.01
+    second_m = torch.bincount(mine[:, 1], minlength=8).double() / n
+    second_r = torch.bincount(ref[:, 1], minlength=8).double() / n
+    assert (second_m - second_r).abs().max() < 0.012
