@@ -86,7 +86,9 @@ def test_diffab_constructor_surface(monkeypatch):
     from diffab_pytorch import DiffAb
 
     sig = inspect.signature(DiffAb.__init__)
-    assert list(sig.parameters)[1:] == ["d_residue_emb", "d_pair_emb", "n_ipa_layers", "d_scalar_per_head", "n_query_point_per_head",
+    extra = [n for n, q in sig.parameters.items() if q.kind is inspect.Parameter.KEYWORD_ONLY]
+    assert extra == ["igso3_without_replacement"] and sig.parameters["igso3_without_replacement"].default is False  # build-defined, opt-in
+    assert [n for n in list(sig.parameters)[1:] if n not in extra] == ["d_residue_emb", "d_pair_emb", "n_ipa_layers", "d_scalar_per_head", "n_query_point_per_head",
                                         "n_value_point_per_head", "n_head", "T", "s", "beta_max", "n_atoms", "aa_vocab_size",
                                         "max_dist_to_consider", "lr", "weight_decay", "betas"]
     for m in ("encode_context", "denoise", "sample", "_add_noise", "_shared_step", "training_step", "validation_step",
