@@ -80,3 +80,8 @@ if os.environ.get("ATTN_TIMESERIES", "0") != "0":
         ent = (a >= lo) & (a < hi)
         dur = (b_ - a)[ent].mean() / 1e3 if ent.any() else float("nan")
         print(f"   {lo / 1e3:7.0f} .. {hi / 1e3:7.0f} | {inside:6.1f} | {dur:6.1f}  (n = {int(ent.sum())})")
+p2 = s[..., 3] - s[..., 2]
+print("  phase 2 by wave: " + "  ".join(f"w{w}: {p2[:, w].mean():.0f}" for w in range(8)))
+print(f"  phase 2 within a work-group: slowest wave - mean wave = {(p2.max(dim=1).values - p2.mean(dim=1)).mean():.0f}, "
+      f"slowest - fastest = {(p2.max(dim=1).values - p2.min(dim=1).values).mean():.0f}; which wave is slowest: "
+      + " ".join(f"{int((p2.argmax(dim=1) == w).sum())}" for w in range(8)))
