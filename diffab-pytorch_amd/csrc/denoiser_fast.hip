@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "denoiser_internal.h"
+#include "rowgemm_b6_tile.h"
 
 namespace diffab {
 
@@ -393,14 +394,29 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 // table of direct differences that the work-group builds once per chunk: 12 MFMAs of 16 cycles and ~10 VALU instructions per key
 // tile against 8 f32 MFMAs of 32 cycles and 96 packed VALU instructions, no LDS staging, linear 1 KiB operand loads.
 // qkp = query-side operands (f32x4 units), key side kside_off further.
-template <int NT, bool MULTI, bool EXT_S = false, bool PLANES = false, bool B6L = false>
+// QUEUE (EXPERIMENTAL build, PLANES single-chunk form only; profiles/r03_lockstep.md): a persistent grid of one work-group per CU pulls work
+// items from one queue per XCD (the XCD is read from the hardware id, so producer and consumer of a patch share an L2): first the
+// (patch, row tile) attention items of the XCD's patches, then one to_out item per patch (128 rows x 128 columns, rowgemm_b6_tile.h),
+// which waits until the patch's row tiles have all signalled completion.  The first item of a work-group is delayed by its class x
+// qa.stagger_ticks (100 MHz): the CUs' pair-stream phases stop coinciding, and the ragged end of the attention items is filled by
+// to_out items instead of idling.  Same arithmetic per item as the two separate launches.
+struct AttnQueue {
+  int* ctr;               // [8] item counters, then [B] completed row tiles per patch; zeroed in front of the launch
+  const void* wo_planes;  // to_out weights as split planes (launch_wsplit128)
+  const float* wo_bias;
+  float* y;               // (B K, 128) layer output
+  int stagger_ticks;
+};
+template <int NT, bool MULTI, bool EXT_S = false, bool PLANES = false, bool B6L = false, bool QUEUE = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps,
                                                             const float* __restrict__ Sg = nullptr, const float* __restrict__ esc = nullptr,
-                                                            const f32x4* __restrict__ qkp = nullptr, int64_t kside_off = 0) {
+                                                            const f32x4* __restrict__ qkp = nullptr, int64_t kside_off = 0,
+                                                            AttnQueue qa = AttnQueue{}) {
+  static_assert(!QUEUE || (PLANES && !MULTI && !EXT_S && !B6L), "work-queue form: single-chunk planes kernel only");
   static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
   static_assert(!B6L || (PLANES && !EXT_S), "operand-plane logits: PLANES form only");
@@ -415,6 +431,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   const int K = NC * KC;
   const int ntile = K / TI;
   // diagnostic s_memtime stamps (stamps == nullptr in every production launch: nothing below executes)
+  unsigned stamp_slot = blockIdx.x;  // QUEUE: the item's (patch, row tile) index in the default launch order
   auto stamp = [&](int k) {
     if (stamps != nullptr) {
       __builtin_amdgcn_sched_barrier(0);
@@ -423,15 +440,72 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #else
       const unsigned long long tnow = __builtin_amdgcn_s_memtime();
 #endif
-      if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
+      if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(stamp_slot) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  stamp(0);
+  if constexpr (!QUEUE) stamp(0);
+  __shared__ int q_item;
+  unsigned q_xcd = 0;
+  bool q_first = true;
+  if constexpr (QUEUE) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(q_xcd));
+  q_xcd &= 7;
+  int q_next = 0;  // thread 0: the ticket of the NEXT item, requested while the current one runs (the atomic's round trip is hidden)
+  if constexpr (QUEUE)
+    if (threadIdx.x == 0) q_next = atomicAdd(qa.ctr + q_xcd, 1);
+  for (;;) {  // QUEUE: one iteration per work item; otherwise executed once
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
   const unsigned bid = blockIdx.x;
-  if ((B & 7) == 0) {
+  if constexpr (QUEUE) {
+    __syncthreads();  // every wave is done with the previous item's LDS
+    if (threadIdx.x == 0) q_item = q_next;
+    __syncthreads();
+    const int item = q_item, per_xcd = B >> 3, n_att = per_xcd * ntile;
+    if (item >= n_att + per_xcd) break;
+    if (threadIdx.x == 0) q_next = atomicAdd(qa.ctr + q_xcd, 1);
+    if (q_first && qa.stagger_ticks > 0) {
+      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + static_cast<unsigned long long>((blockIdx.x >> 3) & 7) * qa.stagger_ticks;
+      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+    q_first = false;
+    // Queue order: the row tiles of the first QD patches, then per further patch p one to_out item (patch p - QD, whose row tiles
+    // were handed out a generation of work-groups earlier) in front of p's ntile row tiles, then the last QD to_out items.  The
+    // to_out items are spread over the launch (they run on the matrix cores beside other CUs' pair streams) and knock the CUs out
+    // of step with each other.
+#ifndef DIFFAB_QUEUE_DEPTH
+#define DIFFAB_QUEUE_DEPTH 32  // >= patches per XCD at B = 256: every to_out item behind the attention items (interleaved was slower)
+#endif
+    constexpr int QD = DIFFAB_QUEUE_DEPTH;
+    int att_p = -1, att_t = 0, out_p = -1;
+    const int head = QD * ntile, body = (ntile + 1) * (per_xcd - QD);
+    if (per_xcd <= QD) {
+      if (item < n_att) { att_p = item / ntile; att_t = item % ntile; } else out_p = item - n_att;
+    } else if (item < head) {
+      att_p = item / ntile; att_t = item % ntile;
+    } else if (item < head + body) {
+      const int r_ = item - head, g_ = r_ / (ntile + 1), o_ = r_ % (ntile + 1);
+      if (o_ == 0) out_p = g_; else { att_p = QD + g_; att_t = o_ - 1; }
+    } else {
+      out_p = per_xcd - QD + (item - head - body);
+    }
+    if (out_p >= 0) {  // to_out of patch pb: its ntile row tiles were handed out earlier from this same queue
+      const int pb = out_p * 8 + static_cast<int>(q_xcd);
+      if (threadIdx.x == 0)
+        while (__hip_atomic_load(qa.ctr + 8 + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile) __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of feat may be served from this CU's L1
+      int tid_o = threadIdx.x;  // opaque copy: nothing of the tile function is hoisted out of the item loop
+      asm volatile("" : "+v"(tid_o));
+      b6tile::rowgemm128_tile<false, 128>(reinterpret_cast<__bf16*>(S), tid_o, pb * (K / 128), feat, AF, static_cast<const __bf16*>(qa.wo_planes),
+                                          qa.wo_bias, nullptr, 0, qa.y, 128, B * K, AF);
+      continue;
+    }
+    b = att_p * 8 + static_cast<int>(q_xcd);
+    tile = att_t;
+    stamp_slot = static_cast<unsigned>(att_p * ntile + att_t) * 8 + q_xcd;
+    stamp(0);
+  } else if ((B & 7) == 0) {
     const int xcd = bid & 7, slot = bid >> 3;
     b = (slot / ntile) * 8 + xcd;
     tile = slot % ntile;
@@ -447,7 +521,9 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   }
 #endif
   const int i0 = tile * TI;
-  const int tid = threadIdx.x, lane0 = tid & 63, wv = EXT_S ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tid_v = threadIdx.x;
+  if constexpr (QUEUE) asm volatile("" : "+v"(tid_v));  // (item loop: recompute the lane coordinates per item instead of keeping them all live)
+  const int tid = tid_v, lane0 = tid & 63, wv = EXT_S ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   // (the wave index as a scalar: the addresses built from it stay in SGPRs, which takes the chunked instantiations from 13 spilled VGPRs
   // + 56 B of scratch to none; the external-logits form is the one instantiation that gets worse with it)
   constexpr int HS = KC + 8, IS = AH * (KC + 8) + 8;  // == 8 (mod 64): both ds_read_b128 patterns on the image are conflict-free
@@ -1200,7 +1276,16 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     }
     if (!last) __syncthreads();  // the next chunk's phase 1 overwrites the image
   }
-  stamp(5);
+  if constexpr (QUEUE) {  // this row tile's feature rows are in L2 (write-through L1; same XCD as the to_out item that reads them)
+    stamp(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(qa.ctr + 8 + b, 1);
+  } else {
+    break;
+  }
+  }  // work items
+  if constexpr (!QUEUE) stamp(5);
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
@@ -1725,6 +1810,34 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                        reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
     timer_end(st);                                                                                                                    \
   } while (0)
+#ifdef DIFFAB_EXPERIMENTAL
+  // DIFFAB_ATTN_QUEUE=1: attention + to_out of the layer as ONE persistent launch over per-XCD work queues (QUEUE form of the kernel),
+  // first items staggered by DIFFAB_ATTN_QUEUE_STAGGER ticks of 10 ns per class (default 500)
+  static const bool env_queue = env_int("DIFFAB_ATTN_QUEUE", 0) != 0;
+  static const int env_queue_ticks = env_int("DIFFAB_ATTN_QUEUE_STAGGER", 500);
+  if (env_queue && !b6l && pair_planes != nullptr && attn_mode == 0 && nt == 8 && nc == 1 && (d->B & 7) == 0 && b6 && attention_split_supported(d) &&
+      rowgemm128_b6_ok(feat, AF, y, D, rows, AF)) {
+    int* qctr = reinterpret_cast<int*>(SPx);
+    DIFFAB_HIP_CHECK(hipMemsetAsync(qctr, 0, sizeof(int) * (8 + static_cast<size_t>(d->B)), st));
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      DIFFAB_HIP_CHECK(hipGetDevice(&dev));
+      DIFFAB_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int groups = static_cast<int>(grid.x) < n_cu ? static_cast<int>(grid.x) : n_cu;
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<8, false, false, true, false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    AttnQueue qa{qctr, out_planes, w->b_out, y, env_queue_ticks};
+    timer_begin(st);
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<8, false, false, true, false, true>), dim3(groups), dim3(512), lds, st, proj, pair_planes + 64, R, t,
+                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_row_scales(d, pair_planes),
+                       static_cast<const f32x4*>(nullptr), static_cast<int64_t>(0), qa);
+    timer_end(st);
+    DIFFAB_LAUNCH_CHECK();
+    return DIFFAB_OK;
+  }
+#endif
 #ifdef DIFFAB_EXPERIMENTAL
   if (b6l && pipe) {
     if (int rc = launch_attention_pipe(d, proj, pair_planes, R, t, w->w_bias, w->gamma, feat, qk_ops, st)) return rc;

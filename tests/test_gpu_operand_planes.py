@@ -127,3 +127,17 @@ def test_operand_planes_vs_float64(hip, B, K, sigma, offset):
     assert maxrel(pc[..., 512:768], want_vs) < 2e-6
     assert maxrel(pc[..., 1152:1344], want_gv) < 2e-6
     assert torch.isnan(pc[..., :512]).all() and torch.isnan(pc[..., 768:1152]).all()  # nothing else is written
+
+
+def test_queue_driven_attention_and_to_out_is_bitwise_the_default(hip):
+    """EXPERIMENTAL build, DIFFAB_ATTN_QUEUE=1: attention + to_out of a layer as ONE persistent launch over per-XCD work queues (the QUEUE
+    form of ipa_attn_fast_kernel, profiles/r03_lockstep.md section 5).  Same arithmetic per work item, so the layer output must be
+    bitwise the default two launches.  The switch is read from the environment once per process: tools/queue_check.py runs the variants in
+    child processes and compares the saved outputs."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools", "queue_check.py"), "16"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "variant 1 bitwise equal to the default: True" in out.stdout and "variant 2 bitwise equal to the default: True" in out.stdout, out.stdout
