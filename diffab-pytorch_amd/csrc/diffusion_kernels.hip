@@ -749,8 +749,9 @@ static int check_sched(const diffab_sched* s) {
 }
 
 #define ELEMENTWISE_ENTRY(NAME, KERNEL, NPTR_OK, N, ...)                                              \
-  DIFFAB_REQUIRE((NPTR_OK) && (N) >= 0, DIFFAB_ERR_ARG, NAME ": null pointer or negative count");     \
-  if ((N) == 0) return DIFFAB_OK;                                                                     \
+  DIFFAB_REQUIRE((N) >= 0, DIFFAB_ERR_ARG, NAME ": negative count");                                  \
+  if ((N) == 0) return DIFFAB_OK; /* empty tensors carry null pointers */                             \
+  DIFFAB_REQUIRE((NPTR_OK), DIFFAB_ERR_ARG, NAME ": null pointer");                                   \
   hipLaunchKernelGGL(KERNEL, dim3(blocks_for(N)), dim3(kThreads), 0, as_stream(stream), __VA_ARGS__); \
   DIFFAB_LAUNCH_CHECK();                                                                              \
   return DIFFAB_OK;
@@ -801,11 +802,10 @@ int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, f
 
 int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw, const float* u_bin,
                         const float* u_in, const float* z, float* rotvec, void* stream) {
-  DIFFAB_REQUIRE(tab && tab->sigmas && tab->cdf && tab->n_bins > 0 && sigma_idx && axis_raw && u_bin && u_in && z && rotvec && B >= 0 &&
-                     K > 0,
-                 DIFFAB_ERR_ARG, "igso3_sample: bad argument");
+  DIFFAB_REQUIRE(tab && tab->sigmas && tab->cdf && tab->n_bins > 0 && B >= 0 && K >= 0, DIFFAB_ERR_ARG, "igso3_sample: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
-  if (n == 0) return DIFFAB_OK;
+  if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
+  DIFFAB_REQUIRE(sigma_idx && axis_raw && u_bin && u_in && z && rotvec, DIFFAB_ERR_ARG, "igso3_sample: null pointer");
   hipLaunchKernelGGL(igso3_sample_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), tab->sigmas, tab->cdf, tab->n_bins,
                      tab->sigma_threshold, sigma_idx, B, K, axis_raw, u_bin, u_in, z, rotvec);
   DIFFAB_LAUNCH_CHECK();
@@ -814,9 +814,10 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
 
 int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, int32_t n_bins, const int64_t* sigma_idx, int32_t B, int32_t K,
                                           const float* race, int32_t* bins, void* stream) {
-  DIFFAB_REQUIRE(pdf && sigma_idx && race && bins && n_sigmas > 0 && n_bins > 0 && n_bins <= 16384 && B >= 0 && K > 0 && K <= n_bins,
-                 DIFFAB_ERR_ARG, "igso3_bins_without_replacement: bad argument (n_bins <= 16384, K <= n_bins)");
-  if (B == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(n_sigmas > 0 && n_bins > 0 && n_bins <= 16384 && B >= 0 && K >= 0 && K <= n_bins, DIFFAB_ERR_ARG,
+                 "igso3_bins_without_replacement: bad argument (n_bins <= 16384, K <= n_bins)");
+  if (B == 0 || K == 0) return DIFFAB_OK;  // empty tensors carry null pointers
+  DIFFAB_REQUIRE(pdf && sigma_idx && race && bins, DIFFAB_ERR_ARG, "igso3_bins_without_replacement: null pointer");
   int n_pad = 2;
   while (n_pad < n_bins) n_pad <<= 1;
   const int lds = n_pad * 8;
@@ -828,10 +829,10 @@ int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, in
 
 int diffab_igso3_sample_bins(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
                              const int32_t* bins, const float* u_in, const float* z, float* rotvec, void* stream) {
-  DIFFAB_REQUIRE(tab && tab->sigmas && tab->n_bins > 0 && sigma_idx && axis_raw && bins && u_in && z && rotvec && B >= 0 && K > 0,
-                 DIFFAB_ERR_ARG, "igso3_sample_bins: bad argument");
+  DIFFAB_REQUIRE(tab && tab->sigmas && tab->n_bins > 0 && B >= 0 && K >= 0, DIFFAB_ERR_ARG, "igso3_sample_bins: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(sigma_idx && axis_raw && bins && u_in && z && rotvec, DIFFAB_ERR_ARG, "igso3_sample_bins: null pointer");
   hipLaunchKernelGGL(igso3_sample_bins_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), tab->sigmas, tab->n_bins,
                      tab->sigma_threshold, sigma_idx, B, K, axis_raw, bins, u_in, z, rotvec);
   DIFFAB_LAUNCH_CHECK();
@@ -847,9 +848,10 @@ int diffab_weighted_multinomial(const float* p1, const float* p2, const float* w
 int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq, const int64_t* t, const uint8_t* mask, int32_t B,
                             int32_t K, float* prob, void* stream) {
   if (int rc = check_sched(s)) return rc;
-  DIFFAB_REQUIRE(seq && t && mask && prob && B >= 0 && K > 0 && (mode == 0 || mode == 1), DIFFAB_ERR_ARG, "seq_forward_prob: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && K >= 0 && (mode == 0 || mode == 1), DIFFAB_ERR_ARG, "seq_forward_prob: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
-  if (n == 0) return DIFFAB_OK;
+  if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
+  DIFFAB_REQUIRE(seq && t && mask && prob, DIFFAB_ERR_ARG, "seq_forward_prob: null pointer");
   hipLaunchKernelGGL(seq_forward_prob_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->beta, s->alpha_bar, s->T, mode,
                      seq, t, mask, B, K, prob);
   DIFFAB_LAUNCH_CHECK();
@@ -859,9 +861,10 @@ int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq,
 int diffab_seq_posterior(const diffab_sched* s, const int64_t* seq_t, const int64_t* seq_0, const int64_t* t, const uint8_t* mask,
                          int32_t B, int32_t K, float* post, void* stream) {
   if (int rc = check_sched(s)) return rc;
-  DIFFAB_REQUIRE(seq_t && seq_0 && t && mask && post && B >= 0 && K > 0, DIFFAB_ERR_ARG, "seq_posterior: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && K >= 0, DIFFAB_ERR_ARG, "seq_posterior: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(seq_t && seq_0 && t && mask && post, DIFFAB_ERR_ARG, "seq_posterior: null pointer");
   hipLaunchKernelGGL(seq_posterior_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->beta, s->alpha_bar, s->T, seq_t,
                      seq_0, t, mask, B, K, post);
   DIFFAB_LAUNCH_CHECK();
@@ -876,9 +879,10 @@ int diffab_categorical_sample(const float* prob, const float* u, int64_t n_rows,
 int diffab_coord_forward(const diffab_sched* s, const float* x0, const int64_t* t, const uint8_t* mask, const float* eps, int32_t B,
                          int32_t K, float* xt, void* stream) {
   if (int rc = check_sched(s)) return rc;
-  DIFFAB_REQUIRE(x0 && t && mask && eps && xt && B >= 0 && K > 0, DIFFAB_ERR_ARG, "coord_forward: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && K >= 0, DIFFAB_ERR_ARG, "coord_forward: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(x0 && t && mask && eps && xt, DIFFAB_ERR_ARG, "coord_forward: null pointer");
   hipLaunchKernelGGL(coord_forward_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->alpha_bar_sqrt,
                      s->one_minus_alpha_bar_sqrt, s->T, x0, t, mask, eps, B, K, xt);
   DIFFAB_LAUNCH_CHECK();
@@ -888,9 +892,10 @@ int diffab_coord_forward(const diffab_sched* s, const float* x0, const int64_t* 
 int diffab_orient_forward(const diffab_sched* s, const float* O0, const uint8_t* mask, const int64_t* t, const float* rotvec, int32_t B,
                           int32_t K, float* Ot, void* stream) {
   if (int rc = check_sched(s)) return rc;
-  DIFFAB_REQUIRE(O0 && t && mask && rotvec && Ot && B >= 0 && K > 0, DIFFAB_ERR_ARG, "orient_forward: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && K >= 0, DIFFAB_ERR_ARG, "orient_forward: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(O0 && t && mask && rotvec && Ot, DIFFAB_ERR_ARG, "orient_forward: null pointer");
   hipLaunchKernelGGL(orient_forward_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), s->alpha_bar_sqrt, s->T, O0, mask, t,
                      rotvec, B, K, Ot);
   DIFFAB_LAUNCH_CHECK();
@@ -899,9 +904,10 @@ int diffab_orient_forward(const diffab_sched* s, const float* O0, const uint8_t*
 
 int diffab_philox_fill(uint64_t seed, int64_t first_patch, int32_t B, int32_t K, int32_t step, int32_t stream_id, int kind, float* out,
                        void* stream) {
-  DIFFAB_REQUIRE(out && B >= 0 && K > 0 && (kind == 0 || kind == 1), DIFFAB_ERR_ARG, "philox_fill: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && K >= 0 && (kind == 0 || kind == 1), DIFFAB_ERR_ARG, "philox_fill: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(out, DIFFAB_ERR_ARG, "philox_fill: null pointer");
   hipLaunchKernelGGL(philox_fill_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), seed, first_patch, B, K, step, stream_id,
                      kind, out);
   DIFFAB_LAUNCH_CHECK();
@@ -937,26 +943,29 @@ int diffab_orientation_loss_bwd(const float* pred, const float* target, int64_t 
 }
 
 int diffab_frames_apply(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream) {
-  DIFFAB_REQUIRE(x && R && out && B >= 0 && N > 0 && L > 0 && P > 0, DIFFAB_ERR_ARG, "frames_apply: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && N >= 0 && L >= 0 && P >= 0, DIFFAB_ERR_ARG, "frames_apply: negative extent");
   const int64_t n = static_cast<int64_t>(B) * N * L * P;
-  if (n == 0) return DIFFAB_OK;
+  if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
+  DIFFAB_REQUIRE(x && R && out, DIFFAB_ERR_ARG, "frames_apply: null pointer");
   hipLaunchKernelGGL(frames_kernel<false>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, R, t, out, N, L, P, n);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
 
 int diffab_frames_invert(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream) {
-  DIFFAB_REQUIRE(x && R && out && B >= 0 && N > 0 && L > 0 && P > 0, DIFFAB_ERR_ARG, "frames_invert: bad argument");
+  DIFFAB_REQUIRE(B >= 0 && N >= 0 && L >= 0 && P >= 0, DIFFAB_ERR_ARG, "frames_invert: negative extent");
   const int64_t n = static_cast<int64_t>(B) * N * L * P;
-  if (n == 0) return DIFFAB_OK;
+  if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
+  DIFFAB_REQUIRE(x && R && out, DIFFAB_ERR_ARG, "frames_invert: null pointer");
   hipLaunchKernelGGL(frames_kernel<true>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, R, t, out, N, L, P, n);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
 
 int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float* out, void* stream) {
-  DIFFAB_REQUIRE(x && out && n >= 0 && num_funcs > 0, DIFFAB_ERR_ARG, "angular_encoding: bad argument");
-  if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(n >= 0 && num_funcs > 0, DIFFAB_ERR_ARG, "angular_encoding: bad argument");
+  if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
+  DIFFAB_REQUIRE(x && out, DIFFAB_ERR_ARG, "angular_encoding: null pointer");
   hipLaunchKernelGGL(angular_encoding_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, n, num_funcs, out);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;

@@ -26,6 +26,7 @@
  *     before it returns.  (Kernel variants that were measured and not adopted, and
  *     the environment switches used to A/B them, exist only in the EXPERIMENTAL
  *     build of this library - `make EXPERIMENTAL=1`, include/diffab_hip_experimental.h.)
+ *   - empty problems (a count or extent of 0) return 0 before any pointer is looked at: an empty tensor's data pointer is NULL;
  *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
  *     diffab_last_error() gives the thread's last message.
  */

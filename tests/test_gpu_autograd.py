@@ -159,3 +159,43 @@ def test_backbone_from_sampled_frames_on_the_device(hip):
     with tempfile.TemporaryDirectory() as tmp:
         n = dio.write_pdb(os.path.join(tmp, "p.pdb"), inp["seq_idx"][0].cuda(), x[0], O[0])
         assert n == 24 * 4
+
+
+def test_empty_and_odd_inputs_through_the_elementwise_entries():
+    """Edge cases of the entries that take free-form tensors: an EMPTY batch (torch's empty tensors carry null pointers: the C ABI returns
+    before it looks at them), non-contiguous and float64 inputs (made contiguous fp32 by the wrappers), and the without-replacement bin
+    draw with a table whose bin count is not a power of two, K = n_bins (a permutation of all bins) and K > n_bins (an error)."""
+    import diffab_oracle as orc
+    from diffab_pytorch import _hip, so3 as S
+    from diffab_pytorch.diffab_pytorch import AngularEncoding, euclidean_transform, inverse_euclidean_transform
+    from diffab_pytorch.diffusion import CoordinateDiffuser, OrientationDiffuser, SequenceDiffuser
+
+    g = torch.Generator().manual_seed(0)
+    R = torch.linalg.qr(torch.randn(2, 5, 3, 3, generator=g)).Q.cuda()
+    t = torch.randn(2, 5, 3, generator=g).cuda()
+    x = torch.randn(2, 4, 5, 3, 3, generator=g).cuda()
+    y = euclidean_transform(x, R, t)
+    assert euclidean_transform(x[:0], R[:0], t[:0]).shape == (0, 4, 5, 3, 3)
+    assert inverse_euclidean_transform(y[:0], R[:0], t[:0]).shape == (0, 4, 5, 3, 3)
+    xn = torch.randn(2, 4, 5, 3, 6, generator=g).cuda()[..., ::2]
+    assert torch.equal(euclidean_transform(xn, R, t), euclidean_transform(xn.contiguous(), R, t))
+    assert torch.equal(euclidean_transform(x.double(), R.double(), t.double()).float(), y)
+    assert float((inverse_euclidean_transform(y, R, t) - x).abs().max()) < 1e-5
+    ae = AngularEncoding()
+    a = torch.randn(3, 7, 2, generator=g).cuda()
+    assert ae(a[:0]).shape == (0, 7, ae(a).shape[-1])
+    e_seq, e_m, e_t = torch.zeros(0, 16, dtype=torch.long).cuda(), torch.zeros(0, 16, dtype=torch.bool).cuda(), torch.zeros(0, dtype=torch.long).cuda()
+    first = lambda r: r[0] if isinstance(r, tuple) else r
+    assert first(SequenceDiffuser(100, 0.01, 0.999, 21).diffuse_from_t0(e_seq, e_t, e_m)).shape == (0, 16)
+    assert first(CoordinateDiffuser(100, 0.01, 0.999).diffuse_from_t0(torch.zeros(0, 16, 3).cuda(), e_t, e_m)).shape == (0, 16, 3)
+    assert first(OrientationDiffuser(100, 0.01, 0.999).diffuse_from_t0(torch.zeros(0, 16, 3, 3).cuda(), e_m, e_t)).shape == (0, 16, 3, 3)
+    assert S.log_rotmat(torch.zeros(0, 3, 3).cuda()).shape == (0, 3, 3)
+    so = S.SO3(torch.linspace(0.02, 1.5, 16), n_bins=1000, num_iters=256)
+    rows = torch.tensor([0, 3, 15])
+    race = -torch.log(torch.rand(3, 1000, generator=g).clamp_min(1e-30))
+    b = so.draw_bins_without_replacement(rows, 1000, race=race).cpu().long()
+    assert torch.equal(b, orc.igso3_bins_without_replacement(so.histograms[rows].cpu(), race, 1000))
+    assert all(sorted(r.tolist()) == list(range(1000)) for r in b)
+    assert so.draw_bins_without_replacement(rows[:0], 8, race=race[:0]).shape == (0, 8)
+    with pytest.raises(_hip.DiffabHipError):
+        so.draw_bins_without_replacement(rows, 1001, race=race)
