@@ -194,6 +194,8 @@ class InvariantPointAttentionLayer(nn.Module):
 
     def forward(self, x, e, r, t, *, flags: int = 0):
         lib = _hip.lib()
+        if x.shape[0] == 0 or x.shape[1] == 0:  # empty batch / empty patch: nothing to launch (the reference's einsums return empty too)
+            return torch.zeros(x.shape, dtype=torch.float32, device=x.device)
         if _wants_grad(self, x, e, r, t):  # differentiable like the reference's forward (:389-465): taped HIP forward + HIP backward
             _no_frame_grads("InvariantPointAttentionLayer", r, t)
             return _IpaLayerFn.apply(self, flags & ~_hip.FLAG_PAIR_PLANES, x, e, r, t, *[p for _, p in self.named_parameters()])
@@ -263,6 +265,15 @@ class Denoiser(nn.Module):
                 residue_mask=None, *, return_logits: bool = False, flags: int = 0) -> Dict[str, torch.Tensor]:
         # generation_mask / residue_mask are accepted and ignored, exactly like the reference (:566-567).
         lib = _hip.lib()
+        if seq_idx_t.shape[0] == 0 or seq_idx_t.shape[1] == 0:  # empty batch: empty outputs, like the reference
+            B0, K0 = seq_idx_t.shape[:2]
+            dev0, V0 = translations_t.device, self.dims["V"]
+            out0 = {"translations_eps": torch.zeros(B0, K0, 3, device=dev0), "orientations_t0": torch.zeros(B0, K0, 3, 3, device=dev0),
+                    "seq_posterior": torch.zeros(B0, K0, V0, device=dev0)}
+            if return_logits:
+                out0["aa_logits"] = torch.zeros(B0, K0, V0, device=dev0)
+                out0["res_emb"] = torch.zeros(B0, K0, self.dims["D"], device=dev0)
+            return out0
         if not return_logits and _wants_grad(self, res_context_emb, pair_context_emb, translations_t, orientations_t):
             # differentiable like the reference's forward (:558-607): taped HIP forward + HIP backward from the outputs' cotangents
             # (return_logits=True is an inference-only diagnostic of this package: detached outputs)

@@ -199,3 +199,13 @@ def test_empty_and_odd_inputs_through_the_elementwise_entries():
     assert so.draw_bins_without_replacement(rows[:0], 8, race=race[:0]).shape == (0, 8)
     with pytest.raises(_hip.DiffabHipError):
         so.draw_bins_without_replacement(rows, 1001, race=race)
+    # an empty batch through the layer and the denoiser: empty outputs, as the reference's einsums give
+    from diffab_pytorch.diffab_pytorch import Denoiser, InvariantPointAttentionLayer
+
+    d = syn.BENCH_DIMS
+    layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    assert layer(z(0, 64, d["D"]), z(0, 64, 64, d["C"]), z(0, 64, 3, 3), z(0, 64, 3)).shape == (0, 64, d["D"])
+    den = Denoiser(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"], 21).cuda()
+    out = den(torch.zeros(0, 64, dtype=torch.long, device="cuda"), z(0, 64, 3), z(0, 64, 3, 3), z(0, 64, d["D"]), z(0, 64, 64, d["C"]), z(0))
+    assert out["translations_eps"].shape == (0, 64, 3) and out["orientations_t0"].shape == (0, 64, 3, 3) and out["seq_posterior"].shape == (0, 64, 21)
