@@ -214,15 +214,15 @@ def other_configs(model, dims, flags):
     except Exception as ex:  # noqa: BLE001
         res["config1_one_patch"] = f"failed: {type(ex).__name__}: {ex}"
     try:
-        B, K, steps = 128, 128, 3
+        B, K, steps, warm = 128, 128, 8, 4  # (the first steps of a process allocate the tape, the gradient buckets and Adam's state)
         inp = syn.patches(B, K, dims, seed=2)
         batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
                  "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),
                  "res_context_emb": inp["res_context_emb"].cuda(), "pair_context_emb": inp["pair_context_emb"].cuda()}
         opt = model.configure_optimizers()
         loss = None
-        for it in range(2 + steps):
-            if it == 2:
+        for it in range(warm + steps):
+            if it == warm:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             opt.zero_grad()
