@@ -1,6 +1,7 @@
 // api.hip - C-ABI entry points for the denoise step, the IPA layer and the reverse sampling loop,
 // plus library plumbing (version, last error, device probe).
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -19,6 +20,48 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- cross-stream ordering guard (common.h StreamOrder) --------------------------------------------------------------------------
+// Why it exists (profiles/r04_two_queue.md): with two library pipelines on two streams of one process, heads_finish_kernel - a small
+// elementwise kernel (sqrt, sincos, IEEE divisions) - computed wrong values in lanes 48-63 of a wave in 1-17 % of the steps, from inputs
+// that it had loaded correctly (in-kernel dump: loaded registers right early and late, a derived product wrong), only while kernels of
+// the bf16x6 GEMM family of the OTHER stream were running beside it, never alone, never beside the f32-MFMA kernels, and not
+// reproducible with stand-alone MFMA / transcendental / copy aggressors (tools/two_queue_*_probe.hip).  Nothing in the library's own
+// state is shared between two calls; the cause sits below this library.  Until it is understood the library does not let its own
+// kernels from two streams overlap: one state per device = {last stream, event}.
+namespace {
+struct OrderState {
+  std::recursive_mutex mu;
+  hipStream_t last = nullptr;
+  bool have = false;
+  hipEvent_t ev = nullptr;
+  int depth = 0;
+};
+OrderState g_order[32];
+bool g_order_on = true;
+}  // namespace
+
+StreamOrder::StreamOrder(void* stream) : dev_(0) {
+  if (hipGetDevice(&dev_) != hipSuccess) dev_ = 0;
+  OrderState& o = g_order[dev_ & 31];
+  o.mu.lock();
+  if (o.depth++ > 0 || !g_order_on) return;  // an entry point called from another entry point: already ordered
+  hipStream_t st = as_stream(stream);
+  if (o.have && o.last != st) {
+    // everything enqueued on the previous stream so far (the library's last call, and whatever the caller put behind it) comes first
+    if (o.ev == nullptr && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) o.ev = nullptr;
+    if (o.ev != nullptr && hipEventRecord(o.ev, o.last) == hipSuccess) (void)hipStreamWaitEvent(st, o.ev, 0);
+    (void)hipGetLastError();  // a stream the caller destroyed meanwhile: nothing left to order against
+  }
+  o.last = st;
+  o.have = true;
+}
+StreamOrder::~StreamOrder() {
+  OrderState& o = g_order[dev_ & 31];
+  --o.depth;
+  o.mu.unlock();
+}
+void set_stream_order(bool on) { g_order_on = on; }
 
 // ---- opt-in launch timer for the dominant kernel (bench.py's roofline leg) ---------------------------------
 // When enabled, the attention-kernel launchers bracket each launch with a hipEvent pair recorded on the launch
@@ -223,6 +266,12 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   return launch_heads_finish(b.vbuf, O_t, logits, d->V, rows, out_O0, out_post, st);
 }
 
+// The taped forwards and their backwards are one unit: where the MFMA path applies the backward reads the probabilities and squared
+// distances the three-launch attention left on the tape, so a taped forward must not be diverted to the generic kernels (which do not
+// write them) - DIFFAB_FLAG_FORCE_GENERIC is ignored by diffab_train_step_fwd / diffab_denoise_step_fwd_taped /
+// diffab_ipa_layer_fwd_taped (unit dims take the generic kernels on both sides anyway); the arithmetic selectors (FP32_GEMM) pass.
+static uint32_t taped_flags(uint32_t flags) { return flags & ~(DIFFAB_FLAG_FORCE_GENERIC | DIFFAB_FLAG_PAIR_PLANES); }
+
 // Training forward: the same launches as denoise_step, but every intermediate lands in its own slot of the tape.
 static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
                               const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps,
@@ -301,6 +350,7 @@ int diffab_device_ok(void) {
 
 int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
                            size_t scratch_bytes, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(X && W && Y && M >= 1 && M < (1LL << 31) && Kd >= 32 && Kd % 32 == 0, DIFFAB_ERR_ARG, "debug_linear128: bad operands");
   hipStream_t st = as_stream(stream);
   if (mode == 0) return launch_linear(X, Kd, W, bias, Y, 128, static_cast<int>(M), 128, Kd, false, st);  // rowgemm128 / tiled f32 MFMA
@@ -317,6 +367,7 @@ size_t diffab_debug_proj_planes_scratch_bytes(const diffab_dims* d) {
 
 int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* R, const float* t,
                              float* qk_out, float* proj_out, void* scratch, size_t scratch_bytes, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "debug_proj_planes")) return rc;
   DIFFAB_REQUIRE(fast_path_supported(d), DIFFAB_ERR_UNSUPPORTED, "debug_proj_planes: benchmark geometry only");
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && x && R && t && qk_out && proj_out && scratch,
@@ -331,6 +382,11 @@ int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weight
   return launch_proj_planes_b6(x, planes, R, t, cent, w->gamma, qk_out, proj_out, d->B * d->K, d->K, st);
 }
 #endif
+
+int diffab_set_stream_guard(int on) {
+  set_stream_order(on != 0);
+  return DIFFAB_OK;
+}
 
 int diffab_debug_set_attn_stamps(void* device_buffer) {
   set_attn_stamps(device_buffer);
@@ -370,6 +426,7 @@ size_t diffab_sample_workspace_bytes(const diffab_dims* d) {
 
 int diffab_ipa_layer_fwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                          const float* t, float* y, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "ipa_layer_fwd")) return rc;
   DIFFAB_REQUIRE(x && e && R && t && y && workspace, DIFFAB_ERR_ARG, "ipa_layer_fwd: null pointer");
   const StepBuffers b = carve_step(d, workspace);
@@ -386,6 +443,7 @@ int diffab_denoise_step_fwd(const diffab_dims* d, const diffab_denoiser_weights*
                             const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0,
                             float* out_posterior, float* out_logits, float* out_res_emb, void* workspace, size_t workspace_bytes,
                             uint32_t flags, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "denoise_step_fwd")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
   DIFFAB_REQUIRE(seq_t && x_t && O_t && res_ctx && pair_ctx && beta && out_eps && out_O0 && out_posterior && workspace, DIFFAB_ERR_ARG,
@@ -410,6 +468,7 @@ int diffab_train_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w
                           const float* res_ctx, const float* pair_ctx, const float* beta, const float* true_post, const float* true_eps,
                           const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, float* out_eps, float* out_O0,
                           float* out_posterior, float* losses3, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "train_step_fwd")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
   DIFFAB_REQUIRE(d->NL <= kMaxLayers, DIFFAB_ERR_UNSUPPORTED, "train_step_fwd: at most %d IPA layers", kMaxLayers);
@@ -420,6 +479,7 @@ int diffab_train_step_fwd(const diffab_dims* d, const diffab_denoiser_weights* w
                  train_tape_floats(d) * sizeof(float));
   const TrainTape tp = carve_tape(d, static_cast<float*>(tape));
   hipStream_t st = as_stream(stream);
+  flags = taped_flags(flags);
   if (int rc = denoise_step_taped(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, tp, flags, st)) return rc;
   return launch_losses_fwd(out_posterior, true_post, out_eps, true_eps, out_O0, true_O0, gen_mask, res_mask, d->B, d->K, d->V, losses3, st,
                            tp.scratch);
@@ -430,6 +490,7 @@ int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w
                           const float* out_O0, const float* out_posterior, const float* true_post, const float* true_eps,
                           const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, const float* upstream3, float* d_res_ctx,
                           float* d_pair_ctx, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "train_step_bwd")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
   if (int rc = check_denoiser_weights(d, grads)) return rc;
@@ -449,6 +510,7 @@ int diffab_train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w
 int diffab_denoise_step_fwd_taped(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
                                   const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps,
                                   float* out_O0, float* out_posterior, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "denoise_step_fwd_taped")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
   DIFFAB_REQUIRE(d->NL <= kMaxLayers, DIFFAB_ERR_UNSUPPORTED, "denoise_step_fwd_taped: at most %d IPA layers", kMaxLayers);
@@ -457,13 +519,14 @@ int diffab_denoise_step_fwd_taped(const diffab_dims* d, const diffab_denoiser_we
   DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(d) * sizeof(float), DIFFAB_ERR_WORKSPACE, "denoise_step_fwd_taped: tape %zu < %zu bytes",
                  tape_bytes, train_tape_floats(d) * sizeof(float));
   const TrainTape tp = carve_tape(d, static_cast<float*>(tape));
-  return denoise_step_taped(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, tp, flags, as_stream(stream));
+  return denoise_step_taped(d, w, seq_t, x_t, O_t, res_ctx, pair_ctx, beta, out_eps, out_O0, out_posterior, tp, taped_flags(flags), as_stream(stream));
 }
 
 int diffab_denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
                             const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_posterior,
                             const float* d_eps, const float* d_O0, const float* d_posterior, float* d_res_ctx, float* d_pair_ctx,
                             const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "denoise_step_bwd")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
   if (int rc = check_denoiser_weights(d, grads)) return rc;
@@ -496,6 +559,7 @@ size_t diffab_ipa_layer_bwd_workspace_bytes(const diffab_dims* d) {
 
 int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                                const float* t, float* y, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "ipa_layer_fwd_taped")) return rc;
   DIFFAB_REQUIRE(x && e && R && t && y && tape, DIFFAB_ERR_ARG, "ipa_layer_fwd_taped: null pointer");
   const diffab_dims d1 = one_layer(d);
@@ -505,7 +569,8 @@ int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weig
   hipStream_t st = as_stream(stream);
   const size_t nb = sizeof(float) * static_cast<size_t>(d->B) * d->K * d->D;
   DIFFAB_HIP_CHECK(hipMemcpyAsync(tp.x[0], x, nb, hipMemcpyDeviceToDevice, st));
-  const bool b6 = tp.planes && use_b6_gemm(flags) && !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(&d1);
+  flags = taped_flags(flags);
+  const bool b6 = tp.planes && use_b6_gemm(flags) && fast_path_supported(&d1);
   if (b6)
     if (int rc = ipa_layer_split_weights(w, tp.planes, st)) return rc;
   if (int rc = ipa_layer_dispatch(&d1, w, tp.x[0], e, R, t, tp.x[1], tp.ipa_ws[0], flags, st, tp.sp[0], tp.d2[0], b6 ? tp.planes : nullptr))
@@ -517,6 +582,7 @@ int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weig
 int diffab_ipa_layer_bwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const diffab_ipa_layer_weights* grads, const float* e,
                          const float* R, const float* t, const float* dy, float* dx, float* d_e, const void* tape, size_t tape_bytes,
                          void* workspace, size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "ipa_layer_bwd")) return rc;
   DIFFAB_REQUIRE(w && grads && e && R && t && dy && dx && tape && workspace, DIFFAB_ERR_ARG, "ipa_layer_bwd: null pointer");
   const diffab_dims d1 = one_layer(d);
@@ -531,6 +597,7 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
                        int64_t* seq, float* x, float* O, const float* res_ctx, const float* pair_ctx, const uint8_t* gen_mask, uint64_t seed,
                        int64_t first_patch, int32_t t_start, int32_t t_stop, void* workspace, size_t workspace_bytes, uint32_t flags,
                        void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_dims(d, "sample_loop")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
   DIFFAB_REQUIRE(s && s->T > 0 && s->alpha && s->beta && s->one_minus_alpha_bar_sqrt, DIFFAB_ERR_ARG, "sample_loop: bad schedule");

@@ -52,6 +52,21 @@ static inline int env_int(const char* name, int dflt) {
 static inline int env_int(const char*, int dflt) { return dflt; }
 #endif
 
+// Cross-stream ordering guard, first statement of every stream-taking entry point (include/diffab_hip.h, "Streams"; the mechanism it
+// works around: profiles/r04_two_queue.md).  Work the library enqueued on a DIFFERENT stream before is ordered in front of this call
+// (hipEventRecord on the previous stream + hipStreamWaitEvent on this one): kernels of two library calls never share the device.  A caller
+// that stays on one stream pays a mutex and a pointer compare; nothing is recorded, nothing waits.
+class StreamOrder {
+ public:
+  explicit StreamOrder(void* stream);
+  ~StreamOrder();
+  StreamOrder(const StreamOrder&) = delete;
+  StreamOrder& operator=(const StreamOrder&) = delete;
+
+ private:
+  int dev_;
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Bump allocator over the caller's workspace (256-B aligned carves).

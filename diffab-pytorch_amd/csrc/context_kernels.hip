@@ -356,6 +356,7 @@ int diffab_residue_embedding_fwd(const diffab_ctx_dims* d, const diffab_residue_
                                  const float* orientations, const float* dihedrals, const int64_t* chain_idx, const float* atom_mask,
                                  const uint8_t* structure_context_mask, const uint8_t* sequence_context_mask, float* out, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_ctx(d, "residue_embedding_fwd")) return rc;
   DIFFAB_REQUIRE(w && w->aa_emb && w->chain_emb && w->w0 && w->b0 && w->w2 && w->b2 && w->w4 && w->b4 && w->w6 && w->b6, DIFFAB_ERR_ARG,
                  "residue_embedding_fwd: null weight");
@@ -458,6 +459,7 @@ int diffab_pair_embedding_fwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
                               const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
                               const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out,
                               void* workspace, size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(distmat != nullptr, DIFFAB_ERR_ARG, "pair_embedding_fwd: distmat is null");
   return pair_embedding_impl(d, w, seq_idx, distmat, nullptr, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
                              sequence_context_mask, out, workspace, workspace_bytes, stream);
@@ -476,6 +478,7 @@ int diffab_residue_embedding_bwd(const diffab_ctx_dims* d, const diffab_residue_
                                  const int64_t* chain_idx, const float* atom_mask, const uint8_t* structure_context_mask,
                                  const uint8_t* sequence_context_mask, const float* d_out, void* workspace, size_t workspace_bytes,
                                  void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_ctx(d, "residue_embedding_bwd")) return rc;
   DIFFAB_REQUIRE(w && w->aa_emb && w->chain_emb && w->w0 && w->b0 && w->w2 && w->b2 && w->w4 && w->b4 && w->w6 && w->b6, DIFFAB_ERR_ARG,
                  "residue_embedding_bwd: null weight");
@@ -541,6 +544,7 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
                               const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
                               const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, void* workspace,
                               size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_ctx(d, "pair_embedding_bwd")) return rc;
   DIFFAB_REQUIRE(w && w->aa_pair_emb && w->relpos_emb && w->pair2distcoef && w->dw0 && w->db0 && w->dw2 && w->db2 && w->mw0 && w->mb0 &&
                      w->mw2 && w->mb2 && w->mw4 && w->mb4,
@@ -628,6 +632,7 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
 int diffab_featurize_xyz(const float* xyz, const int64_t* chain_idx, const uint8_t* residue_mask, int32_t B, int32_t K, int32_t A,
                          float* orientations, float* backbone_dihedrals, uint8_t* backbone_dihedrals_mask, float* pairwise_dihedrals,
                          void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(xyz && B > 0 && K > 0 && A >= 3, DIFFAB_ERR_ARG, "featurize_xyz: bad argument (needs the N, CA, C slots: A >= 3)");
   DIFFAB_REQUIRE(orientations || backbone_dihedrals || pairwise_dihedrals, DIFFAB_ERR_ARG, "featurize_xyz: no output requested");
   hipStream_t st = as_stream(stream);
@@ -650,6 +655,7 @@ int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_em
                                   const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
                                   const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(xyz != nullptr, DIFFAB_ERR_ARG, "pair_embedding_xyz_fwd: xyz is null");
   return pair_embedding_impl(d, w, seq_idx, nullptr, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
                              sequence_context_mask, out, workspace, workspace_bytes, stream);

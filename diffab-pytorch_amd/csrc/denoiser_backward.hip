@@ -1482,7 +1482,8 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
         // dAkv holds g afterwards; d pair_ctx is accumulated there too (MFMA), so the row pass below only writes the transposed copies
         if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, lw->w_bias, d_pair_ctx, st)) return rc;
         keys_done = true;
-        wb_rows = rows / 32;
+        DIFFAB_REQUIRE(rows % 32 == 0, DIFFAB_ERR_UNSUPPORTED, "attention backward (MFMA path): B K = %d must be a multiple of 32", rows);
+        wb_rows = rows / 32;  // one partial row per 32 query rows (launch_pair_stream_bwd)
         // key side straight from the [b][h][i][j] images (g in dAkv, P in Pn): no transposed copies, no VALU row pass at all
         hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<0, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf,
                            dproj, d->K);

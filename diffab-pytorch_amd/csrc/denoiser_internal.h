@@ -107,6 +107,7 @@ int launch_attention_pipe(const diffab_dims* d, const float* proj, const float* 
                           const float* gamma, float* feat, const float* qk_ops, hipStream_t st);
 void set_attn_pipe_stamps(void* device_buffer);
 
+void set_stream_order(bool on);  // api.hip: the cross-stream ordering guard (common.h StreamOrder)
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
 // api.hip: opt-in hipEvent bracket around the dominant (attention) kernel

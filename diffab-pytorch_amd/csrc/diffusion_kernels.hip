@@ -237,7 +237,11 @@ __global__ __launch_bounds__(1024) void igso3_race_kernel(const float* __restric
   const float* prow = pdf + static_cast<int64_t>(sigma_idx[b]) * n_bins;
   const float* erow = race + static_cast<int64_t>(b) * n_bins;
   for (int i = tid; i < n_pad; i += nt) {
-    key[i] = i < n_bins ? prow[i] / erow[i] : -1.0f;  // IEEE division (no fast-math): the host restatement gets the same bits
+    // IEEE division (no fast-math): the host restatement gets the same bits.  NaN-free for any caller-supplied race: a zero-mass bin has
+    // key 0 whatever its draw, and a draw of exactly 0 (u = 1; the library's own uniforms exclude it, philox.h) counts as the smallest
+    // positive float - a NaN key would break the total order the bitonic network relies on.
+    const float p_ = i < n_bins ? prow[i] : 0.0f;
+    key[i] = i < n_bins ? (p_ > 0.0f ? p_ / fmaxf(erow[i], 1.17549435e-38f) : 0.0f) : -1.0f;
     idx[i] = i;
   }
   __syncthreads();
@@ -759,18 +763,23 @@ static int check_sched(const diffab_sched* s) {
 extern "C" {
 
 int diffab_so3_log(const float* R, float* S, int64_t n, void* stream) {
+  StreamOrder order_(stream);
   ELEMENTWISE_ENTRY("so3_log", so3_log_kernel, R && S, n, R, S, n)
 }
 int diffab_so3_exp(const float* S, float* R, int64_t n, void* stream) {
+  StreamOrder order_(stream);
   ELEMENTWISE_ENTRY("so3_exp", so3_exp_kernel, R && S, n, S, R, n)
 }
 int diffab_so3_matrix_to_rotvec(const float* R, float* v, int64_t n, void* stream) {
+  StreamOrder order_(stream);
   ELEMENTWISE_ENTRY("so3_matrix_to_rotvec", so3_matrix_to_rotvec_kernel, R && v, n, R, v, n)
 }
 int diffab_so3_rotvec_to_matrix(const float* v, float* R, int64_t n, void* stream) {
+  StreamOrder order_(stream);
   ELEMENTWISE_ENTRY("so3_rotvec_to_matrix", so3_rotvec_to_matrix_kernel, R && v, n, v, R, n)
 }
 int diffab_so3_scale_rot(const float* R, const float* k, float* out, int64_t n, int64_t per_k, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(per_k > 0, DIFFAB_ERR_ARG, "so3_scale_rot: per_k must be positive");
   ELEMENTWISE_ENTRY("so3_scale_rot", so3_scale_rot_kernel, R && k && out, n, R, k, out, n, per_k)
 }
@@ -787,13 +796,16 @@ static int igso3_table(const float* sigmas, int32_t n_sigmas, int32_t n_bins, in
   return DIFFAB_OK;
 }
 int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream) {
+  StreamOrder order_(stream);
   return igso3_table(sigmas, n_sigmas, n_bins, num_iters, pdf, true, stream);
 }
 int diffab_igso3_table_build_accurate(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream) {
+  StreamOrder order_(stream);
   return igso3_table(sigmas, n_sigmas, n_bins, num_iters, pdf, false, stream);
 }
 
 int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, float* cdf, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(pdf && cdf && n_sigmas > 0 && n_bins > 0, DIFFAB_ERR_ARG, "igso3_cdf_build: bad argument");
   hipLaunchKernelGGL(igso3_cdf_kernel, dim3(n_sigmas), dim3(kThreads), 0, as_stream(stream), pdf, n_bins, cdf);
   DIFFAB_LAUNCH_CHECK();
@@ -802,6 +814,7 @@ int diffab_igso3_cdf_build(const float* pdf, int32_t n_sigmas, int32_t n_bins, f
 
 int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw, const float* u_bin,
                         const float* u_in, const float* z, float* rotvec, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(tab && tab->sigmas && tab->cdf && tab->n_bins > 0 && B >= 0 && K >= 0, DIFFAB_ERR_ARG, "igso3_sample: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
@@ -814,6 +827,7 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
 
 int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, int32_t n_bins, const int64_t* sigma_idx, int32_t B, int32_t K,
                                           const float* race, int32_t* bins, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(n_sigmas > 0 && n_bins > 0 && n_bins <= 16384 && B >= 0 && K >= 0 && K <= n_bins, DIFFAB_ERR_ARG,
                  "igso3_bins_without_replacement: bad argument (n_bins <= 16384, K <= n_bins)");
   if (B == 0 || K == 0) return DIFFAB_OK;  // empty tensors carry null pointers
@@ -829,6 +843,7 @@ int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, in
 
 int diffab_igso3_sample_bins(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
                              const int32_t* bins, const float* u_in, const float* z, float* rotvec, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(tab && tab->sigmas && tab->n_bins > 0 && B >= 0 && K >= 0, DIFFAB_ERR_ARG, "igso3_sample_bins: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
@@ -841,12 +856,14 @@ int diffab_igso3_sample_bins(const diffab_igso3* tab, const int64_t* sigma_idx, 
 
 int diffab_weighted_multinomial(const float* p1, const float* p2, const float* w1, const float* w2, int64_t n, int64_t per_b, float* out,
                                 void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(per_b > 0, DIFFAB_ERR_ARG, "weighted_multinomial: per_b must be positive");
   ELEMENTWISE_ENTRY("weighted_multinomial", weighted_multinomial_kernel, p1 && p2 && w1 && w2 && out, n, p1, p2, w1, w2, n, per_b, out)
 }
 
 int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq, const int64_t* t, const uint8_t* mask, int32_t B,
                             int32_t K, float* prob, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_sched(s)) return rc;
   DIFFAB_REQUIRE(B >= 0 && K >= 0 && (mode == 0 || mode == 1), DIFFAB_ERR_ARG, "seq_forward_prob: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
@@ -860,6 +877,7 @@ int diffab_seq_forward_prob(const diffab_sched* s, int mode, const int64_t* seq,
 
 int diffab_seq_posterior(const diffab_sched* s, const int64_t* seq_t, const int64_t* seq_0, const int64_t* t, const uint8_t* mask,
                          int32_t B, int32_t K, float* post, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_sched(s)) return rc;
   DIFFAB_REQUIRE(B >= 0 && K >= 0, DIFFAB_ERR_ARG, "seq_posterior: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
@@ -872,12 +890,14 @@ int diffab_seq_posterior(const diffab_sched* s, const int64_t* seq_t, const int6
 }
 
 int diffab_categorical_sample(const float* prob, const float* u, int64_t n_rows, int32_t V, int64_t* out, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(V > 0, DIFFAB_ERR_ARG, "categorical_sample: V must be positive");
   ELEMENTWISE_ENTRY("categorical_sample", categorical_sample_kernel, prob && u && out, n_rows, prob, u, n_rows, V, out)
 }
 
 int diffab_coord_forward(const diffab_sched* s, const float* x0, const int64_t* t, const uint8_t* mask, const float* eps, int32_t B,
                          int32_t K, float* xt, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_sched(s)) return rc;
   DIFFAB_REQUIRE(B >= 0 && K >= 0, DIFFAB_ERR_ARG, "coord_forward: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
@@ -891,6 +911,7 @@ int diffab_coord_forward(const diffab_sched* s, const float* x0, const int64_t* 
 
 int diffab_orient_forward(const diffab_sched* s, const float* O0, const uint8_t* mask, const int64_t* t, const float* rotvec, int32_t B,
                           int32_t K, float* Ot, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_sched(s)) return rc;
   DIFFAB_REQUIRE(B >= 0 && K >= 0, DIFFAB_ERR_ARG, "orient_forward: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
@@ -904,6 +925,7 @@ int diffab_orient_forward(const diffab_sched* s, const float* O0, const uint8_t*
 
 int diffab_philox_fill(uint64_t seed, int64_t first_patch, int32_t B, int32_t K, int32_t step, int32_t stream_id, int kind, float* out,
                        void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(B >= 0 && K >= 0 && (kind == 0 || kind == 1), DIFFAB_ERR_ARG, "philox_fill: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;
@@ -917,6 +939,7 @@ int diffab_philox_fill(uint64_t seed, int64_t first_patch, int32_t B, int32_t K,
 int diffab_losses_fwd(const float* pred_post, const float* true_post, const float* pred_eps, const float* true_eps, const float* pred_O0,
                       const float* true_O0, const uint8_t* gen_mask, const uint8_t* res_mask, int32_t B, int32_t K, int32_t V,
                       float* losses3, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(pred_post && true_post && pred_eps && true_eps && pred_O0 && true_O0 && gen_mask && res_mask && losses3 && B > 0 && K > 0 &&
                      V > 0,
                  DIFFAB_ERR_ARG, "losses_fwd: bad argument");
@@ -927,6 +950,7 @@ int diffab_losses_fwd(const float* pred_post, const float* true_post, const floa
 }
 
 int diffab_orientation_loss(const float* pred, const float* target, int64_t n, float* elems, float* sum1, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(pred && target && n > 0 && (elems || sum1), DIFFAB_ERR_ARG, "orientation_loss: bad argument");
   hipLaunchKernelGGL(orientation_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), pred, target, n, elems, sum1);
   DIFFAB_LAUNCH_CHECK();
@@ -935,6 +959,7 @@ int diffab_orientation_loss(const float* pred, const float* target, int64_t n, f
 
 int diffab_orientation_loss_bwd(const float* pred, const float* target, int64_t n, const float* g_elems, const float* g_total,
                                 float* d_pred, float* d_target, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(pred && target && n > 0 && (g_elems || g_total) && (d_pred || d_target), DIFFAB_ERR_ARG, "orientation_loss_bwd: bad argument");
   hipLaunchKernelGGL(orientation_loss_bwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), pred, target, n, g_elems, g_total,
                      d_pred, d_target);
@@ -943,6 +968,7 @@ int diffab_orientation_loss_bwd(const float* pred, const float* target, int64_t 
 }
 
 int diffab_frames_apply(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(B >= 0 && N >= 0 && L >= 0 && P >= 0, DIFFAB_ERR_ARG, "frames_apply: negative extent");
   const int64_t n = static_cast<int64_t>(B) * N * L * P;
   if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
@@ -953,6 +979,7 @@ int diffab_frames_apply(const float* x, const float* R, const float* t, float* o
 }
 
 int diffab_frames_invert(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(B >= 0 && N >= 0 && L >= 0 && P >= 0, DIFFAB_ERR_ARG, "frames_invert: negative extent");
   const int64_t n = static_cast<int64_t>(B) * N * L * P;
   if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
@@ -962,7 +989,33 @@ int diffab_frames_invert(const float* x, const float* R, const float* t, float* 
   return DIFFAB_OK;
 }
 
+// d x = g[0] + sum_k f_k (cos(f_k x) g_sin[k] - sin(f_k x) g_cos[k]); sin / cos are taken from the saved forward output
+__global__ void angular_encoding_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ g, int64_t n, int nf, float* __restrict__ dx) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const int w = 4 * nf + 1;
+  const float* o = enc + i * w;
+  const float* gi = g + i * w;
+  float acc = gi[0];
+  for (int k = 0; k < 2 * nf; ++k) {
+    const float f = k < nf ? static_cast<float>(k + 1) : 1.0f / static_cast<float>(k - nf + 1);
+    acc += f * (o[1 + 2 * nf + k] * gi[1 + k] - o[1 + k] * gi[1 + 2 * nf + k]);
+  }
+  dx[i] = acc;
+}
+
+int diffab_angular_encoding_bwd(const float* enc, const float* g_out, int64_t n, int32_t num_funcs, float* dx, void* stream) {
+  StreamOrder order_(stream);
+  DIFFAB_REQUIRE(n >= 0 && num_funcs > 0, DIFFAB_ERR_ARG, "angular_encoding_bwd: bad argument");
+  if (n == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(enc && g_out && dx, DIFFAB_ERR_ARG, "angular_encoding_bwd: null pointer");
+  hipLaunchKernelGGL(angular_encoding_bwd_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), enc, g_out, n, num_funcs, dx);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float* out, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(n >= 0 && num_funcs > 0, DIFFAB_ERR_ARG, "angular_encoding: bad argument");
   if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
   DIFFAB_REQUIRE(x && out, DIFFAB_ERR_ARG, "angular_encoding: null pointer");
@@ -974,6 +1027,7 @@ int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float*
 int diffab_reverse_update(const diffab_sched* s, int32_t t, int64_t* seq, float* x, float* O, const float* eps_hat, const float* O0_hat,
                           const float* posterior, const uint8_t* gen_mask, const float* z, const float* rotvec, const float* u_seq,
                           int32_t B, int32_t K, int32_t V, void* stream) {
+  StreamOrder order_(stream);
   if (int rc = check_sched(s)) return rc;
   DIFFAB_REQUIRE(seq && x && O && eps_hat && O0_hat && posterior && gen_mask && z && rotvec && u_seq && B >= 0 && K > 0 && V > 0 && t >= 1 &&
                      t <= s->T,
@@ -988,6 +1042,7 @@ int diffab_reverse_update(const diffab_sched* s, int32_t t, int64_t* seq, float*
 
 int diffab_sample_init(int64_t* seq, float* x, float* O, const uint8_t* gen_mask, uint64_t seed, int64_t first_patch, int32_t B, int32_t K,
                        int32_t T, void* stream) {
+  StreamOrder order_(stream);
   DIFFAB_REQUIRE(seq && x && O && gen_mask && B >= 0 && K > 0 && T > 0, DIFFAB_ERR_ARG, "sample_init: bad argument");
   const int64_t n = static_cast<int64_t>(B) * K;
   if (n == 0) return DIFFAB_OK;

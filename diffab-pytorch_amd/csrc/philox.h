@@ -38,8 +38,12 @@ __host__ __device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
   return {c0, c1, c2, c3};
 }
 
-// (0,1) from the top 24 bits: never 0, never 1.
-__host__ __device__ inline float u32_to_unit(uint32_t x) { return static_cast<float>(x >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f; }
+// (0,1) from the top 24 bits: (x >> 8) 2^-24 + 2^-25, never 0.  For x >> 8 == 2^24 - 1 the sum 1 - 2^-25 ties to even = 1.0f in fp32,
+// so the largest value is clamped to 1 - 2^-24: never 1 either (-log(u) > 0: the exponential race of the IGSO3 bin draw divides by it).
+__host__ __device__ inline float u32_to_unit(uint32_t x) {
+  const float u = static_cast<float>(x >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
+  return u < 0.99999994f ? u : 0.99999994f;
+}
 
 struct f32x4 {
   float x, y, z, w;

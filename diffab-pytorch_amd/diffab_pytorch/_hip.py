@@ -89,6 +89,7 @@ SYMBOLS = {
     "diffab_device_ok": (C.c_int, []),
     "diffab_kernel_timer_enable": (C.c_int, [C.c_int]),
     "diffab_debug_set_attn_stamps": (C.c_int, [_fp]),
+    "diffab_set_stream_guard": (C.c_int, [C.c_int]),
     "diffab_debug_linear128": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp]),
     "diffab_kernel_timer_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "diffab_so3_log": (C.c_int, [_fp, _fp, _i64, _fp]),
@@ -138,6 +139,7 @@ SYMBOLS = {
     "diffab_frames_apply": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "diffab_frames_invert": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "diffab_angular_encoding": (C.c_int, [_fp, _i64, _i32, _fp, _fp]),
+    "diffab_angular_encoding_bwd": (C.c_int, [_fp, _fp, _i64, _i32, _fp, _fp]),
     "diffab_denoise_step_fwd_taped": (C.c_int, [_PD, C.POINTER(DenoiserWeights)] + [_fp] * 10 + [_sz, _u32, _fp]),
     "diffab_denoise_step_bwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), C.POINTER(DenoiserWeights)] + [_fp] * 11 + [_sz, _fp, _sz, _fp]),
     "diffab_ipa_layer_tape_bytes": (_sz, [_PD]),

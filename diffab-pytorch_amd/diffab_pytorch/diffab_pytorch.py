@@ -61,9 +61,34 @@ def _no_frame_grads(who: str, *tensors) -> None:
                                   "HIP path (the reference's training step never needs them); detach them or use torch.no_grad()")
 
 
+class _AngularEncodingFn(torch.autograd.Function):
+    """AngularEncoding on HIP; differentiable in x like the reference's plain torch code (diffab_angular_encoding_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, num_funcs: int):
+        lib = _hip.lib()
+        xd = _hip.dev_f32(x)
+        out = torch.empty(*xd.shape[:-1], xd.shape[-1] * (4 * num_funcs + 1), dtype=torch.float32, device=xd.device)
+        _hip.check(lib.diffab_angular_encoding(_hip.ptr(xd), xd.numel(), num_funcs, _hip.ptr(out), _hip.stream_ptr()),
+                   "diffab_angular_encoding")
+        ctx.save_for_backward(out)
+        ctx.num_funcs, ctx.x_shape, ctx.x_device, ctx.x_dtype = num_funcs, tuple(x.shape), x.device, x.dtype
+        return out.to(x.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        lib = _hip.lib()
+        gd = _hip.dev_f32(g)
+        dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=out.device)
+        _hip.check(lib.diffab_angular_encoding_bwd(_hip.ptr(out), _hip.ptr(gd), dx.numel(), ctx.num_funcs, _hip.ptr(dx), _hip.stream_ptr()),
+                   "diffab_angular_encoding_bwd")
+        return dx.to(device=ctx.x_device, dtype=ctx.x_dtype), None
+
+
 class AngularEncoding(nn.Module):
-    """[x, sin(f x), cos(f x)] with f = [1..n, 1/1..1/n] per input value (reference diffab_pytorch.py:20-54); one HIP kernel.
-    Not differentiable here (the reference applies it to input features only)."""
+    """[x, sin(f x), cos(f x)] with f = [1..n, 1/1..1/n] per input value (reference diffab_pytorch.py:20-54); one HIP kernel, and
+    differentiable in x as the reference's torch expression is."""
 
     def __init__(self, num_funcs=3):
         super().__init__()
@@ -74,12 +99,7 @@ class AngularEncoding(nn.Module):
         return d_in * (self.num_funcs * 2 * 2 + 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        lib = _hip.lib()
-        xd = _hip.dev_f32(x)
-        out = torch.empty(*xd.shape[:-1], xd.shape[-1] * (4 * self.num_funcs + 1), dtype=torch.float32, device=xd.device)
-        _hip.check(lib.diffab_angular_encoding(_hip.ptr(xd), xd.numel(), self.num_funcs, _hip.ptr(out), _hip.stream_ptr()),
-                   "diffab_angular_encoding")
-        return out.to(x.device)
+        return _AngularEncodingFn.apply(x, self.num_funcs)
 
 
 class _FramesFn(torch.autograd.Function):

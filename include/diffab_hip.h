@@ -17,7 +17,7 @@
  *     (torch.bool);
  *   - the caller owns every buffer including the workspace (size from the
  *     matching *_workspace_bytes query); kernels are enqueued on `stream` and
- *     never synchronise; no hidden global state; re-entrant across streams; the
+ *     never synchronise on the host; no hidden global state beyond the stream guard below; the
  *     library never reads the environment.  Two DIAGNOSTIC entry points keep
  *     process-global state and are off by default: diffab_kernel_timer_enable/read
  *     (an event list) and diffab_debug_set_attn_stamps (a stamp-buffer pointer);
@@ -26,6 +26,16 @@
  *     before it returns.  (Kernel variants that were measured and not adopted, and
  *     the environment switches used to A/B them, exist only in the EXPERIMENTAL
  *     build of this library - `make EXPERIMENTAL=1`, include/diffab_hip_experimental.h.)
+ *   - Streams: calls on ONE stream are ordered by the stream, as usual.  Calls on DIFFERENT streams are additionally serialised on
+ *     the device by the library itself: before a call enqueues on stream B, everything enqueued so far on the stream of the library's
+ *     previous call (same device) is ordered in front of it (hipEventRecord + hipStreamWaitEvent; no host synchronisation; one mutex
+ *     per device, so concurrent host threads are safe).  Reason, measured on MI355X / ROCm 7.2 (profiles/r04_two_queue.md): while
+ *     kernels of a second library pipeline ran on another hardware queue, a small elementwise kernel computed wrong values in lanes
+ *     48-63 of some waves from correctly loaded inputs; no state of this library is shared between the two calls and stand-alone
+ *     probes do not reproduce it, so the library guards instead of guessing.  A caller that keeps to one stream per device pays a
+ *     pointer compare.  Consequences: a stream handed to the library must stay alive until the library's next call on that device
+ *     has been made; the guard does not cover the caller's OWN kernels on other streams; diffab_set_stream_guard(0) switches it off
+ *     (e.g. while the caller captures library calls into a hipGraph from a stream other than the last one used).
  *   - empty problems (a count or extent of 0) return 0 before any pointer is looked at: an empty tensor's data pointer is NULL;
  *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
  *     diffab_last_error() gives the thread's last message.
@@ -154,6 +164,8 @@ int diffab_kernel_timer_enable(int on);
 /* Diagnostics only: while a device buffer of (work-groups x 8 waves x 8) uint64 is registered, the fused attention kernel
  * writes s_memtime stamps at its phase boundaries into it (tools/attn_phase_profile.py).  NULL (default) disables it. */
 int diffab_debug_set_attn_stamps(void* device_buffer);
+/* The cross-stream ordering guard described under "Streams" above: on (default) / off, process-wide. */
+int diffab_set_stream_guard(int on);
 /* Diagnostics / accuracy tests: Y[M x 128] = X[M x Kd] W[128 x Kd]^T + bias through ONE of the two dense kernels of the MFMA path -
  * mode 0: f32-input MFMA (rowgemm128_kernel), mode 1: bf16 matrix cores, six-term split (rowgemm128_b6_kernel; scratch >=
  * 3 * 128 * Kd * 2 bytes, 16-byte aligned operands).  Kd a multiple of 32.  Lets a test measure both against float64. */
@@ -279,6 +291,9 @@ int diffab_frames_invert(const float* x, const float* R, const float* t, float* 
 /* diffab_pytorch.py:20-54 AngularEncoding.forward: n input values -> n x (4 num_funcs + 1) outputs [x, sin(f x), cos(f x)],
  * f = [1 .. num_funcs, 1/1 .. 1/num_funcs] */
 int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float* out, void* stream);
+/* its backward (the reference module is plain differentiable torch code): enc = the forward's output, g_out its cotangent, both
+ * n x (4 num_funcs + 1); dx[n] = g[0] + sum_k f_k (cos(f_k x) g_sin[k] - sin(f_k x) g_cos[k]) */
+int diffab_angular_encoding_bwd(const float* enc, const float* g_out, int64_t n, int32_t num_funcs, float* dx, void* stream);
 
 /* ---- Denoiser.forward / InvariantPointAttentionLayer.forward under autograd (reference :558-607, :389-465 are differentiable) ----
  * Taped forwards (same outputs as diffab_denoise_step_fwd / diffab_ipa_layer_fwd, activations kept in `tape`) and backwards from

@@ -245,7 +245,11 @@ def igso3_bins_without_replacement(pdf_rows: torch.Tensor, race: torch.Tensor, n
     pdf_rows, race: (n, n_bins) float32; returns (n, num_samples) int64."""
     import numpy as np
 
-    key = (pdf_rows.float().numpy() / race.float().numpy()).astype(np.float32)  # IEEE float32 division, as the HIP kernel
+    # IEEE float32 division, as the HIP kernel; zero-mass bins have key 0 and a draw of exactly 0 counts as the smallest positive float
+    # (csrc/diffusion_kernels.hip igso3_race_kernel: the keys are NaN-free for any race)
+    p32, e32 = pdf_rows.float().numpy(), np.maximum(race.float().numpy(), np.float32(1.17549435e-38))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        key = np.where(p32 > 0, (p32 / e32).astype(np.float32), np.float32(0)).astype(np.float32)
     n, nb = key.shape
     out = np.empty((n, num_samples), dtype=np.int64)
     ar = np.arange(nb)
@@ -473,8 +477,10 @@ def philox4x32(c0, c1, c2, c3, k0, k1):
 
 
 def u32_to_unit(x):
-    """(0,1) float32 from the top 24 bits: (x>>8)*2^-24 + 2^-25."""
-    return ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float32)
+    """(0,1) float32 from the top 24 bits: (x>>8)*2^-24 + 2^-25, the largest value (which rounds to 1.0 in fp32) clamped to
+    1 - 2^-24 (csrc/philox.h)."""
+    u = ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float32)
+    return np.minimum(u, np.float32(0.99999994)).astype(np.float32)
 
 
 def philox_uniform4(seed, patch, residue, step, stream):

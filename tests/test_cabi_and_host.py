@@ -110,3 +110,4 @@ def test_synthetic_patches_are_shard_invariant():
     eye = torch.eye(3).expand_as(R)
     assert torch.allclose(R.transpose(-1, -2) @ R, eye, atol=1e-5)
     assert (full["generation_mask"].sum(-1) >= 5).all() and (full["generation_mask"].sum(-1) <= 20).all()
+

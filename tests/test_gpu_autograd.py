@@ -67,6 +67,17 @@ def test_frames_and_angular_encoding_vs_reference_goldens(hip, golden):
     out = enc(T(g["xa"]).cuda())
     assert maxrel(out, g["enc"]) < 1e-6 and torch.equal(out[..., 0::13].cpu(), T(g["xa"]))  # the x column is copied, not recomputed
     assert torch.equal(enc.freq_bands, torch.tensor([1.0, 2.0, 3.0, 1.0, 0.5, 1.0 / 3.0]))
+    # differentiable in x like the reference's torch expression (diffab_pytorch.py:41-52): HIP backward against torch autograd of the
+    # same three terms on the CPU
+    xa = T(g["xa"])
+    cot = torch.randn(*xa.shape[:-1], xa.shape[-1] * 13, generator=torch.Generator().manual_seed(3))
+    xg = xa.clone().cuda().requires_grad_(True)
+    (enc(xg) * cot.cuda()).sum().backward()
+    xr = xa.clone().requires_grad_(True)
+    xe = xr.unsqueeze(-1)
+    ref = torch.cat([xe, torch.sin(enc.freq_bands * xe), torch.cos(enc.freq_bands * xe)], dim=-1).flatten(-2)
+    (ref * cot).sum().backward()
+    assert maxrel(xg.grad, xr.grad) < 1e-6
 
 
 def test_orientation_loss_autograd_vs_reference_goldens(hip, golden):
