@@ -311,8 +311,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of host time for the CPU baseline cases")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
-    ap.add_argument("--split-attention", action="store_true", help="attention as three launches (csrc/attention_split.hip) instead of fused")
-    ap.add_argument("--external-logits", action="store_true", help="logits in their own launch, fused kernel for the rest")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short BASELINE config 4 / 5 measurements (N=1 only)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead of the sampling headline: training steps (noise + taped forward + 3 losses + HIP "
@@ -367,8 +365,7 @@ def main():
     sd_dev = model._sched_on_device()
     tab = model._reverse_so3().struct()
     ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
-    flags = _hip.FLAG_FORCE_GENERIC if args.generic else (_hip.FLAG_SPLIT_ATTENTION if args.split_attention else
-                                                          (_hip.FLAG_EXTERNAL_LOGITS if args.external_logits else 0))
+    flags = _hip.FLAG_FORCE_GENERIC if args.generic else 0
     seed = 2024
     _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, model.T,
                                       _hip.stream_ptr()), "sample_init")
@@ -435,14 +432,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (bf16x6 / fp16x3 split-precision products on the 16-bit matrix cores, fp32 accumulate; fp32-accurate, DESIGN section 4)",
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B}/GPU synthetic K={K} patches, reverse sampling steps (T=100 schedule), benchmark model "
                             "D=128 C=64 NL=6 H=8 ds=32 P=8 (reference train.py:62-70), random-init weights",
                 "patches_per_gpu": B, "K": K, "global_batch": world * B,
                 "parallelism": f"patch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU over gloo, not a scaling measurement)" if args.rehearse_on_one_gpu else ""),
-                "path": "generic" if args.generic else ("mfma-split-attention" if args.split_attention else ("mfma-external-logits" if args.external_logits else "mfma")),
+                "path": "generic" if args.generic else "mfma",
             },
             "residue_steps_per_s_per_gpu": value / world,
             # SURVEY 8(d) secondary figures: only the residues being generated (masks do not prune compute: every residue of a patch
@@ -453,18 +450,16 @@ def main():
             "whole_path_hbm_frac": value / world * algorithmic_bytes_per_residue_step(K, dims["D"], dims["C"], dims["NL"]) / 1e9
                                    / HBM_PEAK_GBPS,
             "roofline": {
-                "kernel": ("ipa_pair_stream_kernel (pair-embedding stream: bias + softmax + attn-weighted pair sums; logits and P x V "
-                           "are separate launches)") if args.split_attention else
-                          "ipa_attention (pair-embedding stream: bias + softmax + attn-weighted pair/scalar/point sums)",
+                "kernel": "ipa_attention (pair-embedding stream: bias + softmax + attn-weighted pair/scalar/point sums)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None if args.split_attention else traffic,  # the PMC file under profiles/ is for the fused kernel
+                "traffic": traffic,  # the PMC file under profiles/ is for the fused kernel
                 # not measured in this run: rocprofv3 --pmc passes of this same command (FETCH_SIZE x 2 + WRITE_SIZE per launch,
                 # tools/profile_round.sh), committed as profiles/roofline_traffic.json
-                "traffic_source": None if (args.split_attention or traffic is None) else "profiles/roofline_traffic.json (committed rocprofv3 --pmc passes, not this run)",
+                "traffic_source": None if traffic is None else "profiles/roofline_traffic.json (committed rocprofv3 --pmc passes, not this run)",
                 "launches": launches.value,
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg,

@@ -6,9 +6,6 @@
 
 #include "common.h"
 #include "denoiser_internal.h"
-#ifdef DIFFAB_EXPERIMENTAL
-#include "../../include/diffab_hip_experimental.h"
-#endif
 
 namespace diffab {
 
@@ -138,8 +135,7 @@ static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weigh
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
-    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, (flags & DIFFAB_FLAG_SPLIT_ATTENTION) ? 1 : ((flags & DIFFAB_FLAG_EXTERNAL_LOGITS) ? 2 : ((flags & DIFFAB_FLAG_FLASH_ATTENTION) ? 3 : 0)),
-                          sp_keep, d2_keep, planes, pair_planes, nullptr, (flags & DIFFAB_FLAG_FP32_GEMM) != 0);
+    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, sp_keep, d2_keep, planes, pair_planes, (flags & DIFFAB_FLAG_FP32_GEMM) != 0);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -153,8 +149,7 @@ static int mlp3(const diffab_dims* d, const diffab_mlp3_weights* w, const float*
 }
 
 static bool use_pair_planes(const diffab_dims* d, uint32_t flags, const float* pair_ctx, const StepBuffers& b) {
-  const uint32_t other = DIFFAB_FLAG_FORCE_GENERIC | DIFFAB_FLAG_SPLIT_ATTENTION | DIFFAB_FLAG_EXTERNAL_LOGITS | DIFFAB_FLAG_FLASH_ATTENTION |
-                         DIFFAB_FLAG_PAIR_F32;
+  const uint32_t other = DIFFAB_FLAG_FORCE_GENERIC | DIFFAB_FLAG_PAIR_F32;
   return (flags & DIFFAB_FLAG_PAIR_PLANES) && !(flags & other) && b.pair != nullptr && pair_planes_supported(d) &&
          (reinterpret_cast<uintptr_t>(pair_ctx) & 15) == 0;
 }
@@ -216,9 +211,8 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     if (b6) return launch_rowgemm128_b6p(X, D, mlp + slot * mlp_planes_bytes(), bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
     return launch_rowgemm128(X, D, W, ldw, bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
   };
-  // DIFFAB_MLP_UNFUSED=1: one launch per dense layer (A/B timing); default: each MLP as one row-resident kernel (mlp_chain_b6_kernel)
-  static const bool chain_env = env_int("DIFFAB_MLP_UNFUSED", 0) == 0;
-  const bool chain = b6 && chain_env && d->V <= 128;
+  // each MLP as one row-resident kernel (mlp_chain_b6_kernel); one launch per dense layer only where the chain does not apply
+  const bool chain = b6 && d->V <= 128;
   if (fold && chain) {
     const void* pl[2] = {mlp, mlp + mlp_planes_bytes()};
     const float* bs[2] = {b.emb_tab, w->res_b2};
@@ -359,29 +353,6 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
   return launch_rowgemm128_b6(X, Kd, W, Kd, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, scratch, st);
 }
 
-#ifdef DIFFAB_EXPERIMENTAL  // include/diffab_hip_experimental.h
-size_t diffab_debug_proj_planes_scratch_bytes(const diffab_dims* d) {
-  if (check_dims(d, "debug_proj_planes_scratch_bytes")) return 0;
-  return align_up(proj_planes_scratch_bytes(), 256) + align_up(static_cast<size_t>(d->B) * 16, 256);
-}
-
-int diffab_debug_proj_planes(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* R, const float* t,
-                             float* qk_out, float* proj_out, void* scratch, size_t scratch_bytes, void* stream) {
-  StreamOrder order_(stream);
-  if (int rc = check_dims(d, "debug_proj_planes")) return rc;
-  DIFFAB_REQUIRE(fast_path_supported(d), DIFFAB_ERR_UNSUPPORTED, "debug_proj_planes: benchmark geometry only");
-  DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && x && R && t && qk_out && proj_out && scratch,
-                 DIFFAB_ERR_ARG, "debug_proj_planes: null pointer");
-  DIFFAB_REQUIRE(scratch_bytes >= diffab_debug_proj_planes_scratch_bytes(d), DIFFAB_ERR_WORKSPACE, "debug_proj_planes: scratch too small");
-  hipStream_t st = as_stream(stream);
-  char* planes = static_cast<char*>(scratch);
-  float* cent = reinterpret_cast<float*>(planes + align_up(proj_planes_scratch_bytes(), 256));
-  const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
-  if (int rc = launch_ppsplit(W6, planes, st)) return rc;
-  if (int rc = launch_patch_centroids(t, d->B, d->K, cent, st)) return rc;
-  return launch_proj_planes_b6(x, planes, R, t, cent, w->gamma, qk_out, proj_out, d->B * d->K, d->K, st);
-}
-#endif
 
 int diffab_set_stream_guard(int on) {
   set_stream_order(on != 0);

@@ -14,7 +14,7 @@
 //                              the next row's tiles are requested while the current row's are retired
 //   C  ipa_pv_kernel           work-group = (patch, head, 128 or 64 query rows): v_s / v_pts staged once in LDS, o_s and o_pts on
 //                              the MFMA with P as the A operand, global->local frames and norms -> feature row.
-// Users: the opt-in DIFFAB_FLAG_SPLIT_ATTENTION forward; the training tape (the forward of a training step runs A, B, C and keeps P
+// Users: the training tape (the forward of a training step runs A, B, C and keeps P
 // and the squared point distances for the backward); the attention backward (B' = ipa_pair_stream_bwd_kernel below, and the
 // probability recompute when a tape has no slot for them).
 #include <type_traits>
@@ -57,11 +57,7 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int64_t prow0 = static_cast<int64_t>(b) * K;
   // stage the key side of head h: full 128-byte lines (8 lanes per k_s row, 6 per k_pts row)
-#ifdef SPA_ABL_NOSTAGE
-  for (int idx = tid; idx < 8; idx += 256) {
-#else
   for (int idx = tid; idx < K * 8; idx += 256) {
-#endif
     const int j = idx >> 3, c4 = idx & 7;
     *reinterpret_cast<f32x4*>(ks_l + j * KLD + 4 * c4) = *reinterpret_cast<const f32x4*>(proj + (prow0 + j) * ANP + OFF_KS + h * ADS + 4 * c4);
   }
@@ -115,13 +111,8 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       f32x2 d2v = {0.f, 0.f};  // packed fp32: two coordinates per instruction, two partial sums added at the end
-#ifdef SPA_ABL_NOVALU
-      d2v[0] = gk[r][0] + gq[r][0][0];
-      for (int cc = 0; cc < 0; ++cc) {
-#else
 #pragma unroll
       for (int cc = 0; cc < 6; ++cc) {
-#endif
         f32x2 dlo, dhi;  // packed subtract spelled in assembly: the compiler splits a vector fsub into two v_sub_f32
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
             : "=v"(dlo)
@@ -141,9 +132,6 @@ __global__ __launch_bounds__(256) void ipa_logits_kernel(const float* __restrict
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(otile + (orow + 8 * half) * OLD + oc);
-#ifdef SPA_ABL_NOSTORE
-        if (K < 0)
-#endif
         *reinterpret_cast<f32x4*>(sbase + static_cast<int64_t>(orow + 8 * half) * K + (jt - 1) * 16 + oc) = v;
         if (WD2)
           *reinterpret_cast<f32x4*>(dbase + static_cast<int64_t>(orow + 8 * half) * K + (jt - 1) * 16 + oc) =
@@ -289,11 +277,7 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __res
     float* sp = sp_of(row);
     f32x4 lgv[NT];  // logits, then exp(logit - M), of keys 16 jt + 4 q + r for head h
 #pragma unroll
-#ifdef SPB_ABL_NOSLOAD
-    for (int jt = 0; jt < NT; ++jt) lgv[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
     for (int jt = 0; jt < NT; ++jt) lgv[jt] = *reinterpret_cast<const f32x4*>(sp + jt * 16);
-#endif
     MEM_FENCE();
     float mx = -INFINITY;
     stage_e(slot, 0);
@@ -334,12 +318,10 @@ __global__ __launch_bounds__(512) void ipa_pair_stream_kernel(const float* __res
     const float inv = 1.0f / sum;
     // normalised probabilities back in place of the logits, BEFORE any load of the next row is issued: a later wait for those
     // loads then finds these stores long acknowledged (a wait for loads with younger stores in flight waits for the stores too)
-#ifndef SPB_ABL_NOPSTORE
     if (l15 < 8) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) *reinterpret_cast<f32x4*>(sp + jt * 16) = lgv[jt] * inv;
     }
-#endif
     if constexpr (!OE) {
       if (has_next) {
 #pragma unroll

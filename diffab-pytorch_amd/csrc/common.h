@@ -40,17 +40,8 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Kernel-variant switches for A/B timing are read from the environment in EXPERIMENTAL builds only (`make EXPERIMENTAL=1` ->
-// build_exp/libdiffab_hip.so, selected by tools/ through DIFFAB_HIP_LIB); the product library never calls getenv and has no
-// process-global configuration.
-#ifdef DIFFAB_EXPERIMENTAL
-static inline int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e != nullptr ? atoi(e) : dflt;
-}
-#else
-static inline int env_int(const char*, int dflt) { return dflt; }
-#endif
+// (The library never calls getenv; the kernel variants that were measured and not adopted, and the environment switches used to A/B
+// them, live under experiments/ as patches on top of these sources.)
 
 // Cross-stream ordering guard, first statement of every stream-taking entry point (include/diffab_hip.h, "Streams"; the mechanism it
 // works around: profiles/r04_two_queue.md).  Work the library enqueued on a DIFFERENT stream before is ordered in front of this call

@@ -214,9 +214,6 @@ __global__ __launch_bounds__(512, RG_MT == 1 ? 2 : 1) void rowgemm128_kernel(con
   }
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   auto load_w = [&](int ch) {
-#ifdef RG_ABL_NOW
-    if (ch > 0) return;
-#endif
     ch = ch < nchunk ? ch : nchunk - 1;  // unconditional prefetch: the last trips re-read the final chunk
 #pragma unroll
     for (int r = 0; r < 4; ++r) wreg[r] = *reinterpret_cast<const f32x4u*>(wsrc[r] + ch * RG_KC);
@@ -240,9 +237,6 @@ __global__ __launch_bounds__(512, RG_MT == 1 ? 2 : 1) void rowgemm128_kernel(con
   const int nset = nchunk / AW;
   f32x4 aA[MT][4 * AW], aB[MT][4 * AW];
   auto load_a = [&](f32x4 (&a)[MT][4 * AW], int set) {
-#ifdef RG_ABL_NOA
-    if (set > 0) return;
-#endif
     set = set < nset ? set : nset - 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -349,10 +343,8 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
   segs.n_end[0] = N;
   segs.nseg = 1;
   const bool vec = (ldx % 4 == 0) && (Kd % 4 == 0) && aligned16(X) && aligned16(W);
-#ifndef DIFFAB_NO_ROWGEMM
   if (N == 128 && vec && rowgemm128_ok(X, ldx, Y, ldy, M, Kd) && (!bias || aligned16(bias)))
     return launch_rowgemm128(X, ldx, W, Kd, bias, nullptr, 0, Y, ldy, M, Kd, relu, st);
-#endif
   if (N > 64) return launch_linear_bn<128>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
   return launch_linear_bn<64>(X, ldx, segs, bias, Y, ldy, M, N, Kd, relu, vec, st);
 }
@@ -379,8 +371,6 @@ constexpr int TI = 16;  // query residues per work-group
 // NT: key tiles (16 keys each) per chunk: 8 when K % 128 == 0, else 4; compile-time so per-lane arrays stay in VGPRs.
 // MULTI: more than one chunk.  The single-chunk instantiation (K = 64, 128) has NC == 1 at compile time: the chunk loop and every
 // rescale branch fold away and it is the same straight-line kernel as before the chunk loop existed (the loop costs 13 % at K=128).
-// EXT_S (single chunk only): phase 1 is not computed here; the logits image is copied from Sg[b][h][i][j], written by
-// ipa_logits_kernel (attention_split.hip), whose work-groups share the staged key side over 64 query rows instead of 16.
 // PLANES: `e` is not the fp32 pair embedding but its two-plane fp16 image written by pair_split_kernel (same
 // bytes: e s = h1 + h2 to 2^-23 of the tensor maximum, fragment order of the bias product), `esc` = {s, 1 / s}; the two products on
 // the pair tile then run on the f16 matrix cores as three exact partial products each (h1 w1, h1 w2, h2 w1 with fp32 accumulation)
@@ -388,38 +378,13 @@ constexpr int TI = 16;  // query residues per work-group
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
-// B6L (with PLANES): phase 1 does not read the fp32 projection buffer; the scalar AND point-distance logits of a (head, key tile) are
-// ONE 64-slot dot product of operand planes written by proj_planes_b6_kernel (proj_planes.hip: three bf16 planes per slot in the
-// fragment order of v_mfma_f32_16x16x32_bf16, six partial products, fp32 accumulation) plus 8 coef |t_i - t_j|^2 from a 16 x KC
-// table of direct differences that the work-group builds once per chunk: 12 MFMAs of 16 cycles and ~10 VALU instructions per key
-// tile against 8 f32 MFMAs of 32 cycles and 96 packed VALU instructions, no LDS staging, linear 1 KiB operand loads.
-// qkp = query-side operands (f32x4 units), key side kside_off further.
-// QUEUE (EXPERIMENTAL build, PLANES single-chunk form only; profiles/r03_lockstep.md): a persistent grid of one work-group per CU pulls work
-// items from one queue per XCD (the XCD is read from the hardware id, so producer and consumer of a patch share an L2): first the
-// (patch, row tile) attention items of the XCD's patches, then one to_out item per patch (128 rows x 128 columns, rowgemm_b6_tile.h),
-// which waits until the patch's row tiles have all signalled completion.  The first item of a work-group is delayed by its class x
-// qa.stagger_ticks (100 MHz): the CUs' pair-stream phases stop coinciding, and the ragged end of the attention items is filled by
-// to_out items instead of idling.  Same arithmetic per item as the two separate launches.
-struct AttnQueue {
-  int* ctr;               // [8] item counters, then [B] completed row tiles per patch; zeroed in front of the launch
-  const void* wo_planes;  // to_out weights as split planes (launch_wsplit128)
-  const float* wo_bias;
-  float* y;               // (B K, 128) layer output
-  int stagger_ticks;
-};
-template <int NT, bool MULTI, bool EXT_S = false, bool PLANES = false, bool B6L = false, bool QUEUE = false>
+template <int NT, bool MULTI, bool PLANES = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
-                                                            unsigned long long* __restrict__ stamps,
-                                                            const float* __restrict__ Sg = nullptr, const float* __restrict__ esc = nullptr,
-                                                            const f32x4* __restrict__ qkp = nullptr, int64_t kside_off = 0,
-                                                            AttnQueue qa = AttnQueue{}) {
-  static_assert(!QUEUE || (PLANES && !MULTI && !EXT_S && !B6L), "work-queue form: single-chunk planes kernel only");
-  static_assert(!(EXT_S && MULTI), "external logits: single key chunk only");
+                                                            unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr) {
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
-  static_assert(!B6L || (PLANES && !EXT_S), "operand-plane logits: PLANES form only");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
   // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
@@ -430,82 +395,25 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   constexpr int NS = NT * 4;  // (jt, r) key steps of 4 keys each
   const int K = NC * KC;
   const int ntile = K / TI;
-  // diagnostic s_memtime stamps (stamps == nullptr in every production launch: nothing below executes)
-  unsigned stamp_slot = blockIdx.x;  // QUEUE: the item's (patch, row tile) index in the default launch order
+  // diagnostic stamps (stamps == nullptr in every production launch: nothing below executes; diffab_debug_set_attn_stamps,
+  // tools/attn_phase_profile.py).  -DAT_STAMP_REALTIME: the chip-wide 100 MHz counter instead of the per-CU cycle counter.
   auto stamp = [&](int k) {
     if (stamps != nullptr) {
       __builtin_amdgcn_sched_barrier(0);
-#ifdef AT_STAMP_REALTIME  // the 100 MHz counter is the same on every CU (s_memtime is not comparable between CUs)
+#ifdef AT_STAMP_REALTIME
       const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
 #else
       const unsigned long long tnow = __builtin_amdgcn_s_memtime();
 #endif
-      if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(stamp_slot) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
+      if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if constexpr (!QUEUE) stamp(0);
-  __shared__ int q_item;
-  unsigned q_xcd = 0;
-  bool q_first = true;
-  if constexpr (QUEUE) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(q_xcd));
-  q_xcd &= 7;
-  int q_next = 0;  // thread 0: the ticket of the NEXT item, requested while the current one runs (the atomic's round trip is hidden)
-  if constexpr (QUEUE)
-    if (threadIdx.x == 0) q_next = atomicAdd(qa.ctr + q_xcd, 1);
-  for (;;) {  // QUEUE: one iteration per work item; otherwise executed once
+  stamp(0);
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
   const unsigned bid = blockIdx.x;
-  if constexpr (QUEUE) {
-    __syncthreads();  // every wave is done with the previous item's LDS
-    if (threadIdx.x == 0) q_item = q_next;
-    __syncthreads();
-    const int item = q_item, per_xcd = B >> 3, n_att = per_xcd * ntile;
-    if (item >= n_att + per_xcd) break;
-    if (threadIdx.x == 0) q_next = atomicAdd(qa.ctr + q_xcd, 1);
-    if (q_first && qa.stagger_ticks > 0) {
-      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + static_cast<unsigned long long>((blockIdx.x >> 3) & 7) * qa.stagger_ticks;
-      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
-    }
-    q_first = false;
-    // Queue order: the row tiles of the first QD patches, then per further patch p one to_out item (patch p - QD, whose row tiles
-    // were handed out a generation of work-groups earlier) in front of p's ntile row tiles, then the last QD to_out items.  The
-    // to_out items are spread over the launch (they run on the matrix cores beside other CUs' pair streams) and knock the CUs out
-    // of step with each other.
-#ifndef DIFFAB_QUEUE_DEPTH
-#define DIFFAB_QUEUE_DEPTH 32  // >= patches per XCD at B = 256: every to_out item behind the attention items (interleaved was slower)
-#endif
-    constexpr int QD = DIFFAB_QUEUE_DEPTH;
-    int att_p = -1, att_t = 0, out_p = -1;
-    const int head = QD * ntile, body = (ntile + 1) * (per_xcd - QD);
-    if (per_xcd <= QD) {
-      if (item < n_att) { att_p = item / ntile; att_t = item % ntile; } else out_p = item - n_att;
-    } else if (item < head) {
-      att_p = item / ntile; att_t = item % ntile;
-    } else if (item < head + body) {
-      const int r_ = item - head, g_ = r_ / (ntile + 1), o_ = r_ % (ntile + 1);
-      if (o_ == 0) out_p = g_; else { att_p = QD + g_; att_t = o_ - 1; }
-    } else {
-      out_p = per_xcd - QD + (item - head - body);
-    }
-    if (out_p >= 0) {  // to_out of patch pb: its ntile row tiles were handed out earlier from this same queue
-      const int pb = out_p * 8 + static_cast<int>(q_xcd);
-      if (threadIdx.x == 0)
-        while (__hip_atomic_load(qa.ctr + 8 + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile) __builtin_amdgcn_s_sleep(8);
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of feat may be served from this CU's L1
-      int tid_o = threadIdx.x;  // opaque copy: nothing of the tile function is hoisted out of the item loop
-      asm volatile("" : "+v"(tid_o));
-      b6tile::rowgemm128_tile<false, 128>(reinterpret_cast<__bf16*>(S), tid_o, pb * (K / 128), feat, AF, static_cast<const __bf16*>(qa.wo_planes),
-                                          qa.wo_bias, nullptr, 0, qa.y, 128, B * K, AF);
-      continue;
-    }
-    b = att_p * 8 + static_cast<int>(q_xcd);
-    tile = att_t;
-    stamp_slot = static_cast<unsigned>(att_p * ntile + att_t) * 8 + q_xcd;
-    stamp(0);
-  } else if ((B & 7) == 0) {
+  if ((B & 7) == 0) {
     const int xcd = bid & 7, slot = bid >> 3;
     b = (slot / ntile) * 8 + xcd;
     tile = slot % ntile;
@@ -513,19 +421,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     b = bid / ntile;
     tile = bid % ntile;
   }
-#ifdef AT_STAGGER_TICKS  // timing experiment (profiles/r03_lockstep.md): the first generation of work-groups starts staggered, AT_STAGGER_CLASSES
-                         // classes AT_STAGGER_TICKS (100 MHz) apart - the CUs' pair-stream phases stop coinciding
-  if (blockIdx.x < 256) {
-    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + static_cast<unsigned long long>((blockIdx.x >> 3) & (AT_STAGGER_CLASSES - 1)) * AT_STAGGER_TICKS;
-    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
   const int i0 = tile * TI;
-  int tid_v = threadIdx.x;
-  if constexpr (QUEUE) asm volatile("" : "+v"(tid_v));  // (item loop: recompute the lane coordinates per item instead of keeping them all live)
-  const int tid = tid_v, lane0 = tid & 63, wv = EXT_S ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane0 = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // (the wave index as a scalar: the addresses built from it stay in SGPRs, which takes the chunked instantiations from 13 spilled VGPRs
-  // + 56 B of scratch to none; the external-logits form is the one instantiation that gets worse with it)
+  // + 56 B of scratch to none)
   constexpr int HS = KC + 8, IS = AH * (KC + 8) + 8;  // == 8 (mod 64): both ds_read_b128 patterns on the image are conflict-free
   const int64_t prow0 = static_cast<int64_t>(b) * K;  // first projection row of this patch
   const float scale_t = 0.57735026918962576f;         // 3^-1/2   (diffab_pytorch.py:387, :439)
@@ -595,9 +494,6 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     f32x4 wv4[2][2];  // PLANES: the bias weights of lane (head, channel group), requested in phase 1's tail AHEAD of the first pair tiles:
                       // vmcnt retires in order, so loaded behind them they would cost every wave a pair-tile latency in front of the barrier
     auto load_e_tile = [&](int ii, int cc_, int jt) {
-#ifdef AT_ABL_NOE  // timing ablation (wrong results): only the first pair tile is ever loaded
-      if (ii > 0 || jt > 0) return;
-#endif
       if constexpr (PLANES) {  // four 1 KiB blocks per key tile, lane order: ev[ii][jt][2 p + ks] = fragment (plane p, k-step ks)
         const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii]) + (cc_ * NT + jt) * 256 + lane;
 #pragma unroll
@@ -609,102 +505,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       }
     };
     // ---------------------------------------------------------------- phase 1: wave = head
-    if constexpr (EXT_S) {
-      // logits of the 16 rows x 8 heads x KC keys from global memory: 512 contiguous bytes per (row, head); the pair stream of
-      // phase 2's first row is requested right behind them
-      constexpr int F4 = KC / 4;  // float4 per (row, head)
-      f32x4 sreg[TI * AH * F4 / 512];
-#pragma unroll
-      for (int k_ = 0; k_ < TI * AH * F4 / 512; ++k_) {
-        const int idx = tid + 512 * k_, rh = idx / F4, c4 = idx % F4, il = rh / AH, hh = rh % AH;
-        sreg[k_] = *reinterpret_cast<const f32x4*>(Sg + ((static_cast<int64_t>(b) * AH + hh) * K + i0 + il) * K + 4 * c4);
-      }
-#pragma unroll
-      for (int jt = 0; jt < E_EARLY; ++jt) load_e_tile(0, c, jt);
-      MEM_FENCE();
-#pragma unroll
-      for (int k_ = 0; k_ < TI * AH * F4 / 512; ++k_) {
-        const int idx = tid + 512 * k_, rh = idx / F4, c4 = idx % F4, il = rh / AH, hh = rh % AH;
-        *reinterpret_cast<f32x4*>(S + il * IS + hh * HS + 4 * c4) = sreg[k_];
-      }
-    } else if constexpr (B6L) {
-      const int h = wv;
-      const float coef8 = -0.5f * 0.16666666666666666f * gamma[h] * 8.0f;  // 8 coef: the |t_i - t_j|^2 term of all eight points
-      // ---- |t_i - t_j|^2 of the 16 rows x KC keys, direct differences: wave w < NT takes key tile w; D2[key][row], stride 20
-      constexpr int D2LD = 20;
-      float* d2t = S + TI * IS;  // in the per-wave scratch area, which phase 1 does not otherwise use in this form
-      f32x4 dd = {0.f, 0.f, 0.f, 0.f};
-      if (wv < NT) {
-        const float* tj = t + (krow0 + 16 * wv + l15) * 3;
-        const float tjx = tj[0], tjy = tj[1], tjz = tj[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* ti = t + (prow0 + i0 + 4 * q + r) * 3;
-          const float dx = ti[0] - tjx, dy = ti[1] - tjy, dz = ti[2] - tjz;
-          dd[r] = (dx * dx + dy * dy) + dz * dz;
-        }
-      }
-      // ---- operand planes: A = query side (rows i0 .. i0 + 15), B = key side (16 keys per tile); [k-step][plane], 1 KiB each
-      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-      const f32x4* qsrc = qkp + ((static_cast<int64_t>(b) * AH + h) * ntile + tile) * (6 * 64) + lane;
-      const f32x4* ksrc = qkp + kside_off + ((static_cast<int64_t>(b) * AH + h) * ntile + c * NT) * (6 * 64) + lane;
-      constexpr int SD = 3;  // key tiles in flight
-      static_assert(E_EARLY <= SD, "the early pair tiles are requested in the last E_EARLY iterations, which must not request key tiles any more");
-      f32x4 qa[6], kb[SD][6];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) qa[u] = qsrc[u * 64];
-#pragma unroll
-      for (int jt = 0; jt < SD && jt < NT; ++jt)
-#pragma unroll
-        for (int u = 0; u < 6; ++u) kb[jt][u] = ksrc[(jt * 6 + u) * 64];
-      MEM_FENCE();
-      if (wv < NT) *reinterpret_cast<f32x4*>(d2t + (16 * wv + l15) * D2LD + 4 * q) = dd;
-#ifdef AT_DIAG_P1  // diagnostic stamps: 6 = every initial load of this wave has landed, 7 = the distance-table barrier is behind it
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (c == 0) stamp(6);
-#endif
-      __syncthreads();  // the distance table is complete
-#ifdef AT_DIAG_P1
-      if (c == 0) stamp(7);
-#endif
-      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int term = 0; term < 6; ++term)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[3 * ks + TA[term]]),
-                                                          __builtin_bit_cast(bf16x8_t, kb[jt % SD][3 * ks + TB[term]]), acc, 0, 0, 0);
-#ifdef AT_ABL_NOK  // timing ablation (wrong results): the key tiles after the first three are not loaded
-        if (false) {
-#else
-        if (jt + SD < NT) {
-#endif
-#pragma unroll
-          for (int u = 0; u < 6; ++u) kb[jt % SD][u] = ksrc[((jt + SD) * 6 + u) * 64];
-        } else if (jt + E_EARLY >= NT) {
-          if (jt + E_EARLY == NT) {
-            const int hh = lane & 7, qq = lane >> 4;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int hf = 0; hf < 2; ++hf) wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + hh * AC + 32 * ks + 8 * qq + 4 * hf);
-          }
-          load_e_tile(0, c, jt + E_EARLY - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
-        }
-        MEM_FENCE();
-        const f32x4 d2v = *reinterpret_cast<const f32x4*>(d2t + (16 * jt + l15) * D2LD + 4 * q);
-        // acc[r] = ds^-1/2 q_s.k_s + coef (sum_p |gq_p - gk_p|^2 - 8 |t_i - t_j|^2) [- row terms], row i0 + 4 q + r, key 16 jt + l15
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] + coef8 * d2v[r]);
-#ifndef AT_DIAG_P1
-        if (c == 0 && jt == 0) stamp(6);
-        if (c == 0 && jt == 3) stamp(7);
-#endif
-      }
-    } else {
+    {
       const int h = wv;
       const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
       const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
@@ -768,16 +569,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
       if (NT > 1) stage_keys(1 % SD, 1);
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-#ifndef AT_ABL_P1_NOSTAGE
         if (jt + 2 < NT) stage_keys((jt + 2) % SD, jt & 1);  // tile jt+2 -> the buffer tile jt was read from (LDS ops retire in order)
-#endif
         KeyFrag nxt = cur;
         if (jt + 1 < NT) nxt = read_frags(jt + 1);
-#ifdef AT_ABL_P1_NOLOAD
-        if (false) {
-#else
         if (jt + SD < NT) {
-#endif
           load_keys(jt % SD, jt + SD);  // slot of tile jt (staged two iterations ago)
         } else if (jt + E_EARLY >= NT) {
           if constexpr (PLANES) {
@@ -798,26 +593,17 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
         for (int cc = 0; cc < 6; ++cc) gk[cc] = cur.gk[cc];
         cur = nxt;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#ifdef AT_ABL_P1_NOMFMA
-        acc = kb0 + kb1;
-#else
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
-#endif
         // acc[r] = q_s[i0+4q+r] . k_s[key 16jt+l15]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two coordinates per instruction, two partial sums added at the end
           f32x2 d2v = {0.f, 0.f};
-#ifdef AT_ABL_P1_NOVALU
-          d2v[0] = gk[r][0] + gk[r + 1][1];
-          for (int cc = 0; cc < 0; ++cc) {
-#else
 #pragma unroll
           for (int cc = 0; cc < 6; ++cc) {
-#endif
             // packed subtract spelled in assembly: the compiler splits a vector fsub (and fma(b, -1, a)) into two v_sub_f32
             f32x2 dlo, dhi;
             asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
@@ -927,22 +713,6 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int T = 0; T < NT / 2; ++T) {
-#ifdef AT_ABL_STREAMONLY  // timing ablation: phase 2 as a pure stream (the tiles are summed, nothing else happens to them)
-            {
-#pragma unroll
-              for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) oe[k4] += ev[ii][2 * T + tl][k4];
-              const int nx = ii * NT + 2 * T + RT;
-              if (nx < 2 * NT) {
-                load_e_tile(nx / NT, c, nx % NT);
-                load_e_tile((nx + 1) / NT, c, (nx + 1) % NT);
-                MEM_FENCE();
-              }
-              m_hist[T] = 0.f;
-              continue;
-            }
-#endif
             // ---- bias of the two tiles: A fragments straight from the loaded registers (lane = key l15, channels 32 ks + 8 q ..)
             f32x4 acc[2][2];
 #pragma unroll
@@ -1219,11 +989,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int stp = jt * 4 + r;
-#ifdef AT_ABL_NOV  // timing ablation (wrong results): the value side after the first 16 key steps is not loaded
-          if (false) {
-#else
           if (stp + PFV < NS) {
-#endif
             load_vals(stp + PFV);
             MEM_FENCE();
           }
@@ -1276,24 +1042,12 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     }
     if (!last) __syncthreads();  // the next chunk's phase 1 overwrites the image
   }
-  if constexpr (QUEUE) {  // this row tile's feature rows are in L2 (write-through L1; same XCD as the to_out item that reads them)
-    stamp(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(qa.ctr + 8 + b, 1);
-  } else {
-    break;
-  }
-  }  // work items
-  if constexpr (!QUEUE) stamp(5);
+  stamp(5);
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);
-#ifdef DIFFAB_EXPERIMENTAL
-  set_attn_pipe_stamps(p);
-#endif
 }
 
 // in-place local -> global for the three point blocks of the projection buffer (row-vector convention, :324)
@@ -1374,11 +1128,7 @@ __device__ __forceinline__ void pj_epilogue_piece(const PjCtx& c, const f32x4 (&
     const float oz = (vx * f0[2] + vy * f1[1] + vz * f2[0]) + f2[3];
     vx = ox; vy = oy; vz = oz;
   }
-#ifdef PJ_ABL_NOSTORE
-  if (c.M < 0) {
-#else
   if (FULL || c.m0 + lrow < c.M) {
-#endif
     pj_f3 o{vx, vy, vz};
     *reinterpret_cast<pj_f3*>(c.ybase + (16 * mt + r) * ANP + PJB * blk) = o;
   }
@@ -1386,9 +1136,7 @@ __device__ __forceinline__ void pj_epilogue_piece(const PjCtx& c, const f32x4 (&
 template <bool FULL, bool HAVE_PREV, bool PREV_FRAMES>
 __device__ __forceinline__ void pj_run_block(const PjCtx& c, const PjW w, const f32x4 (&a)[2][8], f32x4 (&wreg)[6], f32x4 (&cur)[2][3],
                                              const f32x4 (&prev)[2][3], int blk) {
-#ifndef PJ_ABL_NOWLOAD
   if (blk + 1 < PJNB) pj_load_w(c, w, blk + 1, wreg);
-#endif
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1413,9 +1161,7 @@ __device__ __forceinline__ void pj_run_block(const PjCtx& c, const PjW w, const 
     // The next block's weights go to LDS (q = 1) BEFORE this block issues any global store (q = 2..7): on gfx9 a wait for loads
     // with stores in flight degenerates to vmcnt(0), i.e. to waiting for the L2 acknowledgement of the newest store (measured:
     // 8 % of the kernel when the wait sat right behind the last store of the block).
-#ifndef PJ_ABL_NOWLOAD
     if (q == 1 && blk + 1 < PJNB) pj_store_w(c, (blk + 1) & 1, wreg);
-#endif
     if (HAVE_PREV) {  // 8 epilogue slices of the previous block spread over q = 2..7
       if (q == 2) { pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 0); pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 1); }
       if (q == 3) { pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 2); pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 3); }
@@ -1423,9 +1169,7 @@ __device__ __forceinline__ void pj_run_block(const PjCtx& c, const PjW w, const 
     }
     __builtin_amdgcn_sched_barrier(0);  // keep each slice's stores where they are (the scheduler otherwise sinks all 8 to the barrier)
   }
-#ifndef PJ_ABL_NOBARRIER
   __syncthreads();
-#endif
 }
 
 template <bool FULL>  // FULL: M is a multiple of 128, no row guards
@@ -1621,34 +1365,14 @@ int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipSt
 
 
 // DIFFAB_FLAG_FP32_GEMM: the dense projections on the f32-input MFMA kernels of this file instead of the bf16x6 kernels
-// (gemm_bf16x6.hip; same results to fp32 rounding) - the plain-fp32 reference path (experimental builds: also DIFFAB_FP32_GEMM=1)
-bool use_b6_gemm(uint32_t flags) {
-  static const bool v = env_int("DIFFAB_FP32_GEMM", 0) == 0;
-  return v && !(flags & DIFFAB_FLAG_FP32_GEMM);
-}
-#ifdef DIFFAB_EXPERIMENTAL
-// DIFFAB_OPERAND_PLANES=1: phase 1 of the planes attention kernel from the operand planes of proj_planes.hip (logits on the bf16 matrix
-// cores) instead of the fp32 projection buffer.  Measured (profiles/r03_operand_planes.md): not faster at K = 128 / 256 - the
-// phases of the attention kernel are bound by the bytes a CU can pull, and the planes are 1.5 x the bytes - so it is not the default.
-static bool operand_planes_enabled(const diffab_dims*) {
-  static const bool v = env_int("DIFFAB_OPERAND_PLANES", 0) != 0;
-  return v;
-}
-#endif
+// (gemm_bf16x6.hip; same results to fp32 rounding) - the plain-fp32 reference path
+bool use_b6_gemm(uint32_t flags) { return !(flags & DIFFAB_FLAG_FP32_GEMM); }
 static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
-#ifdef DIFFAB_EXPERIMENTAL
-static size_t pp_planes_offset() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
-size_t ipa_layer_planes_bytes() { return pp_planes_offset() + round256(proj_planes_scratch_bytes()); }
-#else
 size_t ipa_layer_planes_bytes() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
-#endif
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st) {
   DIFFAB_REQUIRE(w && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && w->w_out, DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
   if (int rc = launch_pjsplit(W6, planes, st)) return rc;
-#ifdef DIFFAB_EXPERIMENTAL
-  if (int rc = launch_ppsplit(W6, static_cast<char*>(planes) + pp_planes_offset(), st)) return rc;  // operand-plane projections (proj_planes.hip)
-#endif
   return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + round256(proj_frames_b6_scratch_bytes()), st);
 }
 static size_t b6_scratch_floats() { return (ipa_layer_planes_bytes() + 256) / sizeof(float); }
@@ -1660,22 +1384,11 @@ static size_t ipa_ws_operands_offset(const diffab_dims* d) {
   const size_t o = rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0) + b6_scratch_floats();
   return (o + 63) & ~static_cast<size_t>(63);
 }
-#ifdef DIFFAB_EXPERIMENTAL
-size_t ipa_fast_workspace_floats(const diffab_dims* d) {
-  const size_t rows = static_cast<size_t>(d->B) * d->K;
-  return ipa_ws_operands_offset(d) + 64 + proj_planes_operand_floats(rows) + 4 * static_cast<size_t>(d->B) + 64;
-}
-float* ipa_fast_centroid_slot(const diffab_dims* d, float* ws) {
-  const size_t rows = static_cast<size_t>(d->B) * d->K;
-  return ws + ipa_ws_operands_offset(d) + 64 + proj_planes_operand_floats(rows);
-}
-#else
 size_t ipa_fast_workspace_floats(const diffab_dims* d) { return ipa_ws_operands_offset(d); }
-#endif
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, int attn_mode, float* sp_keep, float* d2_keep, const void* planes,
-                   const float* pair_planes, const float* cent, bool fp32_gemm) {
+                   float* y, float* ws, hipStream_t st, float* sp_keep, float* d2_keep, const void* planes, const float* pair_planes,
+                   bool fp32_gemm) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1703,35 +1416,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   segs.nseg = 6;
   bool vec = aligned16(x);
   for (int s = 0; s < 6; ++s) vec = vec && aligned16(segs.W[s]);
-#ifdef DIFFAB_PROJ_TWO_KERNELS  // previous formulation, kept for A/B timing: tiled GEMM, then an in-place frame pass
-  if (int rc = launch_linear_bn<64>(x, D, segs, nullptr, proj, ANP, rows, ANP, D, false, vec, st)) return rc;
-  hipLaunchKernelGGL(points_to_global_fast_kernel, dim3((rows * 192 + 255) / 256), dim3(256), 0, st, proj, R, t, rows);
-  DIFFAB_LAUNCH_CHECK();
-#else
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
-#ifdef DIFFAB_EXPERIMENTAL
-  // Operand-plane form (pair planes given, default attention mode, bf16x6 GEMMs): the projection kernel writes the query / key sides
-  // as MFMA operands of the attention kernel's logits product (proj_planes.hip) and only the value side into `proj`.
-  // DIFFAB_ATTN_PIPE=1: K = 64 / 128 through the sixteen-wave key-tile pipeline on the operand planes (attention_pipe.hip)
-  static const bool env_pipe = env_int("DIFFAB_ATTN_PIPE", 0) != 0;
-  const bool planes_ok = b6 && pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d) && sp_keep == nullptr;
-  const bool pipe = planes_ok && env_pipe && attention_pipe_supported(d);
-  const bool b6l = planes_ok && (pipe || operand_planes_enabled(d));
-  float* qk_ops = nullptr;
-  if (b6l) {
-    float* base = ws + ipa_ws_operands_offset(d);
-    qk_ops = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(base) + 255) & ~static_cast<uintptr_t>(255));
-    if (cent == nullptr) {
-      float* own = ipa_fast_centroid_slot(d, ws);
-      if (int rc = launch_patch_centroids(t, d->B, d->K, own, st)) return rc;
-      cent = own;
-    }
-    if (int rc = launch_proj_planes_b6(x, static_cast<const char*>(planes) + pp_planes_offset(), R, t, cent, w->gamma, qk_ops, proj, rows, d->K, st))
-      return rc;
-  } else
-#else
-  (void)cent;
-#endif
   if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {
@@ -1748,126 +1433,39 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
 #undef PROJ_LAUNCH
     DIFFAB_LAUNCH_CHECK();
   }
-#endif
-  // DIFFAB_FLAG_SPLIT_ATTENTION (K = 64 / 128): three launches exchanging logits / probabilities through HBM (attention_split.hip).
-  // Its pair-stream kernel sustains 3.8 TB/s (47 % of the HBM peak) against 2.9 for the fused kernel below, but the logits and
-  // P x V launches are not yet at their floors and the three together are slower (0.45 vs 0.37 ms) - hence opt-in.
-  if (sp_keep != nullptr && attention_split_supported(d)) {  // training tape: ws has no tail here, P / d2 go to the tape's own slots
+  // Training tape (sp_keep != nullptr, K = 64 / 128): the attention as three launches that leave the probabilities and the squared point
+  // distances on the tape for the backward (attention_split.hip); ws has no tail there.  Everything else: the fused kernel.
+  if (sp_keep != nullptr && attention_split_supported(d)) {
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, sp_keep, st, d2_keep)) return rc;
     return to_out();
   }
-  if (attn_mode == 1 && attention_split_supported(d)) {
-    float* SP = feat + static_cast<size_t>(rows) * AF + 128;
-    if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, SP, st)) return rc;
-    return to_out();
-  }
-#ifdef DIFFAB_EXPERIMENTAL  // (the product library ignores DIFFAB_FLAG_FLASH_ATTENTION: default kernel)
-  // DIFFAB_FLAG_FLASH_ATTENTION (K = 64 / 128): the key-tile pipeline of attention_flash.hip - no logits image in LDS, the pair stream in
-  // flight from the first instruction.  Parity-tested on the same goldens; measured 0.380 ms against 0.357 ms for the three-phase
-  // kernel below at B = 256 (both leave the matrix pipe idle > 50 % of the time: DESIGN section 4.1), hence opt-in.
-  // DIFFAB_ATTN_FLASH=1 in the environment selects it for every default-mode call (A/B timing with bench.py).
-  static const bool env_flash = env_int("DIFFAB_ATTN_FLASH", 0) != 0;
-  if ((attn_mode == 3 || (attn_mode == 0 && env_flash)) && attention_flash_supported(d)) {
-    const float* pp = (attn_mode == 0 && pair_planes_supported(d)) ? pair_planes : nullptr;
-    if (int rc = launch_attention_flash(d, proj, e, R, t, w->w_bias, w->gamma, feat, g_attn_stamps, st, pp)) return rc;
-    return to_out();
-  }
-#endif
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
   const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
   const dim3 grid(d->B * (d->K / TI));
-  const bool ext_logits = attn_mode == 2 && attention_split_supported(d);  // single chunk by construction (K = 64 / 128)
-  float* SPx = feat + static_cast<size_t>(rows) * AF + 128;
-  if (ext_logits)
-    if (int rc = launch_ipa_logits(d, proj, w->gamma, SPx, st)) return rc;
-#define ATTN_LAUNCH_X(NT_, MULTI_, EXT_)                                                                                              \
+  // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores, the pair stream read as two fp16 planes
+  const bool use_planes = pair_planes != nullptr && pair_planes_supported(d);
+  const float* e_arg = use_planes ? pair_planes + 64 : e;
+  const float* esc = use_planes ? pair_row_scales(d, pair_planes) : nullptr;
+#define ATTN_LAUNCH(NT_, MULTI_, PLANES_)                                                                                             \
   do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, EXT_>),                      \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, PLANES_>),                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, EXT_>), grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat, \
-                       d->B, nc, g_attn_stamps, SPx);                                                                                 \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, PLANES_>), grid, dim3(512), lds, st, proj, e_arg, R, t, w->w_bias,          \
+                       w->gamma, feat, d->B, nc, g_attn_stamps, esc);                                                                 \
     timer_end(st);                                                                                                                    \
   } while (0)
-#define ATTN_LAUNCH(NT_, MULTI_) ATTN_LAUNCH_X(NT_, MULTI_, false)
-#define ATTN_LAUNCH_PLANES(NT_, MULTI_)                                                                                               \
-  do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, false, true>),               \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
-    timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, false, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R, t,      \
-                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_row_scales(d, pair_planes));                                     \
-    timer_end(st);                                                                                                                    \
-  } while (0)
-#define ATTN_LAUNCH_B6L(NT_, MULTI_)                                                                                                  \
-  do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, false, true, true>),         \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
-    timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, false, true, true>), grid, dim3(512), lds, st, proj, pair_planes + 64, R,   \
-                       t, w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_row_scales(d, pair_planes),                                   \
-                       reinterpret_cast<const f32x4*>(qk_ops), static_cast<int64_t>(rows) * (8 * 64 * 3 * 2 / 16));                   \
-    timer_end(st);                                                                                                                    \
-  } while (0)
-#ifdef DIFFAB_EXPERIMENTAL
-  // DIFFAB_ATTN_QUEUE=1: attention + to_out of the layer as ONE persistent launch over per-XCD work queues (QUEUE form of the kernel),
-  // first items staggered by DIFFAB_ATTN_QUEUE_STAGGER ticks of 10 ns per class (default 500)
-  static const bool env_queue = env_int("DIFFAB_ATTN_QUEUE", 0) != 0;
-  static const int env_queue_ticks = env_int("DIFFAB_ATTN_QUEUE_STAGGER", 500);
-  if (env_queue && !b6l && pair_planes != nullptr && attn_mode == 0 && nt == 8 && nc == 1 && (d->B & 7) == 0 && b6 && attention_split_supported(d) &&
-      rowgemm128_b6_ok(feat, AF, y, D, rows, AF)) {
-    int* qctr = reinterpret_cast<int*>(SPx);
-    DIFFAB_HIP_CHECK(hipMemsetAsync(qctr, 0, sizeof(int) * (8 + static_cast<size_t>(d->B)), st));
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      DIFFAB_HIP_CHECK(hipGetDevice(&dev));
-      DIFFAB_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    const int groups = static_cast<int>(grid.x) < n_cu ? static_cast<int>(grid.x) : n_cu;
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<8, false, false, true, false, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    AttnQueue qa{qctr, out_planes, w->b_out, y, env_queue_ticks};
-    timer_begin(st);
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<8, false, false, true, false, true>), dim3(groups), dim3(512), lds, st, proj, pair_planes + 64, R, t,
-                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, SPx, pair_row_scales(d, pair_planes),
-                       static_cast<const f32x4*>(nullptr), static_cast<int64_t>(0), qa);
-    timer_end(st);
-    DIFFAB_LAUNCH_CHECK();
-    return DIFFAB_OK;
-  }
-#endif
-#ifdef DIFFAB_EXPERIMENTAL
-  if (b6l && pipe) {
-    if (int rc = launch_attention_pipe(d, proj, pair_planes, R, t, w->w_bias, w->gamma, feat, qk_ops, st)) return rc;
-    return to_out();
-  }
-#endif
-#ifdef DIFFAB_EXPERIMENTAL
-  if (b6l) {
-    if (nt == 8 && nc == 1) ATTN_LAUNCH_B6L(8, false);
-    else if (nt == 8) ATTN_LAUNCH_B6L(8, true);
-    else if (nc == 1) ATTN_LAUNCH_B6L(4, false);
-    else ATTN_LAUNCH_B6L(4, true);
-  } else
-#endif
-  // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores; single key chunk, attention default mode only
-  if (pair_planes != nullptr && attn_mode == 0 && pair_planes_supported(d)) {
-    if (nt == 8 && nc == 1) ATTN_LAUNCH_PLANES(8, false);
-    else if (nt == 8) ATTN_LAUNCH_PLANES(8, true);
-    else if (nc == 1) ATTN_LAUNCH_PLANES(4, false);
-    else ATTN_LAUNCH_PLANES(4, true);
-  } else if (ext_logits && nt == 8) ATTN_LAUNCH_X(8, false, true);
-  else if (ext_logits) ATTN_LAUNCH_X(4, false, true);
-  else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false);
-  else if (nt == 8) ATTN_LAUNCH(8, true);
-  else if (nc == 1) ATTN_LAUNCH(4, false);
-  else ATTN_LAUNCH(4, true);
-#undef ATTN_LAUNCH_X
+  if (use_planes) {
+    if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, true);
+    else if (nt == 8) ATTN_LAUNCH(8, true, true);
+    else if (nc == 1) ATTN_LAUNCH(4, false, true);
+    else ATTN_LAUNCH(4, true, true);
+  } else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, false);
+  else if (nt == 8) ATTN_LAUNCH(8, true, false);
+  else if (nc == 1) ATTN_LAUNCH(4, false, false);
+  else ATTN_LAUNCH(4, true, false);
 #undef ATTN_LAUNCH
-#undef ATTN_LAUNCH_PLANES
-#undef ATTN_LAUNCH_B6L
   DIFFAB_LAUNCH_CHECK();
   return to_out();
 }

@@ -18,20 +18,11 @@ int launch_heads_finish(const float* v, const float* O_t, const float* logits, i
 bool fast_path_supported(const diffab_dims* d);
 size_t ipa_fast_workspace_floats(const diffab_dims* d);
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
-                   float* y, float* ws, hipStream_t st, int attn_mode = 0,  // 0 fused | 1 three launches | 2 logits launch + fused rest
+                   float* y, float* ws, hipStream_t st,
                    float* sp_keep = nullptr, float* d2_keep = nullptr,  // training tape: three launches, P and d2 kept in these buffers
                    const void* planes = nullptr,  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
                    const float* pair_planes = nullptr,  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
-                   const float* cent = nullptr,  // launch_patch_centroids() output for t (operand-plane form; nullptr: computed here)
                    bool fp32_gemm = false);  // DIFFAB_FLAG_FP32_GEMM: dense products on the f32-input MFMA kernels
-float* ipa_fast_centroid_slot(const diffab_dims* d, float* ws);  // where a caller may park the centroids of a step (B x 4 floats)
-// proj_planes.hip: the projections as MFMA operands of the attention kernel's logits product
-size_t proj_planes_scratch_bytes();
-size_t proj_planes_operand_floats(int64_t rows);
-int launch_ppsplit(const float* const* W6, void* planes, hipStream_t st);
-int launch_patch_centroids(const float* t, int B, int K, float* cent, hipStream_t st);
-int launch_proj_planes_b6(const float* x, const void* planes, const float* R, const float* t, const float* cent, const float* gamma,
-                          void* qk, float* proj, int rows, int K, hipStream_t st);
 // fp16 planes of the pair embedding for the fused attention kernel (K = 64 / 128): pair_planes_floats(d) floats, 256-byte aligned
 bool pair_planes_supported(const diffab_dims* d);
 size_t pair_planes_floats(const diffab_dims* d);
@@ -83,7 +74,7 @@ int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, c
                        hipStream_t st, bool emb_tab_ready = false);  // beta == nullptr: the weights-only embedding table alone
 
 // attention_split.hip: the attention of one IPA layer as three launches (logits | pair stream | P x V) exchanging the
-// (B, 8, K, K) logits / probabilities through SP; single key chunk only (K = 64, 128)
+// (B, 8, K, K) logits / probabilities through SP - the form the training tape keeps; single key chunk only (K = 64, 128)
 bool attention_split_supported(const diffab_dims* d);
 size_t attention_split_workspace_floats(const diffab_dims* d);
 int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamma, float* SP, hipStream_t st);  // S[b][h][i][j] only
@@ -94,18 +85,6 @@ int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P,
                            hipStream_t st);  // training backward: g, d gamma / d w_bias partials, d e
 int launch_attention_split(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
                            const float* gamma, float* feat, float* SP, hipStream_t st, float* D2 = nullptr);
-
-// attention_flash.hip: the fused attention as a key-tile pipeline with an online softmax (K = 64 / 128); default for those K
-bool attention_flash_supported(const diffab_dims* d);
-int launch_attention_flash(const diffab_dims* d, const float* proj, const float* e, const float* R, const float* t, const float* Wb,
-                           const float* gamma, float* feat, unsigned long long* stamps, hipStream_t st,
-                           const float* pair_planes = nullptr);  // launch_pair_split() output: 16-wave form, producers on f16 MFMA
-
-// attention_pipe.hip: sixteen-wave key-tile pipeline on the operand planes (K = 64 / 128)
-bool attention_pipe_supported(const diffab_dims* d);
-int launch_attention_pipe(const diffab_dims* d, const float* proj, const float* pair_planes, const float* R, const float* t, const float* Wb,
-                          const float* gamma, float* feat, const float* qk_ops, hipStream_t st);
-void set_attn_pipe_stamps(void* device_buffer);
 
 void set_stream_order(bool on);  // api.hip: the cross-stream ordering guard (common.h StreamOrder)
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases

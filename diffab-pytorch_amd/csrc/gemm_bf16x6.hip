@@ -310,9 +310,8 @@ int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const flo
                  "rowgemm128_b6: unsupported operands");
   const __bf16* Wc = static_cast<const __bf16*>(planes);
   // 128-row work-groups when they fill the chip (measured at 256 groups: 47 us against 53 for 64-row groups, K = 1024), 64-row
-  // groups below that (B <= 128 patches of 128 residues per GPU: twice the groups); DIFFAB_B6_ROWS=64|128 forces one
-  static const int rows_force = env_int("DIFFAB_B6_ROWS", 0);
-  const int rows_env = rows_force ? rows_force : ((M + 127) / 128 >= 256 ? 128 : 64);
+  // groups below that (B <= 128 patches of 128 residues per GPU: twice the groups)
+  const int rows_env = (M + 127) / 128 >= 256 ? 128 : 64;
 #define B6_LAUNCH(RELU_, ROWS_)                                                                                                         \
   do {                                                                                                                                  \
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_kernel<RELU_, ROWS_>),                              \
@@ -711,11 +710,7 @@ __global__ __launch_bounds__(512) void gemm_tn_b6_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           __bf16 hh, mm, ll;
-#ifdef TN_ABL_NOSPLIT
-          hh = mm = ll = static_cast<__bf16>(v[c]);
-#else
           split3(v[c], hh, mm, ll);
-#endif
           h[c] = hh; m[c] = mm; l[c] = ll;
         }
         __bf16* dst = base + op * (3 * TN_PLANE) + off;

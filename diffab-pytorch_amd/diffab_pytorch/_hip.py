@@ -14,17 +14,14 @@ from typing import Dict, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DIFFAB_HIP_LIB: developer override used by tools/ to load an experimental build of the same C ABI
+# DIFFAB_HIP_LIB: developer override used by tools/ and experiments/ to load another build of the same C ABI (ablations, variants)
 LIB_PATH = os.environ.get("DIFFAB_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdiffab_hip.so")
 
 FLAG_FORCE_GENERIC = 1
-FLAG_EXTERNAL_LOGITS = 4  # K = 64 / 128: logits in their own launch, the fused kernel copies them (csrc/attention_split.hip)
-FLAG_FLASH_ATTENTION = 8  # experimental builds only (csrc/attention_flash.hip); ignored by the product library
 FLAG_PAIR_F32 = 64  # sample_loop: keep the fp32 pair stream (no fp16 planes)
 FLAG_FP32_GEMM = 128  # forward paths: dense products on the f32-input MFMA kernels instead of the bf16 split
 FLAG_PAIR_PLANES = 32  # K = 64 / 128: pair embedding as two fp16 planes, pair-tile products on the f16 matrix cores (always on in sample_loop)
 FLAG_GRAPH_SAMPLER = 16  # sample_loop: one captured step replayed as a hipGraph (launch-bound small batches)
-FLAG_SPLIT_ATTENTION = 2  # K = 64 / 128: attention as three launches (csrc/attention_split.hip); default is the fused kernel
 
 
 class HipUnavailable(RuntimeError):
@@ -153,12 +150,6 @@ SYMBOLS = {
     "diffab_sample_init": (C.c_int, [_fp, _fp, _fp, _fp, _u64, _i64, _i32, _i32, _i32, _fp]),
 }
 
-# include/diffab_hip_experimental.h: present only in the EXPERIMENTAL build (tools/, tests of the unadopted variants)
-EXPERIMENTAL_SYMBOLS = {
-    "diffab_debug_proj_planes_scratch_bytes": (_sz, [_PD]),
-    "diffab_debug_proj_planes": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
-}
-
 _lib: Optional[C.CDLL] = None
 
 
@@ -174,10 +165,6 @@ def load_library() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
             fn.restype, fn.argtypes = res, args
-        for name, (res, args) in EXPERIMENTAL_SYMBOLS.items():
-            fn = getattr(lib, name, None)
-            if fn is not None:
-                fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
 

@@ -17,18 +17,23 @@ from diffab_pytorch import _hip, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
-EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffab-pytorch_amd", "build_exp", "libdiffab_hip.so")
+EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "experiments", "build", "libdiffab_hip.so")
 
 
 @pytest.fixture(scope="module")
 def hip():
-    """The EXPERIMENTAL build of the library (`make EXPERIMENTAL=1`, built by __graft_entry__.build()): the operand-plane kernels are
+    """The EXPERIMENTAL build of the library (experiments/build.sh): the operand-plane kernels are
     a measured, unadopted variant and are not part of the product library."""
     assert _hip.lib().diffab_device_ok() == 1
     if not os.path.exists(EXP_LIB):
-        pytest.skip("experimental library not built (make -C diffab-pytorch_amd/csrc EXPERIMENTAL=1)")
+        pytest.skip("experimental library not built (bash experiments/build.sh)")
     lib = C.CDLL(EXP_LIB)
-    for name, (res, args) in _hip.EXPERIMENTAL_SYMBOLS.items():
+    _PD, _fp, _sz = C.POINTER(_hip.Dims), C.c_void_p, C.c_size_t
+    exp_symbols = {  # experiments/include/diffab_hip_experimental.h
+        "diffab_debug_proj_planes_scratch_bytes": (_sz, [_PD]),
+        "diffab_debug_proj_planes": (C.c_int, [_PD, C.POINTER(_hip.IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    }
+    for name, (res, args) in exp_symbols.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     return lib

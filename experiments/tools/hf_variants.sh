@@ -1,7 +1,7 @@
 #!/bin/bash
 # Two-queue wrong-result investigation: tools/step_race_check.py with each heads_finish variant of the EXPERIMENTAL build.
 R=$GRAFT_REPO_ROOT
-export DIFFAB_HIP_LIB=$R/diffab-pytorch_amd/build_exp/libdiffab_hip.so
+export DIFFAB_HIP_LIB=$R/experiments/build/libdiffab_hip.so
 O=$R/gpurun_out/hf; mkdir -p $O
 for v in ${VARS:-0 5 1 2 3 4}; do
   echo "== DIFFAB_HF_VARIANT=$v" | tee -a $O/hf.log

@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXP = os.path.join(REPO, "diffab-pytorch_amd", "build_exp", "libdiffab_hip.so")
+EXP = os.path.join(REPO, "experiments", "build", "libdiffab_hip.so")
 
 if len(sys.argv) > 2 and sys.argv[2] == "child":
     sys.path.insert(0, os.path.join(REPO, "diffab-pytorch_amd"))

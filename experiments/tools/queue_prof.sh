@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: kernel stats of one IPA layer, default launches vs the queue-driven launch (EXPERIMENTAL build) at several staggers.
 cd /tmp && export TMPDIR=/tmp
-export DIFFAB_HIP_LIB=$GRAFT_REPO_ROOT/diffab-pytorch_amd/build_exp/libdiffab_hip.so
+export DIFFAB_HIP_LIB=$GRAFT_REPO_ROOT/experiments/build/libdiffab_hip.so
 for cfg in "0 0" "1 0" "1 250" "1 500" "1 1000"; do
   set -- $cfg
   export DIFFAB_ATTN_QUEUE=$1 DIFFAB_ATTN_QUEUE_STAGGER=$2

@@ -23,9 +23,8 @@
  *     (an event list) and diffab_debug_set_attn_stamps (a stamp-buffer pointer);
  *     they are not thread-safe and must not be left enabled in production.
  *     DIFFAB_FLAG_GRAPH_SAMPLER makes diffab_sample_loop drain a private stream
- *     before it returns.  (Kernel variants that were measured and not adopted, and
- *     the environment switches used to A/B them, exist only in the EXPERIMENTAL
- *     build of this library - `make EXPERIMENTAL=1`, include/diffab_hip_experimental.h.)
+ *     before it returns.  (Kernel variants that were measured and not adopted, the environment
+ *     switches used to A/B them and the timing-ablation hooks are patches under experiments/.)
  *   - Streams: calls on ONE stream are ordered by the stream, as usual.  Calls on DIFFERENT streams are additionally serialised on
  *     the device by the library itself: before a call enqueues on stream B, everything enqueued so far on the stream of the library's
  *     previous call (same device) is ordered in front of it (hipEventRecord + hipStreamWaitEvent; no host synchronisation; one mutex
@@ -58,13 +57,8 @@ extern "C" {
 
 /* flags */
 #define DIFFAB_FLAG_FORCE_GENERIC 1u /* skip the MFMA kernels specialised for D=128,C=64,H=8,DS=32,P=8 */
-#define DIFFAB_FLAG_EXTERNAL_LOGITS 4u /* K = 64 / 128: the logits of each layer in their own launch (key side staged once per 64 query
-                                          rows), the fused kernel copies them instead of computing its phase 1 */
-#define DIFFAB_FLAG_SPLIT_ATTENTION 2u /* K = 64 / 128: the attention of each layer as three launches (logits | pair stream | P x V)
-                                          instead of the fused kernel; same results to rounding, see csrc/attention_split.hip */
-
-#define DIFFAB_FLAG_FLASH_ATTENTION 8u /* experimental builds only (csrc/attention_flash.hip: the attention as a key-tile pipeline with
-                                          an online softmax); the product library ignores it and runs the default kernel */
+/* (bits 2u, 4u, 8u selected attention variants that were measured slower than the fused kernel and are no longer part of this
+   library: experiments/README.md; the three-launch attention survives as the form the training tape keeps) */
 
 #define DIFFAB_FLAG_PAIR_PLANES 32u /* K = 64 / 128, default attention kernel: the pair embedding is first rewritten as two fp16 planes (e s =
                                       h1 + h2 to 2^-23 of the tensor maximum, same bytes, in the workspace) and the two products on
@@ -187,7 +181,8 @@ int diffab_so3_scale_rot(const float* R, const float* k, float* out, int64_t n, 
 /* ---- IGSO3 ---------------------------------------------------------------- */
 /* so3.py:52-72  pdf[n_sigmas][n_bins] at the bin centres, series of num_iters terms, NaN->0, <0 -> 0.  The reference's table:
  * every term formed with the reference's own fp32 roundings (its rounding noise, rectified by the clamp, is part of the
- * distribution it samples from); the terms are added in float64 (torch's cascade sum has no fixed order to copy). */
+ * distribution it samples from); the terms are added in fp32 in the order of torch's CPU cascade sum for this reduction (ATen
+ * SumKernel multi_row_sum: four levels), csrc/diffusion_kernels.hip igso3_pdf_kernel<true>. */
 int diffab_igso3_table_build(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf, void* stream);
 /* opt-in variant: the whole series in float64, rounded once - the exact density, NOT what the reference samples from */
 int diffab_igso3_table_build_accurate(const float* sigmas, int32_t n_sigmas, int32_t n_bins, int32_t num_iters, float* pdf,

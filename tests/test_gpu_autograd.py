@@ -142,6 +142,17 @@ def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
     check_grad("layer/e", e.grad, g)
     for n_, p_ in layer.named_parameters():
         check_grad("layer/" + n_, p_.grad, g)
+    # DIFFAB_FLAG_FORCE_GENERIC under autograd: the taped forwards ignore it (their backward reads the tape the MFMA path
+    # writes) - same output, same gradients, at unit dims (generic kernels on both sides anyway) and at the benchmark geometry
+    layer.zero_grad(set_to_none=True)
+    x2, e2 = x.detach().clone().requires_grad_(True), e.detach().clone().requires_grad_(True)
+    y2 = layer(x2, e2, inp["orientations"], inp["translations"], flags=_hip.FLAG_FORCE_GENERIC)
+    assert maxrel(y2, g["layer/y"]) < 1e-4
+    (y2 * T(g["layer/c_y"]).cuda()).sum().backward()
+    check_grad("layer/x", x2.grad, g)
+    check_grad("layer/e", e2.grad, g)
+    for n_, p_ in layer.named_parameters():
+        check_grad("layer/" + n_, p_.grad, g)
     # under no_grad the same call is the inference kernel: detached output, same numbers
     with torch.no_grad():
         y0 = layer(x, e, inp["orientations"], inp["translations"])

@@ -329,9 +329,8 @@ def build_case(g):
     return dims, den, inp
 
 
-@pytest.mark.parametrize("flags", [0, _hip.FLAG_FORCE_GENERIC, _hip.FLAG_SPLIT_ATTENTION, _hip.FLAG_EXTERNAL_LOGITS, _hip.FLAG_FP32_GEMM,
-                                   _hip.FLAG_PAIR_PLANES],
-                         ids=["dispatch", "generic", "split", "extlogits", "fp32gemm", "pairplanes"])
+@pytest.mark.parametrize("flags", [0, _hip.FLAG_FORCE_GENERIC, _hip.FLAG_FP32_GEMM, _hip.FLAG_PAIR_PLANES],
+                         ids=["dispatch", "generic", "fp32gemm", "pairplanes"])
 @pytest.mark.parametrize("name", CASES)
 def test_denoiser_vs_reference_goldens(hip, golden, name, flags):
     g = golden("denoiser_" + name)
@@ -420,9 +419,8 @@ def test_fast_path_key_chunks_vs_generic_and_oracle(hip, K):
     for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
         assert maxrel(fast[k], want[k]) < TOL, (K, k, maxrel(fast[k], want[k]))
         assert maxrel(fast[k], gen[k]) < TOL, (K, k, maxrel(fast[k], gen[k]))
-    # the opt-in attention variants (three launches / external logits / fp32 dense kernels) at this K: 4-tile instantiations for
-    # K = 64, and a silent fall-through to the fused kernel where they do not apply (K = 192, 256)
-    for fl in (_hip.FLAG_SPLIT_ATTENTION, _hip.FLAG_EXTERNAL_LOGITS, _hip.FLAG_FP32_GEMM, _hip.FLAG_PAIR_PLANES):
+    # the arithmetic selectors (fp32 dense kernels, fp16 pair planes) at this K: 4-tile instantiations for K = 64, chunked ones for 192 / 256
+    for fl in (_hip.FLAG_FP32_GEMM, _hip.FLAG_PAIR_PLANES):
         alt = den(*[a.cuda() for a in args], beta.cuda(), None, None, return_logits=True, flags=fl)
         for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
             assert maxrel(alt[k], want[k]) < TOL, (K, fl, k, maxrel(alt[k], want[k]))
