@@ -90,7 +90,9 @@ void timer_end(hipStream_t st) {
 
 static int check_dims(const diffab_dims* d, const char* who) {
   DIFFAB_REQUIRE(d != nullptr, DIFFAB_ERR_ARG, "%s: dims is null", who);
-  DIFFAB_REQUIRE(d->B > 0 && d->K > 0 && d->D > 0 && d->C > 0 && d->H > 0 && d->DS > 0 && d->PQ > 0 && d->PV > 0 && d->NL >= 0 && d->V > 0,
+  // C == 0: an IPA layer built with use_pair_bias = False (reference :348-385) - no pair bias, two independent logits, no o_pair block
+  // in the feature row; the layer entries take it on the any-dims path (e and w_bias may be NULL), the Denoiser always has C > 0
+  DIFFAB_REQUIRE(d->B > 0 && d->K > 0 && d->D > 0 && d->C >= 0 && d->H > 0 && d->DS > 0 && d->PQ > 0 && d->PV > 0 && d->NL >= 0 && d->V > 0,
                  DIFFAB_ERR_ARG, "%s: non-positive dimension (B=%d K=%d D=%d C=%d H=%d DS=%d PQ=%d PV=%d NL=%d V=%d)", who, d->B, d->K, d->D,
                  d->C, d->H, d->DS, d->PQ, d->PV, d->NL, d->V);
   DIFFAB_REQUIRE(static_cast<int64_t>(d->B) * d->K < (1ll << 31), DIFFAB_ERR_UNSUPPORTED, "%s: B*K must be < 2^31", who);
@@ -132,7 +134,8 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
 static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                               const float* t, float* y, float* ws, uint32_t flags, hipStream_t st, float* sp_keep = nullptr,
                               float* d2_keep = nullptr, const void* planes = nullptr, const float* pair_planes = nullptr) {
-  DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && w->w_bias && w->wq_p && w->wk_p && w->wv_p && w->w_out && w->b_out,
+  DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && (w->w_bias || d->C == 0) && w->wq_p && w->wk_p && w->wv_p && w->w_out &&
+                     w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
     return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, sp_keep, d2_keep, planes, pair_planes, (flags & DIFFAB_FLAG_FP32_GEMM) != 0);
@@ -299,6 +302,7 @@ static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weight
 static int check_denoiser_weights(const diffab_dims* d, const diffab_denoiser_weights* w) {
   DIFFAB_REQUIRE(w && w->seq_emb && w->res_w0 && w->res_b0 && w->res_w2 && w->res_b2 && (d->NL == 0 || w->layers), DIFFAB_ERR_ARG,
                  "denoiser: null weight pointer");
+  DIFFAB_REQUIRE(d->C > 0, DIFFAB_ERR_ARG, "denoiser: C must be positive (the Denoiser's IPA layers use the pair bias, :478-492)");
   return DIFFAB_OK;
 }
 
@@ -399,7 +403,7 @@ int diffab_ipa_layer_fwd(const diffab_dims* d, const diffab_ipa_layer_weights* w
                          const float* t, float* y, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
   StreamOrder order_(stream);
   if (int rc = check_dims(d, "ipa_layer_fwd")) return rc;
-  DIFFAB_REQUIRE(x && e && R && t && y && workspace, DIFFAB_ERR_ARG, "ipa_layer_fwd: null pointer");
+  DIFFAB_REQUIRE(x && (e || d->C == 0) && R && t && y && workspace, DIFFAB_ERR_ARG, "ipa_layer_fwd: null pointer");
   const StepBuffers b = carve_step(d, workspace);
   DIFFAB_REQUIRE(workspace_bytes >= b.bytes, DIFFAB_ERR_WORKSPACE, "ipa_layer_fwd: workspace %zu < %zu bytes", workspace_bytes, b.bytes);
   const float* pair_planes = nullptr;
@@ -496,7 +500,8 @@ int diffab_denoise_step_fwd_taped(const diffab_dims* d, const diffab_denoiser_we
 int diffab_denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
                             const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_posterior,
                             const float* d_eps, const float* d_O0, const float* d_posterior, float* d_res_ctx, float* d_pair_ctx,
-                            const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+                            float* d_x_t, float* d_O_t, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   StreamOrder order_(stream);
   if (int rc = check_dims(d, "denoise_step_bwd")) return rc;
   if (int rc = check_denoiser_weights(d, w)) return rc;
@@ -509,7 +514,7 @@ int diffab_denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights*
                  workspace_bytes, train_bwd_workspace_floats(d) * sizeof(float));
   const TrainTape tp = carve_tape(d, static_cast<float*>(const_cast<void*>(tape)));
   return denoise_step_bwd(d, w, grads, tp, seq_t, x_t, O_t, pair_ctx, out_posterior, d_eps, d_O0, d_posterior, d_res_ctx, d_pair_ctx,
-                          static_cast<float*>(workspace), as_stream(stream));
+                          static_cast<float*>(workspace), as_stream(stream), d_x_t, d_O_t);
 }
 
 static diffab_dims one_layer(const diffab_dims* d) {
@@ -532,7 +537,7 @@ int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weig
                                const float* t, float* y, void* tape, size_t tape_bytes, uint32_t flags, void* stream) {
   StreamOrder order_(stream);
   if (int rc = check_dims(d, "ipa_layer_fwd_taped")) return rc;
-  DIFFAB_REQUIRE(x && e && R && t && y && tape, DIFFAB_ERR_ARG, "ipa_layer_fwd_taped: null pointer");
+  DIFFAB_REQUIRE(x && (e || d->C == 0) && R && t && y && tape, DIFFAB_ERR_ARG, "ipa_layer_fwd_taped: null pointer");
   const diffab_dims d1 = one_layer(d);
   DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(&d1) * sizeof(float), DIFFAB_ERR_WORKSPACE, "ipa_layer_fwd_taped: tape %zu < %zu bytes", tape_bytes,
                  train_tape_floats(&d1) * sizeof(float));
@@ -551,17 +556,17 @@ int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weig
 }
 
 int diffab_ipa_layer_bwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const diffab_ipa_layer_weights* grads, const float* e,
-                         const float* R, const float* t, const float* dy, float* dx, float* d_e, const void* tape, size_t tape_bytes,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         const float* R, const float* t, const float* dy, float* dx, float* d_e, float* d_R, float* d_t, const void* tape,
+                         size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
   StreamOrder order_(stream);
   if (int rc = check_dims(d, "ipa_layer_bwd")) return rc;
-  DIFFAB_REQUIRE(w && grads && e && R && t && dy && dx && tape && workspace, DIFFAB_ERR_ARG, "ipa_layer_bwd: null pointer");
+  DIFFAB_REQUIRE(w && grads && (e || d->C == 0) && R && t && dy && dx && tape && workspace, DIFFAB_ERR_ARG, "ipa_layer_bwd: null pointer");
   const diffab_dims d1 = one_layer(d);
   DIFFAB_REQUIRE(tape_bytes >= train_tape_floats(&d1) * sizeof(float), DIFFAB_ERR_WORKSPACE, "ipa_layer_bwd: tape too small");
   DIFFAB_REQUIRE(workspace_bytes >= train_bwd_workspace_floats(&d1) * sizeof(float), DIFFAB_ERR_WORKSPACE, "ipa_layer_bwd: workspace %zu < %zu",
                  workspace_bytes, train_bwd_workspace_floats(&d1) * sizeof(float));
   const TrainTape tp = carve_tape(&d1, static_cast<float*>(const_cast<void*>(tape)));
-  return ipa_layer_bwd(&d1, w, grads, tp, R, t, e, dy, dx, d_e, static_cast<float*>(workspace), as_stream(stream));
+  return ipa_layer_bwd(&d1, w, grads, tp, R, t, e, dy, dx, d_e, static_cast<float*>(workspace), as_stream(stream), d_R, d_t);
 }
 
 int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_sched* s, const diffab_igso3* rev_tab,

@@ -325,7 +325,15 @@ __global__ void count_mask_kernel(const uint8_t* __restrict__ gm, const uint8_t*
 
 // d L / d v from G0 = d L / d O0 for O0 = O_t E, E = exp(hat(v)) = I + a S + b S^2 (diffab_pytorch.py:594-596, so3.py:219-237)
 __device__ __forceinline__ void rotvec_head_bwd(const float (&G0)[9], const float* __restrict__ Ot, const float* __restrict__ v3,
-                                                float* __restrict__ dv3) {
+                                                float* __restrict__ dv3, float* __restrict__ dOt = nullptr) {
+  if (dOt != nullptr) {  // d L / d O_t = G0 E^T (the caller asked for frame gradients)
+    float E[9];
+    so3_rotvec_to_matrix(v3[0], v3[1], v3[2], E);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dOt[r * 3 + c] = (G0[r * 3 + 0] * E[c * 3 + 0] + G0[r * 3 + 1] * E[c * 3 + 1]) + G0[r * 3 + 2] * E[c * 3 + 2];
+  }
   // G = dL/dE = O_t^T G0
   float G[9];
 #pragma unroll
@@ -418,7 +426,8 @@ __global__ void losses_bwd_kernel(const float* __restrict__ post, const float* _
 // Null cotangent pointers stand for zeros.
 __global__ void heads_cotangent_kernel(const float* __restrict__ post, const float* __restrict__ c_post, const float* __restrict__ c_eps,
                                        const float* __restrict__ c_O0, const float* __restrict__ O_t, const float* __restrict__ v, int V,
-                                       int64_t rows, float* __restrict__ d_logits, float* __restrict__ d_eps, float* __restrict__ d_v) {
+                                       int64_t rows, float* __restrict__ d_logits, float* __restrict__ d_eps, float* __restrict__ d_v,
+                                       float* __restrict__ d_Ot) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= rows) return;
   float dot = 0.f;
@@ -429,12 +438,14 @@ __global__ void heads_cotangent_kernel(const float* __restrict__ post, const flo
   for (int c = 0; c < 3; ++c) d_eps[i * 3 + c] = c_eps ? c_eps[i * 3 + c] : 0.0f;
   if (c_O0 == nullptr) {
     d_v[i * 3] = d_v[i * 3 + 1] = d_v[i * 3 + 2] = 0.0f;
+    if (d_Ot)
+      for (int k = 0; k < 9; ++k) d_Ot[i * 9 + k] = 0.0f;
     return;
   }
   float G0[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) G0[k] = c_O0[i * 9 + k];
-  rotvec_head_bwd(G0, O_t + i * 9, v + i * 3, d_v + i * 3);
+  rotvec_head_bwd(G0, O_t + i * 9, v + i * 3, d_v + i * 3, d_Ot ? d_Ot + i * 9 : nullptr);  // d O_t is WRITTEN here, the layers add to it
 }
 
 // ------------------------------------------------------------------ attention backward in two atomic-free passes
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_rows_kernel(const float* __r
   __syncthreads();
   const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
   const float scale_p = -0.5f / sqrtf(4.5f * PQ);
-  const float scale_t = 1.0f / sqrtf(3.0f);
+  const float scale_t = 1.0f / sqrtf(C > 0 ? 3.0f : 2.0f);  // 3 independent logits with the pair bias, 2 without (C == 0)
   // ---- recompute logits
   typedef float v4 __attribute__((ext_vector_type(4)));
   const int lo = threadIdx.x & 7, oct = threadIdx.x >> 3, noct = blockDim.x >> 3;
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(512) void ipa_attn_bwd_rows_mr_kernel(const float* 
   __syncthreads();
   const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
   const float scale_p = -0.5f / sqrtf(4.5f * PQ);
-  const float scale_t = 1.0f / sqrtf(3.0f);
+  const float scale_t = 1.0f / sqrtf(C > 0 ? 3.0f : 2.0f);  // 3 independent logits with the pair bias, 2 without (C == 0)
   const int lo = tid & 7, oct = tid >> 3, noct = nthr >> 3;
   const float* e0 = e + row0 * K * C;  // + rr * K * C
   // sum over the 8 lanes of an octet of 8 per-lane values, lane `lo` ending with total number `lo` (reduce-scatter: 7 shuffles)
@@ -1267,6 +1278,71 @@ __global__ void ipa_dog_kernel(const float* __restrict__ feat, const float* __re
   for (int k = 0; k < 3; ++k) dogbuf[row * n_og + hp * 3 + k] = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
 }
 
+// Gradients with respect to the FRAME (R_i, t_i) of residue i through one IPA layer (reference: euclidean_transform /
+// inverse_euclidean_transform are plain differentiable torch code, diffab_pytorch.py:315-336, used at :410-413 and :453).  One
+// work-group per residue row.  Two contributions, both accumulated (+=) into dR[row][9], dt[row][3]:
+//  (a) local -> global of the q / k / v points, g = p R + t (:324): with dg = d loss / d g (dproj, BEFORE points_bwd_kernel rewrites it),
+//      d t += sum_points dg,  d R[k][c] += sum_points p[k] dg[c],  p = (g - t) R^T recomputed from the stored global points;
+//  (b) global -> local of the attention-weighted value points, o_l = (o_g - t) R^T (:336) and o_n = |o_l| (:454): with
+//      dl = d o_l + d o_n o_l / o_n,  d t -= dl R,  d R[c][k] += dl[c] (o_g - t)[k],  (o_g - t) = o_l R.
+// p and (o_g - t) are recovered through R^T = R^-1: the frames on this path are rotations (to fp32 rounding), as in every caller.
+__global__ __launch_bounds__(256) void ipa_frames_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ dproj, int NP, int pt_col0,
+                                                             int n_pts, const float* __restrict__ feat, const float* __restrict__ dfeat, int F,
+                                                             int ol_col0, int on_col0, int n_vpts, const float* __restrict__ R,
+                                                             const float* __restrict__ t, float* __restrict__ dR, float* __restrict__ dt) {
+  const int64_t row = blockIdx.x;
+  const float* Rr = R + row * 9;
+  const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
+  const float tx = t[row * 3], ty = t[row * 3 + 1], tz = t[row * 3 + 2];
+  float acc[12];  // dR row-major, then dt
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (int pt = threadIdx.x; pt < n_pts; pt += blockDim.x) {
+    const float* g = proj + row * NP + pt_col0 + pt * 3;
+    const float* dg = dproj + row * NP + pt_col0 + pt * 3;
+    const float gx = g[0] - tx, gy = g[1] - ty, gz = g[2] - tz;
+    const float p[3] = {gx * r0 + gy * r1 + gz * r2, gx * r3 + gy * r4 + gz * r5, gx * r6 + gy * r7 + gz * r8};  // (g - t) R^T
+    const float d[3] = {dg[0], dg[1], dg[2]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[k * 3 + c] += p[k] * d[c];
+    acc[9] += d[0]; acc[10] += d[1]; acc[11] += d[2];
+  }
+  for (int vp = threadIdx.x; vp < n_vpts; vp += blockDim.x) {
+    const float* ol = feat + row * F + ol_col0 + vp * 3;
+    const float* dol = dfeat + row * F + ol_col0 + vp * 3;
+    const float on = feat[row * F + on_col0 + vp], don = dfeat[row * F + on_col0 + vp];
+    float dl[3], og[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dl[c] = dol[c] + (on > 0.0f ? don * ol[c] / on : 0.0f);
+    og[0] = ol[0] * r0 + ol[1] * r3 + ol[2] * r6;  // (o_g - t) = o_l R
+    og[1] = ol[0] * r1 + ol[1] * r4 + ol[2] * r7;
+    og[2] = ol[0] * r2 + ol[1] * r5 + ol[2] * r8;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[c * 3 + k] += dl[c] * og[k];
+    acc[9] -= dl[0] * r0 + dl[1] * r3 + dl[2] * r6;  // d t -= dl R
+    acc[10] -= dl[0] * r1 + dl[1] * r4 + dl[2] * r7;
+    acc[11] -= dl[0] * r2 + dl[1] * r5 + dl[2] * r8;
+  }
+  __shared__ float red[4][12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    float v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const int k = threadIdx.x;
+    const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    if (k < 9) { if (dR) dR[row * 9 + k] += v; }
+    else if (dt) dt[row * 3 + (k - 9)] += v;
+  }
+}
+
 // gradient w.r.t. global points -> local points, in place: g = p R + t  =>  dp[k] = sum_c dg[c] R[k][c]
 __global__ void points_bwd_kernel(float* __restrict__ dproj, int ld, int col0, int n_pts, const float* __restrict__ R, int64_t rows) {
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -1367,7 +1443,9 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
                         const float* O0_hat, const float* post_hat, const float* true_post, const float* true_eps, const float* true_O0,
                         const uint8_t* gm, const uint8_t* rm, const float* upstream3, const float* cot_eps, const float* cot_O0,
                         const float* cot_post, const float* layer_dy, float* layer_dx, float* d_res_ctx, float* d_pair_ctx, float* ws,
-                        hipStream_t st) {
+                        hipStream_t st, float* d_x_t = nullptr, float* d_O_t = nullptr) {
+  // d_x_t (rows x 3) / d_O_t (rows x 9), nullable: gradients with respect to the frames (translations_t, orientations_t), which the
+  // reference's forward is differentiable in (:315-336, :594-596); the training step never asks for them
   const int rows = d->B * d->K, D = d->D, H = d->H, DS = d->DS, PQ = d->PQ, PV = d->PV, C = d->C, V = d->V;
   const int NP = 3 * H * DS + 2 * H * PQ * 3 + H * PV * 3;
   const int F = H * DS + H * C + H * PV * 3 + H * PV;
@@ -1408,11 +1486,13 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     DIFFAB_LAUNCH_CHECK();
   } else if (mode == BWD_COTANGENTS) {
     hipLaunchKernelGGL(heads_cotangent_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, cot_post, cot_eps, cot_O0, O_t, tp.vbuf, V,
-                       static_cast<int64_t>(rows), d_logits, d_eps, d_v);
+                       static_cast<int64_t>(rows), d_logits, d_eps, d_v, d_O_t);
     DIFFAB_LAUNCH_CHECK();
   } else {
     DIFFAB_HIP_CHECK(hipMemcpyAsync(dcur, layer_dy, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
   }
+  if (d_O_t && mode != BWD_COTANGENTS) DIFFAB_HIP_CHECK(hipMemsetAsync(d_O_t, 0, sizeof(float) * rows * 9, st));  // (the heads kernel wrote it above)
+  if (d_x_t) DIFFAB_HIP_CHECK(hipMemsetAsync(d_x_t, 0, sizeof(float) * rows * 3, st));
   // ---- heads (Linear-ReLU-Linear-ReLU-Linear), gradients into cat3 accumulate over the three heads
   const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
   const diffab_mlp3_weights* hg[3] = {&g->coord, &g->orient, &g->seq};
@@ -1506,7 +1586,8 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     }
     DIFFAB_LAUNCH_CHECK();
     // d w_bias[h][c] += sum_rows partial, d gamma[h] += sum_rows partial (one column sum over the [rows][H*C + H] partials)
-    if (int rc = colsum(wb_part, H * C + H, wb_rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
+    if (C > 0)  // (use_pair_bias = False: no pair bias, no d w_bias)
+      if (int rc = colsum(wb_part, H * C + H, wb_rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
     if (int rc = colsum(wb_part + H * C, H * C + H, wb_rows, H, const_cast<float*>(lg->gamma), st)) return rc;
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
     constexpr int JJm = 4;  // keys per work-group of the multi-key kernel
@@ -1524,6 +1605,11 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
                          DS, PQ, PV);
     }
     DIFFAB_LAUNCH_CHECK();
+    if (d_x_t || d_O_t) {  // frame gradients of this layer, from the GLOBAL point gradients (before points_bwd_kernel rewrites dproj)
+      hipLaunchKernelGGL(ipa_frames_bwd_kernel, dim3(rows), dim3(256), 0, st, proj, dproj, NP, 3 * H * DS, 2 * H * PQ + H * PV, feat, dfeat, F,
+                         H * DS + H * C, H * DS + H * C + H * PV * 3, H * PV, O_t, x_t, d_O_t, d_x_t);
+      DIFFAB_LAUNCH_CHECK();
+    }
     // global-point gradients -> local-point gradients (three point blocks)
     {  // the three point blocks (q, k, v) are adjacent columns of dproj: one launch over all of a row's points
       const int npts = 2 * H * PQ + H * PV;
@@ -1596,20 +1682,20 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
 int denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
                      const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* post_hat,
                      const float* cot_eps, const float* cot_O0, const float* cot_post, float* d_res_ctx, float* d_pair_ctx, float* ws,
-                     hipStream_t st) {
+                     hipStream_t st, float* d_x_t, float* d_O_t) {
   return run_backward(BWD_COTANGENTS, d, w, g, tp, seq_t, x_t, O_t, pair_ctx, nullptr, nullptr, post_hat, nullptr, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, cot_eps, cot_O0, cot_post, nullptr, nullptr, d_res_ctx, d_pair_ctx, ws, st);
+                      nullptr, nullptr, cot_eps, cot_O0, cot_post, nullptr, nullptr, d_res_ctx, d_pair_ctx, ws, st, d_x_t, d_O_t);
 }
 
 // One IPA layer backward: tp is the one-layer tape of the taped layer forward (x[0] = the layer input), dy -> dx, d pair_ctx += ..
 int ipa_layer_bwd(const diffab_dims* d1, const diffab_ipa_layer_weights* lw, const diffab_ipa_layer_weights* lg, const TrainTape& tp,
                   const float* R, const float* t, const float* pair_ctx, const float* dy, float* dx, float* d_pair_ctx, float* ws,
-                  hipStream_t st) {
+                  hipStream_t st, float* d_R, float* d_t) {
   diffab_denoiser_weights w{}, g{};
   w.layers = lw;
   g.layers = lg;
   return run_backward(BWD_LAYER, d1, &w, &g, tp, nullptr, t, R, pair_ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, nullptr, nullptr, nullptr, dy, dx, nullptr, d_pair_ctx, ws, st);
+                      nullptr, nullptr, nullptr, nullptr, nullptr, dy, dx, nullptr, d_pair_ctx, ws, st, d_t, d_R);
 }
 
 }  // namespace diffab

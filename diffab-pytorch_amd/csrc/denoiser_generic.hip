@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void ipa_attn_generic_kernel(const float* __re
   const float* erow = e + row_i * K * C;  // e[b, i, :, :]
   const float scale_s = 1.0f / sqrtf(static_cast<float>(DS));
   const float scale_p = -0.5f / sqrtf(4.5f * PQ);
-  const float scale_t = 1.0f / sqrtf(3.0f);
+  const float scale_t = 1.0f / sqrtf(C > 0 ? 3.0f : 2.0f);  // num_independent_logits^-1/2: 3 with the pair bias, 2 without (C == 0, :385-387)
   for (int idx = threadIdx.x; idx < H * K; idx += blockDim.x) {
     const int h = idx / K, j = idx % K;
     const float* krow = proj + (static_cast<int64_t>(b) * K + j) * NP;

@@ -116,10 +116,10 @@ int train_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const
 int denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* g, const TrainTape& tp,
                      const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* post_hat,
                      const float* cot_eps, const float* cot_O0, const float* cot_post, float* d_res_ctx, float* d_pair_ctx, float* ws,
-                     hipStream_t st);
+                     hipStream_t st, float* d_x_t = nullptr, float* d_O_t = nullptr);  // frame gradients (nullable)
 int ipa_layer_bwd(const diffab_dims* d1, const diffab_ipa_layer_weights* lw, const diffab_ipa_layer_weights* lg, const TrainTape& tp,
                   const float* R, const float* t, const float* pair_ctx, const float* dy, float* dx, float* d_pair_ctx, float* ws,
-                  hipStream_t st);
+                  hipStream_t st, float* d_R = nullptr, float* d_t = nullptr);  // frame gradients (nullable)
 // Y = act(X W^T + b) backward: dW += dY^T X (W is N x Kd, row-major), db += colsum dY (nullable), dX (+)= dY W (nullable).
 // dY must already carry the activation mask (bwd_relu_mask: dY *= act > 0, in place).  bwd_gemm_nn: C (+)= A[M,K] B[K,N].
 int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M, int N,

@@ -229,8 +229,14 @@ __global__ void igso3_sample_kernel(const float* __restrict__ sigmas, const floa
 // when the row has fewer than K bins of positive mass (the reference raises there).
 __global__ __launch_bounds__(1024) void igso3_race_kernel(const float* __restrict__ pdf, int n_bins, int n_pad,
                                                           const int64_t* __restrict__ sigma_idx, int K, const float* __restrict__ race,
-                                                          int32_t* __restrict__ bins) {
+                                                          int32_t* __restrict__ bins, const float* __restrict__ sigmas, float sigma_thr) {
   extern __shared__ float race_lds[];
+  // rows whose sigma is not below the threshold take the Gaussian angle (so3.py:122-125): their bins are never read - no sort (with
+  // the T = 100 schedule that is every row with t > 5: 95 % of a training batch); uniform exit, before any barrier
+  if (sigmas != nullptr && !(sigmas[sigma_idx[blockIdx.x]] < sigma_thr)) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) bins[static_cast<int64_t>(blockIdx.x) * K + k] = 0;
+    return;
+  }
   float* key = race_lds;                                    // [n_pad]
   int* idx = reinterpret_cast<int*>(race_lds + n_pad);      // [n_pad]
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -596,6 +602,59 @@ __global__ void frames_kernel(const float* __restrict__ x, const float* __restri
   }
 }
 
+// d R, d t of the two frame maps from the cotangent g of their output (the reference's einsums are differentiable in r and t,
+// diffab_pytorch.py:315-336); one work-group per (b, l), reduction over the heads and points that share the frame:
+//   apply  (out = x R + t):      d R[k][c] = sum x[k] g[c],        d t = sum g
+//   invert (out = (x - t) R^T):  d R[c][k] = sum g[c] (x - t)[k],  d t[k] = - sum_c g[c] R[c][k]
+template <bool INVERT>
+__global__ __launch_bounds__(256) void frames_bwd_kernel(const float* __restrict__ x, const float* __restrict__ R, const float* __restrict__ t,
+                                                         const float* __restrict__ g, int N, int L, int P, float* __restrict__ dR,
+                                                         float* __restrict__ dt) {
+  const int64_t bl = blockIdx.x;
+  const int64_t b = bl / L, l = bl % L;
+  const float* Rr = R + bl * 9;
+  const float tx = t[bl * 3], ty = t[bl * 3 + 1], tz = t[bl * 3 + 2];
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+  for (int idx = threadIdx.x; idx < N * P; idx += blockDim.x) {
+    const int n = idx / P, p = idx % P;
+    const int64_t i = ((b * N + n) * L + l) * P + p;
+    const float gx = g[i * 3], gy = g[i * 3 + 1], gz = g[i * 3 + 2];
+    const float gg[3] = {gx, gy, gz};
+    if (INVERT) {
+      const float d[3] = {x[i * 3] - tx, x[i * 3 + 1] - ty, x[i * 3 + 2] - tz};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[c * 3 + k] += gg[c] * d[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[9 + k] -= (gx * Rr[0 * 3 + k] + gy * Rr[1 * 3 + k]) + gz * Rr[2 * 3 + k];
+    } else {
+      const float xx[3] = {x[i * 3], x[i * 3 + 1], x[i * 3 + 2]};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[k * 3 + c] += xx[k] * gg[c];
+      acc[9] += gx; acc[10] += gy; acc[11] += gz;
+    }
+  }
+  __shared__ float red[4][12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    float v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const int k = threadIdx.x;
+    const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    if (k < 9) { if (dR) dR[bl * 9 + k] = v; }
+    else if (dt) dt[bl * 3 + (k - 9)] = v;
+  }
+}
+
 // AngularEncoding (diffab_pytorch.py:20-54): per input element x -> [x, sin(f_i x) (2 nf values), cos(f_i x) (2 nf values)],
 // f = [1, .., nf, 1/1, .., 1/nf] (the reference builds the band table in fp32: 1.0 / (i + 1.0) rounded once)
 __global__ void angular_encoding_kernel(const float* __restrict__ x, int64_t n, int nf, float* __restrict__ out) {
@@ -826,7 +885,7 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
 }
 
 int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, int32_t n_bins, const int64_t* sigma_idx, int32_t B, int32_t K,
-                                          const float* race, int32_t* bins, void* stream) {
+                                          const float* race, int32_t* bins, const float* sigmas, float sigma_threshold, void* stream) {
   StreamOrder order_(stream);
   DIFFAB_REQUIRE(n_sigmas > 0 && n_bins > 0 && n_bins <= 16384 && B >= 0 && K >= 0 && K <= n_bins, DIFFAB_ERR_ARG,
                  "igso3_bins_without_replacement: bad argument (n_bins <= 16384, K <= n_bins)");
@@ -836,7 +895,8 @@ int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, in
   while (n_pad < n_bins) n_pad <<= 1;
   const int lds = n_pad * 8;
   DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(igso3_race_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(igso3_race_kernel, dim3(B), dim3(1024), lds, as_stream(stream), pdf, n_bins, n_pad, sigma_idx, K, race, bins);
+  hipLaunchKernelGGL(igso3_race_kernel, dim3(B), dim3(1024), lds, as_stream(stream), pdf, n_bins, n_pad, sigma_idx, K, race, bins, sigmas,
+                     sigma_threshold);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -974,6 +1034,18 @@ int diffab_frames_apply(const float* x, const float* R, const float* t, float* o
   if (n == 0) return DIFFAB_OK;  // empty tensors carry null pointers
   DIFFAB_REQUIRE(x && R && out, DIFFAB_ERR_ARG, "frames_apply: null pointer");
   hipLaunchKernelGGL(frames_kernel<false>, dim3(blocks_for(n)), dim3(kThreads), 0, as_stream(stream), x, R, t, out, N, L, P, n);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+int diffab_frames_bwd(const float* x, const float* R, const float* t, const float* g_out, int32_t invert, float* dR, float* dt, int32_t B,
+                      int32_t N, int32_t L, int32_t P, void* stream) {
+  StreamOrder order_(stream);
+  DIFFAB_REQUIRE(B >= 0 && N >= 0 && L >= 0 && P >= 0, DIFFAB_ERR_ARG, "frames_bwd: negative extent");
+  if (static_cast<int64_t>(B) * L == 0) return DIFFAB_OK;
+  DIFFAB_REQUIRE(x && R && t && g_out, DIFFAB_ERR_ARG, "frames_bwd: null pointer");
+  if (invert) hipLaunchKernelGGL(frames_bwd_kernel<true>, dim3(B * L), dim3(256), 0, as_stream(stream), x, R, t, g_out, N, L, P, dR, dt);
+  else hipLaunchKernelGGL(frames_bwd_kernel<false>, dim3(B * L), dim3(256), 0, as_stream(stream), x, R, t, g_out, N, L, P, dR, dt);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

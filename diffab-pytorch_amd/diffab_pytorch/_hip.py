@@ -98,7 +98,7 @@ SYMBOLS = {
     "diffab_igso3_table_build_accurate": (C.c_int, [_fp, _i32, _i32, _i32, _fp, _fp]),
     "diffab_igso3_cdf_build": (C.c_int, [_fp, _i32, _i32, _fp, _fp]),
     "diffab_igso3_sample": (C.c_int, [_PI, _fp, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "diffab_igso3_bins_without_replacement": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
+    "diffab_igso3_bins_without_replacement": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp, C.c_float, _fp]),
     "diffab_igso3_sample_bins": (C.c_int, [_PI, _fp, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
     "diffab_weighted_multinomial": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i64, _fp, _fp]),
     "diffab_seq_forward_prob": (C.c_int, [_PS, C.c_int, _fp, _fp, _fp, _i32, _i32, _fp, _fp]),
@@ -135,15 +135,16 @@ SYMBOLS = {
     "diffab_orientation_loss_bwd": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp, _fp, _fp]),
     "diffab_frames_apply": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "diffab_frames_invert": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "diffab_frames_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "diffab_angular_encoding": (C.c_int, [_fp, _i64, _i32, _fp, _fp]),
     "diffab_angular_encoding_bwd": (C.c_int, [_fp, _fp, _i64, _i32, _fp, _fp]),
     "diffab_denoise_step_fwd_taped": (C.c_int, [_PD, C.POINTER(DenoiserWeights)] + [_fp] * 10 + [_sz, _u32, _fp]),
-    "diffab_denoise_step_bwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), C.POINTER(DenoiserWeights)] + [_fp] * 11 + [_sz, _fp, _sz, _fp]),
+    "diffab_denoise_step_bwd": (C.c_int, [_PD, C.POINTER(DenoiserWeights), C.POINTER(DenoiserWeights)] + [_fp] * 13 + [_sz, _fp, _sz, _fp]),
     "diffab_ipa_layer_tape_bytes": (_sz, [_PD]),
     "diffab_ipa_layer_bwd_workspace_bytes": (_sz, [_PD]),
     "diffab_ipa_layer_fwd_taped": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _sz, _u32, _fp]),
-    "diffab_ipa_layer_bwd": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz,
-                                       _fp, _sz, _fp]),
+    "diffab_ipa_layer_bwd": (C.c_int, [_PD, C.POINTER(IpaLayerWeights), C.POINTER(IpaLayerWeights), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                       _sz, _fp, _sz, _fp]),
     "diffab_reverse_update": (C.c_int, [_PS, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "diffab_sample_loop": (C.c_int, [_PD, C.POINTER(DenoiserWeights), _PS, _PI, _fp, _fp, _fp, _fp, _fp, _fp, _u64, _i64, _i32,
                                      _i32, _fp, _sz, _u32, _fp]),
@@ -237,8 +238,9 @@ def ipa_layer_weights(params: Dict[str, torch.Tensor], keep: list) -> IpaLayerWe
     """params: the layer's own named parameters (reference names, diffab_pytorch.py:354-379)."""
     order = ("gamma", "to_q_scalar.weight", "to_k_scalar.weight", "to_v_scalar.weight", "to_pair_bias.weight",
              "to_q_point.weight", "to_k_point.weight", "to_v_point.weight", "to_out.weight", "to_out.bias")
-    ts = [dev_f32(params[k]) for k in order]
-    keep.extend(ts)
+    # (a layer built with use_pair_bias=False has no to_pair_bias: NULL in the struct, C = 0 in its dims)
+    ts = [dev_f32(params[k]) if k in params else None for k in order]
+    keep.extend(t for t in ts if t is not None)
     return IpaLayerWeights(*[ptr(t) for t in ts])
 
 

@@ -55,12 +55,6 @@ def _wants_grad(module: Optional[nn.Module], *tensors) -> bool:
     return module is not None and any(p.requires_grad for p in module.parameters())
 
 
-def _no_frame_grads(who: str, *tensors) -> None:
-    if any(torch.is_tensor(t_) and t_.requires_grad for t_ in tensors):
-        raise NotImplementedError(f"{who}: gradients with respect to the frames (orientations / translations) are not implemented on the "
-                                  "HIP path (the reference's training step never needs them); detach them or use torch.no_grad()")
-
-
 class _AngularEncodingFn(torch.autograd.Function):
     """AngularEncoding on HIP; differentiable in x like the reference's plain torch code (diffab_angular_encoding_bwd)."""
 
@@ -103,8 +97,8 @@ class AngularEncoding(nn.Module):
 
 
 class _FramesFn(torch.autograd.Function):
-    """euclidean_transform / inverse_euclidean_transform on HIP; differentiable with respect to the points (the opposite rotation
-    of the cotangent, same kernel with t = NULL)."""
+    """euclidean_transform / inverse_euclidean_transform on HIP; differentiable in the points (the opposite rotation of the cotangent,
+    same kernel with t = NULL) and in the frames r, t (diffab_frames_bwd), as the reference's einsums are (:315-336)."""
 
     @staticmethod
     def forward(ctx, x, r, t, invert: bool):
@@ -114,31 +108,39 @@ class _FramesFn(torch.autograd.Function):
         out = torch.empty_like(xd)
         fn = lib.diffab_frames_invert if invert else lib.diffab_frames_apply
         _hip.check(fn(_hip.ptr(xd), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(out), B, N, L, P, _hip.stream_ptr()), "diffab_frames")
-        ctx.invert, ctx.shape, ctx.dev = invert, (B, N, L, P), x.device
-        ctx.save_for_backward(rd)
+        ctx.invert, ctx.shape, ctx.devs = invert, (B, N, L, P), (x.device, r.device, t.device)
+        ctx.save_for_backward(xd, rd, td)
         return out.to(x.device)
 
     @staticmethod
     def backward(ctx, g):
         lib = _hip.lib()
-        (rd,) = ctx.saved_tensors
+        xd, rd, td = ctx.saved_tensors
         gd = _hip.dev_f32(g)
         B, N, L, P = ctx.shape
-        dx = torch.empty_like(gd)
-        fn = lib.diffab_frames_apply if ctx.invert else lib.diffab_frames_invert  # d x = g R^T (apply) | g R (invert)
-        _hip.check(fn(_hip.ptr(gd), _hip.ptr(rd), None, _hip.ptr(dx), B, N, L, P, _hip.stream_ptr()), "diffab_frames (backward)")
-        return dx.to(ctx.dev), None, None, None
+        dx = dr = dt = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(gd)
+            fn = lib.diffab_frames_apply if ctx.invert else lib.diffab_frames_invert  # d x = g R^T (apply) | g R (invert)
+            _hip.check(fn(_hip.ptr(gd), _hip.ptr(rd), None, _hip.ptr(dx), B, N, L, P, _hip.stream_ptr()), "diffab_frames (backward)")
+            dx = dx.to(ctx.devs[0])
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dr = torch.empty_like(rd) if ctx.needs_input_grad[1] else None
+            dt = torch.empty_like(td) if ctx.needs_input_grad[2] else None
+            _hip.check(lib.diffab_frames_bwd(_hip.ptr(xd), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(gd), int(ctx.invert), _hip.ptr(dr), _hip.ptr(dt),
+                                             B, N, L, P, _hip.stream_ptr()), "diffab_frames_bwd")
+            dr = dr.to(ctx.devs[1]) if dr is not None else None
+            dt = dt.to(ctx.devs[2]) if dt is not None else None
+        return dx, dr, dt, None
 
 
 def euclidean_transform(x, r, t):
     """global = x R + t for points x (b, n heads, l, p, 3), r (b, l, 3, 3), t (b, l, 3) (reference diffab_pytorch.py:315-324)."""
-    _no_frame_grads("euclidean_transform", r, t)
     return _FramesFn.apply(x, r, t, False)
 
 
 def inverse_euclidean_transform(x, r, t):
     """local = (x - t) R^T (reference diffab_pytorch.py:327-336)."""
-    _no_frame_grads("inverse_euclidean_transform", r, t)
     return _FramesFn.apply(x, r, t, True)
 
 
@@ -162,7 +164,8 @@ class _IpaLayerFn(torch.autograd.Function):
                                                   _hip.ptr(tape), tape.numel(), flags, _hip.stream_ptr()), "diffab_ipa_layer_fwd_taped")
         ctx.layer, ctx.names, ctx.dims = layer, names, dims
         ctx.need_e = ctx.needs_input_grad[3]
-        ctx.devs = (x.device, e.device, [p.device for p in params])
+        ctx.need_frames = (ctx.needs_input_grad[4], ctx.needs_input_grad[5])  # d r, d t (reference :315-336 is differentiable in them)
+        ctx.devs = (x.device, e.device, [p.device for p in params], r.device, t.device)
         ctx.save_for_backward(ed, rd, td, tape, *params)
         return y.to(x.device)
 
@@ -179,12 +182,15 @@ class _IpaLayerFn(torch.autograd.Function):
         dyd = _hip.dev_f32(dy)
         dx = torch.empty_like(dyd)
         de = torch.zeros_like(ed) if ctx.need_e else None
+        dr = torch.empty_like(rd) if ctx.need_frames[0] else None
+        dt = torch.empty_like(td) if ctx.need_frames[1] else None
         ws = _hip.workspace(lib.diffab_ipa_layer_bwd_workspace_bytes(C.byref(dims)))
         _hip.check(lib.diffab_ipa_layer_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(ed), _hip.ptr(rd), _hip.ptr(td), _hip.ptr(dyd),
-                                            _hip.ptr(dx), _hip.ptr(de), _hip.ptr(tape), tape.numel(), _hip.ptr(ws), ws.numel(),
-                                            _hip.stream_ptr()), "diffab_ipa_layer_bwd")
-        x_dev, e_dev, p_devs = ctx.devs
-        return (None, None, dx.to(x_dev), de.to(e_dev) if ctx.need_e else None, None, None) + tuple(gr.to(dv) for gr, dv in zip(grads, p_devs))
+                                            _hip.ptr(dx), _hip.ptr(de), _hip.ptr(dr), _hip.ptr(dt), _hip.ptr(tape), tape.numel(), _hip.ptr(ws),
+                                            ws.numel(), _hip.stream_ptr()), "diffab_ipa_layer_bwd")
+        x_dev, e_dev, p_devs, r_dev, t_dev = ctx.devs
+        return (None, None, dx.to(x_dev), de.to(e_dev) if ctx.need_e else None, dr.to(r_dev) if dr is not None else None,
+                dt.to(t_dev) if dt is not None else None) + tuple(gr.to(dv) for gr, dv in zip(grads, p_devs))
 
 
 class InvariantPointAttentionLayer(nn.Module):
@@ -193,31 +199,31 @@ class InvariantPointAttentionLayer(nn.Module):
     def __init__(self, d_residue_emb, d_pair_emb, d_scalar_per_head=16, n_query_point_per_head=4, n_value_point_per_head=4, n_head=8,
                  use_pair_bias=True):
         super().__init__()
-        if not use_pair_bias:
-            raise NotImplementedError("use_pair_bias=False is not on the DiffAb path and has no HIP kernel")
         self.n_head = n_head
         self.use_pair_bias = use_pair_bias
-        self.dims = dict(D=d_residue_emb, C=d_pair_emb, H=n_head, DS=d_scalar_per_head, PQ=n_query_point_per_head,
+        # use_pair_bias=False (reference :348-385, not on the DiffAb path): no to_pair_bias, two independent logits, no pair block in
+        # to_out's input; on the HIP side that is C = 0 on the any-dims kernels (forward and backward), e is not read
+        self.dims = dict(D=d_residue_emb, C=d_pair_emb if use_pair_bias else 0, H=n_head, DS=d_scalar_per_head, PQ=n_query_point_per_head,
                          PV=n_value_point_per_head)
         d_scalar = d_scalar_per_head * n_head
         # creation order = the reference's, so a seeded construction draws identical initial weights
         self.to_q_scalar = nn.Linear(d_residue_emb, d_scalar, bias=False)
         self.to_k_scalar = nn.Linear(d_residue_emb, d_scalar, bias=False)
         self.to_v_scalar = nn.Linear(d_residue_emb, d_scalar, bias=False)
-        self.to_pair_bias = nn.Linear(d_pair_emb, n_head, bias=False)
+        if use_pair_bias:
+            self.to_pair_bias = nn.Linear(d_pair_emb, n_head, bias=False)
         self.to_q_point = nn.Linear(d_residue_emb, n_query_point_per_head * 3 * n_head, bias=False)
         self.to_k_point = nn.Linear(d_residue_emb, n_query_point_per_head * 3 * n_head, bias=False)
         self.to_v_point = nn.Linear(d_residue_emb, n_value_point_per_head * 3 * n_head, bias=False)
         self.gamma = nn.Parameter(torch.log(torch.exp(torch.ones(n_head)) - 1.0))
-        self.to_out = nn.Linear(d_scalar + d_pair_emb * n_head + n_value_point_per_head * 3 * n_head + n_value_point_per_head * n_head,
-                                d_residue_emb)
+        self.to_out = nn.Linear(d_scalar + (d_pair_emb * n_head if use_pair_bias else 0) + n_value_point_per_head * 3 * n_head +
+                                n_value_point_per_head * n_head, d_residue_emb)
 
     def forward(self, x, e, r, t, *, flags: int = 0):
         lib = _hip.lib()
         if x.shape[0] == 0 or x.shape[1] == 0:  # empty batch / empty patch: nothing to launch (the reference's einsums return empty too)
             return torch.zeros(x.shape, dtype=torch.float32, device=x.device)
         if _wants_grad(self, x, e, r, t):  # differentiable like the reference's forward (:389-465): taped HIP forward + HIP backward
-            _no_frame_grads("InvariantPointAttentionLayer", r, t)
             return _IpaLayerFn.apply(self, flags & ~_hip.FLAG_PAIR_PLANES, x, e, r, t, *[p for _, p in self.named_parameters()])
         xd, ed, rd, td = (_hip.dev_f32(a) for a in (x, e, r, t))
         B, K = xd.shape[:2]
@@ -297,7 +303,6 @@ class Denoiser(nn.Module):
         if not return_logits and _wants_grad(self, res_context_emb, pair_context_emb, translations_t, orientations_t):
             # differentiable like the reference's forward (:558-607): taped HIP forward + HIP backward from the outputs' cotangents
             # (return_logits=True is an inference-only diagnostic of this package: detached outputs)
-            _no_frame_grads("Denoiser", translations_t, orientations_t)
             eps, O0, post = _DenoiserFn.apply(self, flags & ~_hip.FLAG_PAIR_PLANES, seq_idx_t, translations_t, orientations_t, beta,
                                               res_context_emb, pair_context_emb, *[p for _, p in self.named_parameters()])
             return {"translations_eps": eps, "orientations_t0": O0, "seq_posterior": post}
@@ -347,7 +352,8 @@ class _DenoiserFn(torch.autograd.Function):
                                                      tape.numel(), flags, _hip.stream_ptr()), "diffab_denoise_step_fwd_taped")
         ctx.denoiser, ctx.names, ctx.dims = denoiser, names, dims
         ctx.need = (ctx.needs_input_grad[6], ctx.needs_input_grad[7])
-        ctx.devs = (res_ctx.device, pair_ctx.device, [p.device for p in params])
+        ctx.need_frames = (ctx.needs_input_grad[3], ctx.needs_input_grad[4])  # d translations_t, d orientations_t
+        ctx.devs = (res_ctx.device, pair_ctx.device, [p.device for p in params], x_t.device, O_t.device)
         ctx.save_for_backward(seq, x, O, pc, post, tape, *params)
         out_dev = x_t.device
         return eps.to(out_dev), O0.to(out_dev), post.to(out_dev)
@@ -365,13 +371,16 @@ class _DenoiserFn(torch.autograd.Function):
         ce, cO, cp = (None if t_ is None else _hip.dev_f32(t_) for t_ in (g_eps, g_O0, g_post))
         d_rc = torch.empty(B, K, dims.D, dtype=torch.float32, device=seq.device)
         d_pc = torch.zeros_like(pc) if ctx.need[1] else None
+        d_x = torch.empty_like(x) if ctx.need_frames[0] else None
+        d_O = torch.empty_like(O) if ctx.need_frames[1] else None
         ws = _hip.workspace(lib.diffab_train_workspace_bytes(C.byref(dims)))
         _hip.check(lib.diffab_denoise_step_bwd(C.byref(dims), C.byref(w.struct), C.byref(g.struct), _hip.ptr(seq), _hip.ptr(x), _hip.ptr(O),
                                                _hip.ptr(pc), _hip.ptr(post), _hip.ptr(ce), _hip.ptr(cO), _hip.ptr(cp), _hip.ptr(d_rc),
-                                               _hip.ptr(d_pc), _hip.ptr(tape), tape.numel(), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
-                   "diffab_denoise_step_bwd")
-        rc_dev, pc_dev, p_devs = ctx.devs
-        return (None,) * 6 + (d_rc.to(rc_dev) if ctx.need[0] else None, d_pc.to(pc_dev) if ctx.need[1] else None) + \
+                                               _hip.ptr(d_pc), _hip.ptr(d_x), _hip.ptr(d_O), _hip.ptr(tape), tape.numel(), _hip.ptr(ws), ws.numel(),
+                                               _hip.stream_ptr()), "diffab_denoise_step_bwd")
+        rc_dev, pc_dev, p_devs, x_dev, O_dev = ctx.devs
+        return (None, None, None, d_x.to(x_dev) if d_x is not None else None, d_O.to(O_dev) if d_O is not None else None, None,
+                d_rc.to(rc_dev) if ctx.need[0] else None, d_pc.to(pc_dev) if ctx.need[1] else None) + \
             tuple(gr.to(dv) for gr, dv in zip(grads, p_devs))
 
 
@@ -662,9 +671,10 @@ class DiffAb(_ModuleBase):
 
     def __init__(self, d_residue_emb, d_pair_emb, n_ipa_layers, d_scalar_per_head, n_query_point_per_head, n_value_point_per_head, n_head,
                  T=100, s=0.01, beta_max=0.999, n_atoms=15, aa_vocab_size=21, max_dist_to_consider=32, lr=1e-4, weight_decay=0.0,
-                 betas=(0.9, 0.999), *, igso3_without_replacement: bool = False):
-        """The reference's constructor (diffab_pytorch.py:629-660).  `igso3_without_replacement` (keyword-only, build-defined): the forward
-        orientation noise draws a patch's K histogram bins without replacement, as the reference's torch.multinomial does (so3.py:78)."""
+                 betas=(0.9, 0.999), *, igso3_without_replacement: bool = True):
+        """The reference's constructor (diffab_pytorch.py:629-660).  `igso3_without_replacement` (keyword-only, build-defined switch, default =
+        the reference's behaviour): the forward orientation noise draws a patch's K histogram bins without replacement, as
+        torch.multinomial does at so3.py:78; False selects independent inverse-CDF draws (what the build-defined reverse sampler uses)."""
         super().__init__()
         self.sched = cosine_variance_schedule(T=T, s=s, beta_max=beta_max)
         self.residue_context_embedding = ResidueEmbedding(n_atoms, d_residue_emb)
@@ -693,7 +703,8 @@ class DiffAb(_ModuleBase):
     def _reverse_so3(self) -> _so3.SO3:
         """IGSO3 table over sigma_t = sqrt(beta_t) for the reverse step (build-defined)."""
         if self._rev_so3 is None or self._rev_so3.histograms.device != _hip.device():
-            self._rev_so3 = _so3.SO3(self.sched["beta"].sqrt(), sigma_threshold=0.1, n_bins=8192, num_iters=1024)
+            # (the device sampler of the reverse loop draws by inverse CDF: one table lookup per residue inside reverse_update)
+            self._rev_so3 = _so3.SO3(self.sched["beta"].sqrt(), sigma_threshold=0.1, n_bins=8192, num_iters=1024, without_replacement=False)
         return self._rev_so3
 
     # ------------------------------------------------------------------ reference API

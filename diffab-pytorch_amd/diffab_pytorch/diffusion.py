@@ -154,10 +154,10 @@ class CoordinateDiffuser(_Diffuser):
 
 
 class OrientationDiffuser(_Diffuser):
-    def __init__(self, T: int, s: float = 0.01, beta_max: float = 0.999, *, igso3_without_replacement: bool = False):
+    def __init__(self, T: int, s: float = 0.01, beta_max: float = 0.999, *, igso3_without_replacement: bool = True):
         super().__init__(T, s, beta_max)
-        # IGSO3 table over sigma_t = sqrt(1 - abar_t)  (diffusion.py:254-260).  igso3_without_replacement: a patch's K histogram bins
-        # drawn as the reference's torch.multinomial draws them (so3.py:78; see so3.SO3)
+        # IGSO3 table over sigma_t = sqrt(1 - abar_t)  (diffusion.py:254-260).  igso3_without_replacement (default, the reference's
+        # behaviour): a patch's K histogram bins drawn as torch.multinomial draws them (so3.py:78; see so3.SO3); False = inverse CDF
         self.so3 = so3.SO3(
             sigmas_to_consider=self.sched["one_minus_alpha_bar_sqrt"],
             cache_prefix=".cache/so3_histograms",

@@ -12,11 +12,12 @@ Differences from the reference, all documented in DESIGN.md:
     table (fp32 terms, see SO3.__init__), with the float64 series as the opt-in ``accurate=True``;
   * random draws come from a Philox stream seeded from torch's default generator
     (``torch.manual_seed`` still makes calls reproducible) - or from explicit noise tensors;
-  * histogram bins are drawn by inverse CDF by default, i.e. WITH replacement across the residues of a patch; the reference's
-    torch.multinomial draws the K bins of one patch WITHOUT replacement (so3.py:78) - ``SO3(..., without_replacement=True)`` (or
-    ``sample_*(..., without_replacement=True)``) draws them that way, by the exponential race torch itself uses on a GPU
-    (``diffab_igso3_bins_without_replacement``).  The default stays the inverse CDF: per residue it follows the tabulated
-    density, which a draw without replacement does not when a row's mass sits in fewer than ~K bins (small sigma).
+  * histogram bins: like the reference's ``torch.multinomial(probs, num_samples)`` (so3.py:78, replacement=False by default) the K
+    bins of one patch are drawn WITHOUT replacement - by the exponential race torch itself uses on a GPU
+    (``diffab_igso3_bins_without_replacement``; only rows with sigma below the threshold are sorted, the others take the Gaussian
+    angle).  ``without_replacement=False`` (constructor or per call) selects the inverse CDF instead, i.e. independent draws per
+    residue, which follow the tabulated density also where a row's mass sits in fewer than ~K bins (small sigma: there the
+    reference's joint draw pushes most of a patch's angles into the tail) - the build-defined reverse sampler uses that form.
 """
 from __future__ import annotations
 
@@ -133,7 +134,7 @@ class SO3:
     """IGSO3 angle table + axis-angle sampler (so3.py:9-126)."""
 
     def __init__(self, sigmas_to_consider, cache_prefix=".cache/so3_histograms", sigma_threshold=0.1, n_bins=8192, num_iters=1024, *,
-                 accurate: bool = False, without_replacement: bool = False):
+                 accurate: bool = False, without_replacement: bool = True):
         """``accurate=False`` (what DiffAb uses): the reference's table - every series term with the reference's own fp32
         roundings, so its rectified rounding noise (~1e-4 of spurious tail mass on the small-sigma rows) is part of the table,
         as it is part of what the reference samples from.  ``accurate=True``: the series in float64, i.e. the exact density."""
@@ -171,10 +172,11 @@ class SO3:
         _hip.check(lib.diffab_philox_fill(seed, 0, n, s, 0, 3, 0, _hip.ptr(nz), _hip.stream_ptr()), "diffab_philox_fill")
         return ax[..., :3].contiguous(), un[..., 0].contiguous(), un[..., 1].contiguous(), nz[..., 2].contiguous()
 
-    def draw_bins_without_replacement(self, sigma_idx, num_samples, *, race=None, seed=None) -> torch.Tensor:
+    def draw_bins_without_replacement(self, sigma_idx, num_samples, *, race=None, seed=None, threshold=None) -> torch.Tensor:
         """(n, num_samples) int32 histogram bins of rows sigma_idx, each row's draws WITHOUT replacement, in draw order - the joint
         distribution of `torch.multinomial(self.histograms[sigma_idx], num_samples)` (so3.py:78).  `race` (n, n_bins): Exp(1) draws
-        (default: -log of Philox uniforms)."""
+        (default: -log of Philox uniforms).  ``threshold``: rows with sigma >= threshold are not sorted (their bins come back 0: the
+        sampler takes the Gaussian angle there); None sorts every row."""
         lib = _hip.lib()
         idx = _hip.dev_i64(torch.as_tensor(sigma_idx))
         n, s = int(idx.numel()), int(num_samples)
@@ -182,11 +184,13 @@ class SO3:
             seed = _draw_seed() if seed is None else seed
             u = torch.empty(n, (self.n_bins + 3) // 4, 4, dtype=torch.float32, device=_hip.device())
             _hip.check(lib.diffab_philox_fill(seed, 0, n, u.shape[1], 0, 5, 1, _hip.ptr(u), _hip.stream_ptr()), "diffab_philox_fill")  # stream 5: the race
-            race = -torch.log(u.view(n, -1)[:, :self.n_bins].clamp_min(1e-38)).contiguous()
+            race = -torch.log(u.view(n, u.shape[1] * 4)[:, :self.n_bins].clamp_min(1e-38)).contiguous()  # (n may be 0: no view(n, -1))
         race = _hip.dev_f32(race)
         bins = torch.empty(n, s, dtype=torch.int32, device=idx.device)
         _hip.check(lib.diffab_igso3_bins_without_replacement(_hip.ptr(self.histograms), int(self._sigmas.numel()), self.n_bins, _hip.ptr(idx), n,
-                                                             s, _hip.ptr(race), _hip.ptr(bins), _hip.stream_ptr()),
+                                                             s, _hip.ptr(race), _hip.ptr(bins),
+                                                             _hip.ptr(self._sigmas) if threshold is not None else None,
+                                                             C.c_float(float(threshold) if threshold is not None else 0.0), _hip.stream_ptr()),
                    "diffab_igso3_bins_without_replacement")
         return bins
 
@@ -202,7 +206,8 @@ class SO3:
                 axis_raw = a0 if axis_raw is None else axis_raw
                 u_in = c0 if u_in is None else u_in
                 z = d0 if z is None else z
-            bins = self.draw_bins_without_replacement(idx, s, race=race, seed=seed)
+            thr = self.sigma_threshold if threshold is None else threshold
+            bins = self.draw_bins_without_replacement(idx, s, race=race, seed=seed, threshold=None if thr == float("inf") else thr)
             axis_raw, u_in, z = (_hip.dev_f32(t) for t in (axis_raw, u_in, z))
             out = torch.empty(n, s, 3, dtype=torch.float32, device=idx.device)
             tab = self.struct(threshold)

@@ -197,9 +197,13 @@ int diffab_igso3_sample(const diffab_igso3* tab, const int64_t* sigma_idx, int32
 
 /* so3.py:78  `torch.multinomial(probs, num_samples)` draws the K bins of a patch WITHOUT replacement.  bins (B,K) int32 = the K
  * bins of histogram row sigma_idx[b] with the largest pdf[bin] / race[b][bin], largest first, ties by lower bin: with race (B, n_bins)
- * ~ Exp(1) this is a draw without replacement in draw order (the exponential race torch itself uses on a GPU).  n_bins <= 16384. */
+ * ~ Exp(1) this is a draw without replacement in draw order (the exponential race torch itself uses on a GPU).  n_bins <= 16384.
+ * sigmas (n_sigmas, nullable) + sigma_threshold: rows with sigma >= threshold use the Gaussian angle and never read their bins
+ * (so3.py:122-125) - they are skipped (bins 0) instead of sorted; NULL sorts every row.  Cost of a sorted row: one 1024-thread
+ * work-group, a bitonic network over the 8192 keys in LDS. */
 int diffab_igso3_bins_without_replacement(const float* pdf, int32_t n_sigmas, int32_t n_bins, const int64_t* sigma_idx, int32_t B,
-                                          int32_t K, const float* race, int32_t* bins, void* stream);
+                                          int32_t K, const float* race, int32_t* bins, const float* sigmas, float sigma_threshold,
+                                          void* stream);
 /* diffab_igso3_sample with the histogram bins given (bins (B,K) from diffab_igso3_bins_without_replacement) instead of u_bin */
 int diffab_igso3_sample_bins(const diffab_igso3* tab, const int64_t* sigma_idx, int32_t B, int32_t K, const float* axis_raw,
                              const int32_t* bins, const float* u_in, const float* z, float* rotvec, void* stream);
@@ -283,6 +287,10 @@ int diffab_orientation_loss_bwd(const float* pred, const float* target, int64_t 
  * NULL (rotation only: the x-gradient of the opposite direction). */
 int diffab_frames_apply(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream);
 int diffab_frames_invert(const float* x, const float* R, const float* t, float* out, int32_t B, int32_t N, int32_t L, int32_t P, void* stream);
+/* d R (B, L, 3, 3) and d t (B, L, 3) of the same two maps from the cotangent g_out of their output (each nullable; written, not accumulated):
+ * invert = 0: euclidean_transform, 1: inverse_euclidean_transform.  The x-gradient is the other map with t = NULL. */
+int diffab_frames_bwd(const float* x, const float* R, const float* t, const float* g_out, int32_t invert, float* dR, float* dt, int32_t B,
+                      int32_t N, int32_t L, int32_t P, void* stream);
 /* diffab_pytorch.py:20-54 AngularEncoding.forward: n input values -> n x (4 num_funcs + 1) outputs [x, sin(f x), cos(f x)],
  * f = [1 .. num_funcs, 1/1 .. 1/num_funcs] */
 int diffab_angular_encoding(const float* x, int64_t n, int32_t num_funcs, float* out, void* stream);
@@ -294,22 +302,26 @@ int diffab_angular_encoding_bwd(const float* enc, const float* g_out, int64_t n,
  * Taped forwards (same outputs as diffab_denoise_step_fwd / diffab_ipa_layer_fwd, activations kept in `tape`) and backwards from
  * ARBITRARY cotangents.  Gradient buffers in `grads` and d_pair_ctx / d_e must be zero-filled by the caller (they are accumulated
  * into); NULL cotangents mean zero.  Tape: diffab_train_tape_bytes(d) / diffab_ipa_layer_tape_bytes(d); workspace:
- * diffab_train_workspace_bytes(d) / diffab_ipa_layer_bwd_workspace_bytes(d).  Gradients with respect to x_t / O_t (R / t) are
- * not produced (the training path never needs them). */
+ * diffab_train_workspace_bytes(d) / diffab_ipa_layer_bwd_workspace_bytes(d).  d_x_t (B,K,3) / d_O_t (B,K,3,3) and d_R / d_t: the
+ * gradients with respect to the frames (reference: euclidean_transform / inverse_euclidean_transform :315-336 and O_t @ exp(v) :594-596
+ * are differentiable in them), WRITTEN by the call, each nullable (the training step never needs them).  They are the gradients of
+ * the formulas with R^T = R^-1, i.e. for rotation frames, as on the whole path.  DIFFAB_FLAG_FORCE_GENERIC is ignored by the taped
+ * forwards (their backward reads the tape the MFMA path writes). */
 int diffab_denoise_step_fwd_taped(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t,
                                   const float* O_t, const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps,
                                   float* out_O0, float* out_posterior, void* tape, size_t tape_bytes, uint32_t flags, void* stream);
 int diffab_denoise_step_bwd(const diffab_dims* d, const diffab_denoiser_weights* w, const diffab_denoiser_weights* grads,
                             const int64_t* seq_t, const float* x_t, const float* O_t, const float* pair_ctx, const float* out_posterior,
                             const float* d_eps, const float* d_O0, const float* d_posterior, float* d_res_ctx, float* d_pair_ctx,
-                            const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                            float* d_x_t, float* d_O_t, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                            void* stream);
 size_t diffab_ipa_layer_tape_bytes(const diffab_dims* d);
 size_t diffab_ipa_layer_bwd_workspace_bytes(const diffab_dims* d);
 int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                                const float* t, float* y, void* tape, size_t tape_bytes, uint32_t flags, void* stream);
 int diffab_ipa_layer_bwd(const diffab_dims* d, const diffab_ipa_layer_weights* w, const diffab_ipa_layer_weights* grads, const float* e,
-                         const float* R, const float* t, const float* dy, float* dx, float* d_e, const void* tape, size_t tape_bytes,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         const float* R, const float* t, const float* dy, float* dx, float* d_e, float* d_R, float* d_t, const void* tape,
+                         size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- encode_context (reference diffab_pytorch.py:57-312, 680-724) -----------------------------------------
  * Runs once per sample.  atom_mask is float32 (B,K,A) (1 = atom present); context masks are 1 byte per residue, NULL = "not

@@ -297,14 +297,15 @@ def to_local(p, R, t):
     return torch.einsum("bhlpk,blck->bhlpc", p - t[:, None, :, None, :], R)
 
 
-def ipa_layer(x, e, R, t, sd, prefix, H, return_attn=False):
+def ipa_layer(x, e, R, t, sd, prefix, H, return_attn=False, use_pair_bias=True):
     """One InvariantPointAttentionLayer.forward (diffab_pytorch.py:389-465):
-    no LayerNorm / residual / transition, raw gamma (no softplus), unmasked."""
+    no LayerNorm / residual / transition, raw gamma (no softplus), unmasked.
+    use_pair_bias=False (:348-385): no to_pair_bias, two independent logits (scale 2^-1/2), no pair block in to_out's input."""
     g = lambda name: sd[prefix + name].to(x.dtype)
     B, K, D = x.shape
     Wqs, Wks, Wvs = g("to_q_scalar.weight"), g("to_k_scalar.weight"), g("to_v_scalar.weight")
     Wqp, Wkp, Wvp = g("to_q_point.weight"), g("to_k_point.weight"), g("to_v_point.weight")
-    Wb, gamma = g("to_pair_bias.weight"), g("gamma")
+    Wb, gamma = (g("to_pair_bias.weight") if use_pair_bias else None), g("gamma")
     Wo, bo = g("to_out.weight"), g("to_out.bias")
     ds = Wqs.shape[0] // H
     Pq = Wqp.shape[0] // (3 * H)
@@ -323,10 +324,11 @@ def ipa_layer(x, e, R, t, sd, prefix, H, return_attn=False):
     vp = to_global(points(x @ Wvp.T, Pv), R, t)
 
     logit_s = torch.einsum("bhid,bhjd->bhij", qs, ks) * ds**-0.5  # :416-419
-    bias = (e @ Wb.T).permute(0, 3, 1, 2)  # :423
+    bias = (e @ Wb.T).permute(0, 3, 1, 2) if use_pair_bias else 0.0  # :423
     diff = qp[:, :, :, None] - kp[:, :, None, :]  # (b,h,i,j,p,3)   :426-428
     logit_p = -0.5 * (4.5 * Pq) ** -0.5 * gamma.view(1, H, 1, 1) * (diff**2).sum(-1).sum(-1)  # :431-436
-    attn = ((3**-0.5) * (logit_s + bias + logit_p)).softmax(dim=-1)  # :439,443
+    n_logits = 3 if use_pair_bias else 2  # :385
+    attn = ((n_logits**-0.5) * ((logit_s + bias + logit_p) if use_pair_bias else (logit_s + logit_p))).softmax(dim=-1)  # :439-443
 
     o_s = torch.einsum("bhij,bhjd->bhid", attn, vs).permute(0, 2, 1, 3).reshape(B, K, H * ds)  # :445-446
     o_e = torch.einsum("bhij,bijc->bhic", attn, e).permute(0, 2, 1, 3).reshape(B, K, -1)  # :449-450
@@ -335,7 +337,7 @@ def ipa_layer(x, e, R, t, sd, prefix, H, return_attn=False):
     o_n = o_l.norm(dim=-1)  # :454
     o_l = o_l.permute(0, 2, 1, 3, 4).reshape(B, K, H * Pv * 3)  # "(h p c)"
     o_n = o_n.permute(0, 2, 1, 3).reshape(B, K, H * Pv)  # "(h p)"
-    feat = torch.cat([o_s, o_e, o_l, o_n], dim=-1)  # :460
+    feat = torch.cat([o_s, o_e, o_l, o_n] if use_pair_bias else [o_s, o_l, o_n], dim=-1)  # :460
     out = feat @ Wo.T + bo  # :464
     if return_attn:
         return out, attn, feat

@@ -449,6 +449,17 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "encode_context_grads.npz"), **gg)
 
     # ---------------------------------------------------------------- frames, AngularEncoding (module-level functions of the hot path)
+    def subsample(name, gr, store, full):
+        flat = gr.detach().reshape(-1)
+        if full or flat.numel() <= 4096:
+            store["grad/" + name] = npf(gr)
+            return
+        n = flat.numel()
+        stride = max(1, n // 512)
+        off = (7 * len(name)) % stride
+        store["sub/" + name] = npf(flat[off::stride][:512])
+        store["info/" + name] = np.array([n, stride, off, float(flat.double().norm()), float(flat.abs().max())])
+
     print("euclidean_transform / inverse_euclidean_transform / AngularEncoding")
     gf = torch.Generator().manual_seed(51)
     xpts = 5.0 * torch.randn(2, 3, 5, 4, 3, generator=gf)
@@ -469,23 +480,44 @@ def main():
     g_fwd = xg.grad.clone()
     xg.grad = None
     (rmod.inverse_euclidean_transform(xg, Rf, tf) * cg).sum().backward()
+    # ... and with respect to the frames (the einsums are differentiable in r and t as well)
+    fr = {}
+    for key, fn in (("fwd", rmod.euclidean_transform), ("inv", rmod.inverse_euclidean_transform)):
+        Rg, tg = Rf.clone().requires_grad_(True), tf.clone().requires_grad_(True)
+        (fn(xpts, Rg, tg) * cg).sum().backward()
+        fr[f"grad_{key}_R"], fr[f"grad_{key}_t"] = npf(Rg.grad), npf(tg.grad)
     np.savez_compressed(os.path.join(GOLD, "frames.npz"), x=npf(xpts), R=npf(Rf), t=npf(tf), fwd=npf(fwd), inv=npf(inv), xa=npf(xa), enc=npf(enc),
-                        cot=npf(cg), grad_fwd=npf(g_fwd), grad_inv=npf(xg.grad))
+                        cot=npf(cg), grad_fwd=npf(g_fwd), grad_inv=npf(xg.grad), **fr)
+
+    print("InvariantPointAttentionLayer(use_pair_bias=False): forward + autograd (reference :348-385, :422-459)")
+    for tag, dims, B, K, seed, sigma in (("unit", dict(syn.UNIT_DIMS), 2, 16, 81, 4.0), ("bench", dict(syn.BENCH_DIMS), 1, 64, 82, 6.0)):
+        torch.manual_seed(seed)
+        lay = rmod.InvariantPointAttentionLayer(dims["D"], dims["C"], dims["DS"], dims["PQ"], dims["PV"], dims["H"], use_pair_bias=False)
+        with torch.no_grad():
+            lay.gamma.copy_(torch.rand(dims["H"]) + 0.2)
+        assert not hasattr(lay, "to_pair_bias")
+        inp = syn.patches(B, K, dims, seed=seed, coord_sigma=sigma)
+        xl = inp["res_context_emb"].clone().requires_grad_(True)
+        Rl = inp["orientations"].clone().requires_grad_(True)
+        tl = inp["translations"].clone().requires_grad_(True)
+        yl = lay(xl, inp["pair_context_emb"], Rl, tl)
+        sd_l = {k: v.detach().clone() for k, v in lay.state_dict().items()}
+        check(f"ipa_layer no pair bias ({tag})", orc.ipa_layer(xl.detach(), inp["pair_context_emb"], Rl.detach(), tl.detach(), sd_l, "", dims["H"],
+                                                            use_pair_bias=False), yl.detach(), 2e-6)
+        c_y = torch.randn(B, K, dims["D"], generator=torch.Generator().manual_seed(seed))
+        (yl * c_y).sum().backward()
+        gl = dict(meta=np.array([B, K, seed, dims["D"], dims["C"], dims["DS"], dims["H"], dims["PQ"], dims["PV"]]), coord_sigma=np.array(sigma),
+                  y=npf(yl), c_y=npf(c_y))  # weights: torch.manual_seed(seed) construction + the gamma draw, as above
+        subsample("x", xl.grad, gl, tag == "unit")
+        subsample("R", Rl.grad, gl, True)
+        subsample("t", tl.grad, gl, True)
+        for n_, p_ in lay.named_parameters():
+            subsample(n_, p_.grad, gl, tag == "unit")
+        np.savez_compressed(os.path.join(GOLD, f"ipa_layer_no_pair_bias_{tag}.npz"), **gl)
 
     # ---------------------------------------------------------------- autograd through the module forwards from arbitrary cotangents
     # (Denoiser.forward :558-607, InvariantPointAttentionLayer.forward :389-465, OrientationLoss :610-625 are differentiable upstream;
     # a caller with a loss of their own on model.denoise() needs these gradients)
-    def subsample(name, gr, store, full):
-        flat = gr.detach().reshape(-1)
-        if full or flat.numel() <= 4096:
-            store["grad/" + name] = npf(gr)
-            return
-        n = flat.numel()
-        stride = max(1, n // 512)
-        off = (7 * len(name)) % stride
-        store["sub/" + name] = npf(flat[off::stride][:512])
-        store["info/" + name] = np.array([n, stride, off, float(flat.double().norm()), float(flat.abs().max())])
-
     for tag, dims, B, K, seed, sigma in (("unit", dict(syn.UNIT_DIMS, NL=2), 2, 16, 61, 4.0), ("bench", dict(syn.BENCH_DIMS, NL=2), 1, 128, 62, 6.0)):
         print(f"module autograd from cotangents ({tag} dims, reference autograd)")
         full = tag == "unit"
@@ -500,13 +532,18 @@ def main():
         c_post = torch.randn(B, K, 21, generator=gc)
         res_ctx = inp["res_context_emb"].clone().requires_grad_(True)
         pair_ctx = inp["pair_context_emb"].clone().requires_grad_(True)
-        out = den(inp["seq_idx"], inp["translations"], inp["orientations"], res_ctx, pair_ctx, beta, None, None)
+        # the frames are differentiable inputs of the reference's forward too (euclidean_transform :315-336, O_t @ exp(v) :594-596)
+        x_t = inp["translations"].clone().requires_grad_(True)
+        O_t = inp["orientations"].clone().requires_grad_(True)
+        out = den(inp["seq_idx"], x_t, O_t, res_ctx, pair_ctx, beta, None, None)
         ((out["translations_eps"] * c_eps).sum() + (out["orientations_t0"] * c_O0).sum() + (out["seq_posterior"] * c_post).sum()).backward()
         g = dict(meta=np.array([B, K, seed, dims["D"], dims["C"], dims["NL"], dims["DS"], dims["H"], dims["PQ"], dims["PV"]]),
                  coord_sigma=np.array(sigma), beta=npf(beta), c_eps=npf(c_eps), c_O0=npf(c_O0), c_post=npf(c_post),
                  out_eps=npf(out["translations_eps"]), out_post=npf(out["seq_posterior"]))
         subsample("res_ctx", res_ctx.grad, g, full)
         subsample("pair_ctx", pair_ctx.grad, g, full)
+        subsample("x_t", x_t.grad, g, True)
+        subsample("O_t", O_t.grad, g, True)
         for n_, p_ in den.named_parameters():
             subsample(n_, p_.grad, g, full)
         # one IPA layer alone: d y random -> d x, d e, parameter gradients
@@ -516,12 +553,16 @@ def main():
         xl = inp["res_context_emb"].clone().requires_grad_(True)
         el = inp["pair_context_emb"].clone().requires_grad_(True)
         c_y = torch.randn(B, K, dims["D"], generator=gc)
-        yl = layer(xl, el, inp["orientations"], inp["translations"])
+        Rl = inp["orientations"].clone().requires_grad_(True)
+        tl = inp["translations"].clone().requires_grad_(True)
+        yl = layer(xl, el, Rl, tl)
         (yl * c_y).sum().backward()
         g["layer/c_y"] = npf(c_y)
         g["layer/y"] = npf(yl)
         subsample("layer/x", xl.grad, g, full)
         subsample("layer/e", el.grad, g, full)
+        subsample("layer/R", Rl.grad, g, True)
+        subsample("layer/t", tl.grad, g, True)
         for n_, p_ in layer.named_parameters():
             subsample("layer/" + n_, p_.grad, g, full)
         np.savez_compressed(os.path.join(GOLD, f"module_autograd_{tag}.npz"), **g)

@@ -87,7 +87,8 @@ def test_diffab_constructor_surface(monkeypatch):
 
     sig = inspect.signature(DiffAb.__init__)
     extra = [n for n, q in sig.parameters.items() if q.kind is inspect.Parameter.KEYWORD_ONLY]
-    assert extra == ["igso3_without_replacement"] and sig.parameters["igso3_without_replacement"].default is False  # build-defined, opt-in
+    # build-defined keyword; its default is the reference's behaviour (torch.multinomial without replacement, so3.py:78)
+    assert extra == ["igso3_without_replacement"] and sig.parameters["igso3_without_replacement"].default is True
     assert [n for n in list(sig.parameters)[1:] if n not in extra] == ["d_residue_emb", "d_pair_emb", "n_ipa_layers", "d_scalar_per_head", "n_query_point_per_head",
                                         "n_value_point_per_head", "n_head", "T", "s", "beta_max", "n_atoms", "aa_vocab_size",
                                         "max_dist_to_consider", "lr", "weight_decay", "betas"]

@@ -58,8 +58,11 @@ def test_frames_and_angular_encoding_vs_reference_goldens(hip, golden):
         xg = x.clone().requires_grad_(True)
         (fn(xg, R, t) * T(g["cot"]).cuda()).sum().backward()
         assert maxrel(xg.grad, g[key]) < 1e-6, key
-    with pytest.raises(NotImplementedError):
-        euclidean_transform(x, R.clone().requires_grad_(True), t)
+    # ... and with respect to the frames (reference: the einsums of :324 / :336 are differentiable in r and t)
+    for fn, key in ((euclidean_transform, "fwd"), (inverse_euclidean_transform, "inv")):
+        Rg, tg = R.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        (fn(x, Rg, tg) * T(g["cot"]).cuda()).sum().backward()
+        assert maxrel(Rg.grad, g[f"grad_{key}_R"]) < 2e-6 and maxrel(tg.grad, g[f"grad_{key}_t"]) < 2e-6, key
     # reference tests/test_modules.py:16-26
     enc = AngularEncoding(num_funcs=3)
     assert enc.get_output_dimension(3) == 3 * (3 * 2 * 2 + 1)
@@ -110,7 +113,9 @@ def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
     inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=seed, coord_sigma=float(g["coord_sigma"])).items()}
     rc = inp["res_context_emb"].clone().requires_grad_(True)
     pc = inp["pair_context_emb"].clone().requires_grad_(True)
-    out = den(inp["seq_idx"], inp["translations"], inp["orientations"], rc, pc, T(g["beta"]).cuda(), None, None)
+    x_t = inp["translations"].clone().requires_grad_(True)  # the frames are differentiable inputs as well (:315-336, :594-596)
+    O_t = inp["orientations"].clone().requires_grad_(True)
+    out = den(inp["seq_idx"], x_t, O_t, rc, pc, T(g["beta"]).cuda(), None, None)
     for k in ("translations_eps", "orientations_t0", "seq_posterior"):
         assert out[k].grad_fn is not None, k  # a caller's own loss on these reaches the parameters
     assert maxrel(out["translations_eps"], g["out_eps"]) < 1e-4 and maxrel(out["seq_posterior"], g["out_post"]) < 1e-4
@@ -119,6 +124,8 @@ def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
     loss.backward()
     check_grad("res_ctx", rc.grad, g)
     check_grad("pair_ctx", pc.grad, g)
+    check_grad("x_t", x_t.grad, g)
+    check_grad("O_t", O_t.grad, g)
     for n_, p_ in den.named_parameters():
         assert p_.grad is not None, n_
         check_grad(n_, p_.grad, g)
@@ -128,18 +135,19 @@ def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
     out["translations_eps"].square().sum().backward()
     assert den.coordinate_denoising[4].weight.grad.abs().max() > 0
     assert float(den.sequence_denoising[4].weight.grad.abs().max()) == 0.0
-    with pytest.raises(NotImplementedError):
-        den(inp["seq_idx"], inp["translations"].clone().requires_grad_(True), inp["orientations"], rc, pc, T(g["beta"]).cuda())
     # ---- one IPA layer: d y -> d x, d e, parameter gradients
     layer = den.ipa.layers[0]
     layer.zero_grad(set_to_none=True)
     x = inp["res_context_emb"].clone().requires_grad_(True)
     e = inp["pair_context_emb"].clone().requires_grad_(True)
-    y = layer(x, e, inp["orientations"], inp["translations"])
+    Rl, tl = inp["orientations"].clone().requires_grad_(True), inp["translations"].clone().requires_grad_(True)
+    y = layer(x, e, Rl, tl)
     assert y.grad_fn is not None and maxrel(y, g["layer/y"]) < 1e-4
     (y * T(g["layer/c_y"]).cuda()).sum().backward()
     check_grad("layer/x", x.grad, g)
     check_grad("layer/e", e.grad, g)
+    check_grad("layer/R", Rl.grad, g)
+    check_grad("layer/t", tl.grad, g)
     for n_, p_ in layer.named_parameters():
         check_grad("layer/" + n_, p_.grad, g)
     # DIFFAB_FLAG_FORCE_GENERIC under autograd: the taped forwards ignore it (their backward reads the tape the MFMA path
@@ -157,6 +165,37 @@ def test_denoiser_and_ipa_layer_autograd_vs_reference_goldens(hip, golden, tag):
     with torch.no_grad():
         y0 = layer(x, e, inp["orientations"], inp["translations"])
     assert y0.grad_fn is None and maxrel(y0, g["layer/y"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["unit", "bench"])
+def test_ipa_layer_without_pair_bias_vs_reference_goldens(hip, golden, tag):
+    """InvariantPointAttentionLayer(use_pair_bias=False) (reference :348-385, :422-459: two independent logits, no pair terms in to_out):
+    forward and every gradient (x, the frames, the nine parameters) against the real reference's autograd.  Weights: the same seeded
+    construction as the generator (creation order of the reference, then the gamma draw)."""
+    from diffab_pytorch.diffab_pytorch import InvariantPointAttentionLayer
+
+    g = golden("ipa_layer_no_pair_bias_" + tag)
+    B, K, seed, D, C, DS, H, PQ, PV = [int(v) for v in g["meta"]]
+    dims = dict(D=D, C=C, NL=1, DS=DS, H=H, PQ=PQ, PV=PV, V=21)
+    torch.manual_seed(seed)
+    layer = InvariantPointAttentionLayer(D, C, DS, PQ, PV, H, use_pair_bias=False)
+    with torch.no_grad():
+        layer.gamma.copy_(torch.rand(H) + 0.2)
+    assert not hasattr(layer, "to_pair_bias") and layer.to_out.in_features == H * DS + H * PV * 3 + H * PV
+    layer = layer.cuda()
+    inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=seed, coord_sigma=float(g["coord_sigma"])).items()}
+    with torch.no_grad():
+        assert maxrel(layer(inp["res_context_emb"], inp["pair_context_emb"], inp["orientations"], inp["translations"]), g["y"]) < 1e-4
+    x = inp["res_context_emb"].clone().requires_grad_(True)
+    Rl, tl = inp["orientations"].clone().requires_grad_(True), inp["translations"].clone().requires_grad_(True)
+    y = layer(x, inp["pair_context_emb"], Rl, tl)
+    assert maxrel(y, g["y"]) < 1e-4
+    (y * T(g["c_y"]).cuda()).sum().backward()
+    check_grad("x", x.grad, g)
+    check_grad("R", Rl.grad, g)
+    check_grad("t", tl.grad, g)
+    for n_, p_ in layer.named_parameters():
+        check_grad(n_, p_.grad, g)
 
 
 def test_backbone_from_sampled_frames_on_the_device(hip):

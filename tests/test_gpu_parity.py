@@ -253,13 +253,17 @@ def test_igso3_angle_distribution(hip):
 
     od = OrientationDiffuser(T=100, s=0.01, beta_max=0.999)
     torch.manual_seed(3)
+    assert od.so3.without_replacement is True  # the default joint draw is the reference's (torch.multinomial without replacement)
     for t in (2, 5):
-        th = od.so3.sample_from_histogram(torch.full((64,), t), 512).flatten().double()
-        cdf = od.so3._cdf[t].double().cpu()
-        emp = torch.sort(th).values
-        idx = (emp / (np.pi / 8192)).long().clamp_max(8191)
-        ks = (cdf[idx] - torch.arange(1, len(emp) + 1) / len(emp)).abs().max()
-        assert ks < 0.02, (t, float(ks))
+        def ks_of(th):
+            cdf = od.so3._cdf[t].double().cpu()
+            emp = torch.sort(th.flatten().double()).values
+            idx = (emp / (np.pi / 8192)).long().clamp_max(8191)
+            return float((cdf[idx] - torch.arange(1, len(emp) + 1) / len(emp)).abs().max())
+        # independent draws (inverse CDF) follow the table row; so does the FIRST bin of each without-replacement draw - the joint draw
+        # of 512 bins from a row whose mass sits in a few hundred bins does not (so3.py:78 has that property: the spread test below)
+        assert ks_of(od.so3.sample_from_histogram(torch.full((64,), t), 512, without_replacement=False)) < 0.02, t
+        assert ks_of(od.so3.sample_from_histogram(torch.full((4096,), t), 1)) < 0.03, t
     rv = od.so3.sample_isotropic_gaussian(torch.full((64,), 50), 512)
     ang = rv.norm(dim=-1)
     sg = float(od.sched["one_minus_alpha_bar_sqrt"][50])
