@@ -146,6 +146,16 @@ def cpu_baseline(dims, sd, K, seed, budget_s=30.0):
     }
 
 
+def train_bytes_per_patch(K, dims, dpair):
+    """Algorithmic HBM bytes of one training step per patch: the pair tensor read once by the forward and once by the
+    backward of each layer, the attention tape (probabilities written and read once: 2 x H K^2 4 B per layer),
+    and - only when d pair_ctx is asked for - its read-modify-write (two more passes over the pair tensor per layer): 56.6 MB and
+    107 MB per patch-step at K = 128, NL = 6."""
+    pair = dims["NL"] * K * K * dims["C"] * 4
+    tape = dims["NL"] * 2 * dims["H"] * K * K * 4  # probabilities written + read (the squared distances the tape also keeps are a choice)
+    return 2 * pair + tape + (2 * pair if dpair else 0)
+
+
 def other_configs(model, dims, flags):
     """Short secondary measurements on one GPU, reported next to the headline line (never part of `value`):
     BASELINE config 5 (K=256 long-CDR stress, 128 patches: per-GPU share of 512 on 4 GPUs) and config 4 (training step,
@@ -213,27 +223,50 @@ def other_configs(model, dims, flags):
         del inp, ws
     except Exception as ex:  # noqa: BLE001
         res["config1_one_patch"] = f"failed: {type(ex).__name__}: {ex}"
-    try:
-        B, K, steps, warm = 128, 128, 8, 4  # (the first steps of a process allocate the tape, the gradient buckets and Adam's state)
-        inp = syn.patches(B, K, dims, seed=2)
-        batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
-                 "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),
-                 "res_context_emb": inp["res_context_emb"].cuda(), "pair_context_emb": inp["pair_context_emb"].cuda()}
+    # BASELINE config 4 at its per-GPU share (128 patches): three definitions of "a training step", each with its own algorithmic bytes
+    #   contexts_given        contexts are constant inputs (no d pair_ctx): pair stream read by forward and backward + P / d2 tape
+    #   contexts_given_dpair  SURVEY 8(d)'s definition: + the read-modify-write of d pair_ctx (2 more passes over the pair tensor)
+    #   full_step_raw_batch   the reference-shaped step (:808-880): raw batch -> encode_context forward + backward -> all 2 538 468 parameters
+    def train_leg(batch, steps=8, warm=4, dpair=False):
         opt = model.configure_optimizers()
         loss = None
         for it in range(warm + steps):
             if it == warm:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            opt.zero_grad()
+            opt.zero_grad(set_to_none=True)
+            if dpair:
+                batch["pair_context_emb"].grad = None
             loss = model.training_step(batch, it)
             loss.backward()
             opt.step()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        res["training_step"] = {"patches": B, "K": K, "steps": steps, "ms_per_step": dt * 1e3, "residue_steps_per_s": B * K / dt,
-                                "loss_finite": bool(torch.isfinite(loss.detach()).item()),
-                                "what": "noise + taped forward + 3 losses + HIP backward + Adam, contexts given"}
+        return (time.perf_counter() - t0) / steps, bool(torch.isfinite(loss.detach()).item())
+
+    try:
+        B, K = 128, 128
+        inp = syn.patches(B, K, dims, seed=2)
+        batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
+                 "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),
+                 "res_context_emb": inp["res_context_emb"].cuda(), "pair_context_emb": inp["pair_context_emb"].cuda()}
+        legs = {}
+        for name, dpair in (("contexts_given", False), ("contexts_given_dpair", True)):
+            batch["pair_context_emb"].requires_grad_(dpair)
+            dt, fin = train_leg(batch, dpair=dpair)
+            mb = train_bytes_per_patch(K, dims, dpair) / 1e6
+            legs[name] = {"ms_per_step": dt * 1e3, "residue_steps_per_s": B * K / dt, "loss_finite": fin,
+                          "algorithmic_MB_per_patch_step": mb, "hbm_frac": B * mb * 1e6 / dt / 1e9 / HBM_PEAK_GBPS}
+        batch["pair_context_emb"].requires_grad_(False)
+        del batch, inp
+        gc.collect()
+        torch.cuda.empty_cache()
+        raw = {k: v.cuda() for k, v in syn.context_batch(B, K, n_atoms=15, seed=5, with_distmat=False).items()}
+        raw.pop("distmat")  # (the reference's collate_fn does not produce it either, data.py:94-95: distances are taken from xyz)
+        dt, fin = train_leg(raw)
+        legs["full_step_raw_batch"] = {"ms_per_step": dt * 1e3, "residue_steps_per_s": B * K / dt, "loss_finite": fin,
+                                       "what": "raw batch (15 atoms, chain ids) -> featurisation of xyz -> encode_context forward + backward -> "
+                                               "noise + taped denoise forward + 3 losses + HIP backward -> Adam on all 2 538 468 parameters"}
+        res["training_step"] = dict(patches=B, K=K, steps=8, **legs)
     except Exception as ex:  # noqa: BLE001
         res["training_step"] = f"failed: {type(ex).__name__}: {ex}"
     gc.collect()
@@ -243,8 +276,10 @@ def other_configs(model, dims, flags):
 
 def train_bench(args, model, dims, rank, world, dist):
     """BASELINE config 4: B patches per GPU (1024 = 8 x 128), one training step = forward noise + taped denoise forward + three
-    losses + HIP backward + all-reduce of the gradient buckets (in place, RCCL) + Adam.  Contexts are leaf inputs, as in the
-    gradient goldens (the hot-path definition of SURVEY 8d: 107 MB of algorithmic traffic per patch-step)."""
+    losses + HIP backward + all-reduce of the gradient buckets (in place, RCCL) + Adam.  The measured step (`value`) follows SURVEY
+    8(d)'s definition: the contexts are grad-requiring inputs, so the backward also produces d pair_ctx (107 MB of algorithmic
+    traffic per patch-step).  The same step with constant contexts (no d pair_ctx: 56.6 MB per patch-step) is timed behind it and
+    reported as `contexts_constant` with its own roofline fraction."""
     from diffab_pytorch import distributed as D, synthetic as syn
 
     B, K = args.batch, args.k
@@ -259,6 +294,7 @@ def train_bench(args, model, dims, rank, world, dist):
     def step(i):
         nonlocal loss
         opt.zero_grad(set_to_none=True)
+        batch["pair_context_emb"].grad = None
         loss = model.training_step(batch, i)
         loss.backward()
         D.allreduce_gradients(model.parameters(), dist, flats=model.gradient_buckets())
@@ -269,34 +305,48 @@ def train_bench(args, model, dims, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def timed(dpair):
+        batch["pair_context_emb"].requires_grad_(dpair)
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
+    elapsed = timed(True)
+    had_dpair = batch["pair_context_emb"].grad is not None
+    elapsed_const = timed(False)
     in_place = all(p.grad is None or any(f is not None and p.grad.untyped_storage().data_ptr() == f.untyped_storage().data_ptr()
                                          for f in model.gradient_buckets()) for p in model.denoiser.parameters())
     if rank == 0:
         value = world * B * K * args.steps / elapsed
-        train_bytes_per_patch = 107e6  # NL K^2 C 4 x (fwd read + bwd read + grad-e read-modify-write) + saved activations
-        achieved = value / world / K * train_bytes_per_patch / 1e9
+        by, by_c = train_bytes_per_patch(K, dims, True), train_bytes_per_patch(K, dims, False)
+        achieved = value / world / K * by / 1e9
+        value_c = world * B * K * args.steps / elapsed_const
         print(json.dumps({
             "metric": "CDR-residue training-steps/sec (K=128 patch, forward + backward + Adam)", "value": value, "unit": "residue-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (bf16x6 split-precision dense products, fp32 accumulate; fp32-accurate, DESIGN section 4)", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: training step, batch={B}/GPU synthetic K={K} patches, benchmark model NL=6; noise + taped "
-                                   "forward + 3 losses + HIP backward + gradient all-reduce (RCCL, in-place buckets) + Adam; contexts given",
+                                   "forward + 3 losses + HIP backward incl. d pair_ctx + gradient all-reduce (RCCL, in-place buckets) + Adam; "
+                                   "contexts given as grad-requiring inputs (SURVEY 8d)",
                        "patches_per_gpu": B, "K": K, "global_batch": world * B, "parallelism": f"data-parallel x{world}"},
-            "roofline": {"kernel": "whole training step (no single dominant kernel: profiles/r02_train_kernel_stats.csv)", "bound": "hbm",
+            "roofline": {"kernel": "whole training step (no single dominant kernel: profiles/r04_train_kernel_stats.csv)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_patch_step": train_bytes_per_patch},
+                         "algorithmic_bytes_per_patch_step": by},
+            "contexts_constant": {"what": "the same step with constant contexts (no d pair_ctx)", "ms_per_step": elapsed_const / args.steps * 1e3,
+                                  "residue_steps_per_s": value_c, "algorithmic_bytes_per_patch_step": by_c,
+                                  "hbm_frac": value_c / world / K * by_c / 1e9 / HBM_PEAK_GBPS},
+            "d_pair_ctx_computed": bool(had_dpair),
             "loss_finite": bool(torch.isfinite(loss.detach()).item()), "gradients_reduced_in_place": bool(in_place),
         }), flush=True)
 

@@ -765,8 +765,9 @@ class DiffAb(_ModuleBase):
         has them already (the hot-path benchmarks and gradient goldens, where contexts are leaf inputs)."""
         dev_in = batch["generation_mask"].device
         bsz = batch["generation_mask"].size(0)
-        t = torch.randint(low=1, high=self.T + 1, size=(bsz,)).to(dev_in)
-        beta = self.sched["beta"][t.cpu()].to(dev_in)
+        t_host = torch.randint(low=1, high=self.T + 1, size=(bsz,))  # CPU generator, as the reference (:813); the schedule lookup stays on
+        beta = self.sched["beta"][t_host].to(dev_in)                  # the host: no device -> host copy (a stream drain) per step
+        t = t_host.to(dev_in)
         xyz_t0 = batch["xyz"]
         if "orientations" not in batch and xyz_t0.dim() == 4:  # frames from the backbone atoms (SURVEY 8 row f2)
             batch = dict(batch, **_features.featurize(xyz_t0, orientations=True, backbone_dihedrals=False, pairwise_dihedrals=False))

@@ -98,11 +98,47 @@ def check_trajectory(model, inp, seed, shard, n_steps_expected, kw=None):
     return B * K * model.T / dt, dt
 
 
+def oracle_reverse_step(model, inp, sl, seed, t):
+    """The oracle's reverse step t -> t-1 for the patches `sl` (a slice) of a batch, with the Philox noise of their GLOBAL patch ids."""
+    sd = {"denoiser." + k: v.detach().cpu() for k, v in model.denoiser.state_dict().items()}
+    sched = orc.cosine_variance_schedule(model.T, s=0.01, beta_max=0.999)
+    c = {k: v[sl].cpu() for k, v in inp.items()}
+    B, K = c["seq_idx"].shape
+    patch = (sl.start + np.arange(B))[:, None] + np.zeros((B, K), dtype=np.int64)
+    res = np.zeros((B, K), dtype=np.int64) + np.arange(K)[None, :]
+    z = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, orc.STREAM_TRANS)[:3], -1))
+    ax = torch.from_numpy(np.stack(orc.philox_normal4(seed, patch, res, t, orc.STREAM_AXIS)[:3], -1))
+    ua = orc.philox_uniform4(seed, patch, res, t, orc.STREAM_ANGLE)
+    na = orc.philox_normal4(seed, patch, res, t, orc.STREAM_ANGLE)
+    us = torch.from_numpy(orc.philox_uniform4(seed, patch, res, t, orc.STREAM_SEQ)[0])
+    sig = sched["beta"].sqrt()
+    cdf_row = model._reverse_so3()._cdf[t].cpu()[None, None, :].expand(B, K, -1)
+    th_h = orc.igso3_theta_from_hist(orc.igso3_bin_from_cdf(cdf_row, torch.from_numpy(ua[0])), torch.from_numpy(ua[1]))
+    th_g = orc.igso3_theta_from_gaussian(sig[t].expand(B, K), torch.from_numpy(na[2]))
+    rotvec = orc.igso3_rotvec(ax, th_h, th_g, sig[t].expand(B))
+    den = orc.denoiser(sd, c["seq_idx"], c["translations"], c["orientations"], c["res_context_emb"], c["pair_context_emb"],
+                       sched["beta"][t].expand(B), model.denoiser.dims["NL"], model.denoiser.dims["H"])
+    return orc.reverse_update(t, c["seq_idx"], c["translations"], c["orientations"], den, c["generation_mask"], sched, z, rotvec, us)
+
+
 def test_config2_b256_k128_100_steps(hip):
     dims, model = bench_model(100)
     inp = device_patches(256, 128, dims, seed=2)
     rate, dt = check_trajectory(model, inp, seed=11, shard=(64, 72), n_steps_expected=100)
     print(f"config 2: B=256 K=128 x 100 steps in {dt:.3f} s (incl. launch + sync) = {rate / 1e6:.2f} M residue-steps/s")
+    # DIRECT parity at the instantiations this batch size selects (128-row dense tiles, the non-SPLIT projection kernel - forms that
+    # smaller batches never run): one teacher-forced reverse step of all 256 patches, an 8-patch slice of it against the oracle
+    from conftest import maxrel
+
+    for t in (57, 3):
+        got = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], res_context_emb=inp["res_context_emb"],
+                           pair_context_emb=inp["pair_context_emb"], generation_mask=inp["generation_mask"], seed=29, t_start=t, t_stop=t - 1,
+                           init=False)
+        sl = slice(120, 128)
+        s1, x1, O1 = oracle_reverse_step(model, inp, sl, 29, t)
+        assert maxrel(got["translations"][sl], x1) < 1e-4, (t, maxrel(got["translations"][sl], x1))
+        assert maxrel(got["orientations"][sl], O1) < 1e-4, (t, maxrel(got["orientations"][sl], O1))
+        assert int((got["seq_idx"][sl].cpu() != s1).sum()) <= 2, t  # a draw flips only on a CDF edge (tests/test_gpu_parity.py counts them)
 
 
 def test_config5_b512_k256_200_steps_T200(hip):
