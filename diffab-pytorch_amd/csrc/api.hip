@@ -133,12 +133,14 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
 
 static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                               const float* t, float* y, float* ws, uint32_t flags, hipStream_t st, float* sp_keep = nullptr,
-                              float* d2_keep = nullptr, const void* planes = nullptr, const float* pair_planes = nullptr) {
+                              float* d2_keep = nullptr, const void* planes = nullptr, const float* pair_planes = nullptr,
+                              bool taped = false) {  // taped: ws is a slot of the training tape (the backward reads proj and feat)
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && (w->w_bias || d->C == 0) && w->wq_p && w->wk_p && w->wv_p && w->w_out &&
                      w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
-    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, sp_keep, d2_keep, planes, pair_planes, (flags & DIFFAB_FLAG_FP32_GEMM) != 0);
+    return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, sp_keep, d2_keep, planes, pair_planes, (flags & DIFFAB_FLAG_FP32_GEMM) != 0,
+                          taped);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -241,14 +243,22 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
     float* outs[3] = {out_eps, b.vbuf, logits};
     const int nout[3] = {3, 3, d->V};
-    for (int hd = 0; hd < 3; ++hd) {
+    for (int hd = 0; hd < 3; ++hd)
       DIFFAB_REQUIRE(hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
-      if (chain) {
-        const void* pl[3] = {mlp + (2 + 2 * hd) * mlp_planes_bytes(), mlp + (3 + 2 * hd) * mlp_planes_bytes(), mlp + (8 + hd) * mlp_planes_bytes()};
-        const float* bs[3] = {b.beta_tab + static_cast<size_t>(hd) * d->B * D, hw[hd]->b2, hw[hd]->b4};
-        if (int rc = launch_mlp_chain_b6(cur, D, pl, bs, nullptr, d->K, 3, nout[hd], outs[hd], nout[hd], rows, st)) return rc;
-        continue;
+    if (chain) {  // the three heads read the same rows: one launch, blockIdx.y = head
+      const void* pl[9];
+      const float* bs[9];
+      for (int hd = 0; hd < 3; ++hd) {
+        pl[3 * hd] = mlp + (2 + 2 * hd) * mlp_planes_bytes();
+        pl[3 * hd + 1] = mlp + (3 + 2 * hd) * mlp_planes_bytes();
+        pl[3 * hd + 2] = mlp + (8 + hd) * mlp_planes_bytes();
+        bs[3 * hd] = b.beta_tab + static_cast<size_t>(hd) * d->B * D;
+        bs[3 * hd + 1] = hw[hd]->b2;
+        bs[3 * hd + 2] = hw[hd]->b4;
       }
+      if (int rc = launch_mlp_chains_b6(cur, D, 3, pl, bs, nullptr, d->K, 3, nout, outs, nout, rows, st)) return rc;
+    }
+    for (int hd = 0; hd < 3 && !chain; ++hd) {
       if (int rc = dense128(2 + 2 * hd, cur, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, true))
         return rc;
       if (int rc = dense128(3 + 2 * hd, b.t1, hw[hd]->w2, D, hw[hd]->b2, nullptr, 0, b.t2, true)) return rc;
@@ -282,7 +292,7 @@ static int denoise_step_taped(const diffab_dims* d, const diffab_denoiser_weight
     if (b6)
       if (int rc = ipa_layer_split_weights(&w->layers[l], tp.planes, st)) return rc;
     if (int rc = ipa_layer_dispatch(d, &w->layers[l], tp.x[l], pair_ctx, O_t, x_t, tp.x[l + 1], tp.ipa_ws[l], flags, st, tp.sp[l], tp.d2[l],
-                                    b6 ? tp.planes : nullptr))
+                                    b6 ? tp.planes : nullptr, nullptr, true))
       return rc;
   }
   if (int rc = launch_beta_concat(tp.x[d->NL], beta, D, d->K, rows, tp.cat3, st)) return rc;
@@ -549,7 +559,8 @@ int diffab_ipa_layer_fwd_taped(const diffab_dims* d, const diffab_ipa_layer_weig
   const bool b6 = tp.planes && use_b6_gemm(flags) && fast_path_supported(&d1);
   if (b6)
     if (int rc = ipa_layer_split_weights(w, tp.planes, st)) return rc;
-  if (int rc = ipa_layer_dispatch(&d1, w, tp.x[0], e, R, t, tp.x[1], tp.ipa_ws[0], flags, st, tp.sp[0], tp.d2[0], b6 ? tp.planes : nullptr))
+  if (int rc = ipa_layer_dispatch(&d1, w, tp.x[0], e, R, t, tp.x[1], tp.ipa_ws[0], flags, st, tp.sp[0], tp.d2[0], b6 ? tp.planes : nullptr,
+                                  nullptr, true))
     return rc;
   DIFFAB_HIP_CHECK(hipMemcpyAsync(y, tp.x[1], nb, hipMemcpyDeviceToDevice, st));
   return DIFFAB_OK;

@@ -1388,7 +1388,7 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d) { return ipa_ws_operands_
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, float* sp_keep, float* d2_keep, const void* planes, const float* pair_planes,
-                   bool fp32_gemm) {
+                   bool fp32_gemm, bool taped) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1406,7 +1406,9 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   // to_out (diffab_pytorch.py:459-464): feat (rows x 1024) Wo^T + b
   auto to_out = [&]() -> int {
     if (b6 && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
-      return launch_rowgemm128_b6p(feat, AF, out_planes, w->b_out, nullptr, 0, y, D, rows, AF, false, st);
+      // (inference: the projections are dead once the attention has run, their rows take the k parts of a small batch; on the
+      // training tape they are kept for the backward)
+      return launch_rowgemm128_b6p(feat, AF, out_planes, w->b_out, nullptr, 0, y, D, rows, AF, false, st, taped ? nullptr : proj);
     return launch_linear(feat, AF, w->w_out, w->b_out, y, D, rows, D, AF, false, st);
   };
   // one GEMM for the six projections: Y[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T

@@ -22,7 +22,8 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                    float* sp_keep = nullptr, float* d2_keep = nullptr,  // training tape: three launches, P and d2 kept in these buffers
                    const void* planes = nullptr,  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
                    const float* pair_planes = nullptr,  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
-                   bool fp32_gemm = false);  // DIFFAB_FLAG_FP32_GEMM: dense products on the f32-input MFMA kernels
+                   bool fp32_gemm = false,
+                   bool taped = false);  // ws is a slot of the training tape: proj and feat are read by the backward (no scratch use)  // DIFFAB_FLAG_FP32_GEMM: dense products on the f32-input MFMA kernels
 // fp16 planes of the pair embedding for the fused attention kernel (K = 64 / 128): pair_planes_floats(d) floats, 256-byte aligned
 bool pair_planes_supported(const diffab_dims* d);
 size_t pair_planes_floats(const diffab_dims* d);
@@ -45,12 +46,15 @@ bool rowgemm128_b6_ok(const float* X, int ldx, const float* Y, int ldy, int M, i
 int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t st, int nrows = 128);  // rows >= nrows: zero planes
 // X[M x 128] through 2 or 3 dense 128-wide layers in ONE kernel (ReLU between them, the last layer n_out <= 128 columns wide,
 // activations stay in LDS); layer 0's bias may be a table indexed per row like launch_rowgemm128's
+int launch_mlp_chains_b6(const float* X, int ldx, int nchains, const void* const* planes, const float* const* bias, const int64_t* bias_idx0,
+                         int bias_div0, int nlayers, const int* n_out, float* const* Y, const int* ldy, int M, hipStream_t st);
 int launch_mlp_chain_b6(const float* X, int ldx, const void* const* planes, const float* const* bias, const int64_t* bias_idx0, int bias_div0,
                         int nlayers, int n_out, float* Y, int ldy, int M, hipStream_t st);
 int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, int k0, void* planes, hipStream_t st);  // (n, k) = W[n sn + k sk]
 int launch_wsplit128_segs(const float* const* W, const int* k_end, int nseg, void* planes, hipStream_t st);  // W_q[k][n] stacked along k
 int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
-                          int ldy, int M, int Kd, bool relu, hipStream_t st);
+                          int ldy, int M, int Kd, bool relu, hipStream_t st, float* parts = nullptr);
+size_t rowgemm128_b6_parts_floats(int M, int Kd);  // scratch of the k-parts form (few row tiles)
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                          int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st);
 bool use_b6_gemm(uint32_t flags = 0);  // false with DIFFAB_FLAG_FP32_GEMM (experimental builds: or DIFFAB_FP32_GEMM=1 in the environment)

@@ -97,6 +97,42 @@ __global__ __launch_bounds__(ROWS * 4) void rowgemm128_b6_kernel(const float* __
   b6tile::rowgemm128_tile<RELU, ROWS>(b6_lds, threadIdx.x, blockIdx.x, X, ldx, Wc, bias, bias_idx, bias_div, Y, ldy, M, Kd);  // rowgemm_b6_tile.h
 }
 
+// The same product for a handful of row tiles (one patch: two 64-row tiles on 256 CUs): one work-group per (row tile, k part) leaves its
+// part in parts[tile][part][ROWS][128], a second launch adds the parts of an element in the fixed order of rowgemm_b6_tile.h - the result
+// is bitwise the one of rowgemm128_b6_kernel.  (One launch with the last work-group of a tile adding up was measured: 72 us against 31
+// for the plain kernel at one patch - the agent-scope release / acquire it needs writes back and invalidates the XCD's whole L2.)
+template <int ROWS>
+__global__ __launch_bounds__(ROWS * 4) void rowgemm128_b6_parts_kernel(const float* __restrict__ X, int ldx, const __bf16* __restrict__ Wc, int M,
+                                                                       int Kd, float* __restrict__ parts) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 b6_lds[];
+  float* mine = parts + (static_cast<size_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (ROWS * 128);
+  b6tile::rowgemm128_tile<false, ROWS, true>(b6_lds, threadIdx.x, blockIdx.x, X, ldx, Wc, nullptr, nullptr, 0, nullptr, 0, M, Kd,
+                                             blockIdx.y * b6tile::PART_CHUNKS, mine);
+}
+template <bool RELU, int ROWS>
+__global__ __launch_bounds__(256) void rowgemm128_b6_parts_sum_kernel(const float* __restrict__ parts, int nparts, const float* __restrict__ bias,
+                                                                      const int64_t* __restrict__ bias_idx, int bias_div,
+                                                                      float* __restrict__ Y, int ldy, int M) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;  // (row, 4 columns)
+  const int row = gid >> 5, col = (gid & 31) * 4;
+  if (row >= M) return;
+  const float* src = parts + (static_cast<size_t>(row / ROWS) * nparts * ROWS + row % ROWS) * 128 + col;
+  b6tile::f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < nparts; ++p) {
+    const b6tile::f32x4 v = *reinterpret_cast<const b6tile::f32x4*>(src + static_cast<size_t>(p) * (ROWS * 128));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tot[c] += v[c];
+  }
+  const bool table = bias_idx != nullptr || bias_div > 0;
+  const float* brow = table ? bias + (bias_idx ? bias_idx[row] : row / bias_div) * 128 : bias;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float o = tot[c] + (brow ? brow[col + c] : 0.f);
+    if (RELU) o = fmaxf(o, 0.f);
+    Y[static_cast<int64_t>(row) * ldy + col + c] = o;
+  }
+}
+
 // ================================================================== a chain of two or three 128-wide dense layers in one kernel
 // Y = L3(relu(L2(relu(L1(X))))) (or two layers) for 128 rows per work-group, every layer K = 128 -> 128 columns (the last one n_out <=
 // 128 wide, its missing weight rows zero planes).  The denoiser's MLPs (embedding: 2 layers; the three heads: 3 layers each) were
@@ -113,9 +149,30 @@ struct MlpChain {
   int n_out;    // columns of the last layer that exist
 };
 constexpr int kChainLdsBytes = 2 * 3 * 128 * BK * 2 + 4 * 3 * 128 * BK * 2;  // 49 152 + 98 304
+// up to three chains over the SAME input rows in one launch (blockIdx.y = chain: the denoiser's three heads - at one patch three
+// work-groups side by side instead of three latency-bound launches one after the other)
+struct MlpChainSet {
+  MlpChain c[3];
+  float* Y[3];
+  int ldy[3];
+};
 
-__global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restrict__ X, int ldx, MlpChain ch, float* __restrict__ Y, int ldy,
-                                                           int M) {
+__global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restrict__ X, int ldx, MlpChainSet set, int M) {
+  // the chain of this work-group, field by field (uniform selects: indexing the by-value argument would move it to scratch)
+  const int cy = blockIdx.y;
+#define CHAIN_SEL(f) (cy == 0 ? set.c[0].f : cy == 1 ? set.c[1].f : set.c[2].f)
+  const __bf16 *pl0 = CHAIN_SEL(planes[0]), *pl1 = CHAIN_SEL(planes[1]), *pl2 = CHAIN_SEL(planes[2]);
+  const float *bs0 = CHAIN_SEL(bias[0]), *bs1 = CHAIN_SEL(bias[1]), *bs2 = CHAIN_SEL(bias[2]);
+  struct { const int64_t* bias_idx0; int bias_div0, nlayers, n_out; } ch;
+  ch.bias_idx0 = CHAIN_SEL(bias_idx0);
+  ch.bias_div0 = CHAIN_SEL(bias_div0);
+  ch.nlayers = CHAIN_SEL(nlayers);
+  ch.n_out = CHAIN_SEL(n_out);
+#undef CHAIN_SEL
+  auto planes_of = [&](int L) { return L == 0 ? pl0 : L == 1 ? pl1 : pl2; };
+  auto bias_of = [&](int L) { return L == 0 ? bs0 : L == 1 ? bs1 : bs2; };
+  float* __restrict__ Y = cy == 0 ? set.Y[0] : cy == 1 ? set.Y[1] : set.Y[2];
+  const int ldy = cy == 0 ? set.ldy[0] : cy == 1 ? set.ldy[1] : set.ldy[2];
   extern __shared__ __attribute__((aligned(16))) __bf16 cl[];
   __bf16* Ws = cl;                        // [2][3][128][32]
   __bf16* img = cl + 2 * 3 * 128 * BK;    // [4][3][128][32]
@@ -169,9 +226,9 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
   const int fx = (l31 >> 2) & 3;
   const int a_off = (32 * rw + l31) * BK, w_off = (64 * cw + l31) * BK;
   constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
-  load_w(ch.planes[0], 0);
+  load_w(pl0, 0);
   for (int L = 0; L < ch.nlayers; ++L) {
-    const __bf16* Wc = ch.planes[L];
+    const __bf16* Wc = planes_of(L);
     const bool last = L == ch.nlayers - 1;
     f32x16 acc[2];
 #pragma unroll
@@ -206,7 +263,7 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
       if (c < 3) {  // next chunk of this layer into the other buffer, then request the one after it (or the next layer's first chunk)
         store_w(buf ^ 1);
         if (c < 2) load_w(Wc, c + 2);
-        else if (!last) load_w(ch.planes[L + 1], 0);
+        else if (!last) load_w(planes_of(L + 1), 0);
         MEM_FENCE();
       }
       __syncthreads();
@@ -216,14 +273,15 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int col = 64 * cw + 32 * tt + l31;
-      float bv = (ch.bias[L] && !table && (!last || col < ch.n_out)) ? ch.bias[L][col] : 0.0f;
+      const float* bl = bias_of(L);
+      float bv = (bl && !table && (!last || col < ch.n_out)) ? bl[col] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lrow = 32 * rw + (r & 3) + 8 * (r >> 2) + 4 * hk, row = m0 + lrow;
         if (table) {
           const int rc = row < M ? row : M - 1;
           const int64_t bi = ch.bias_idx0 ? ch.bias_idx0[rc] : rc / ch.bias_div0;
-          bv = ch.bias[0][bi * 128 + col];
+          bv = bs0[bi * 128 + col];
         }
         float o = acc[tt][r] + bv;
         if (last) {
@@ -244,27 +302,40 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
   }
 }
 
-// X[M x 128] through a chain of 2 or 3 dense layers (see mlp_chain_b6_kernel); planes from launch_wsplit128 (Kd = 128; the last layer's
-// with nrows = n_out)
-int launch_mlp_chain_b6(const float* X, int ldx, const void* const* planes, const float* const* bias, const int64_t* bias_idx0, int bias_div0,
-                        int nlayers, int n_out, float* Y, int ldy, int M, hipStream_t st) {
-  DIFFAB_REQUIRE(X && Y && M >= 1 && (nlayers == 2 || nlayers == 3) && n_out >= 1 && n_out <= 128 && ldx % 4 == 0 &&
+// X[M x 128] through `nchains` (1..3) chains of 2 or 3 dense layers each, one launch (see mlp_chain_b6_kernel); planes from
+// launch_wsplit128 (Kd = 128; the last layer's with nrows = n_out); chain c: planes[3 c + layer], bias[3 c + layer], layer-0 bias table
+// selected by bias_idx0 / bias_div0 (shared by the chains: each has its own table behind bias[3 c])
+int launch_mlp_chains_b6(const float* X, int ldx, int nchains, const void* const* planes, const float* const* bias, const int64_t* bias_idx0,
+                         int bias_div0, int nlayers, const int* n_out, float* const* Y, const int* ldy, int M, hipStream_t st) {
+  DIFFAB_REQUIRE(X && M >= 1 && nchains >= 1 && nchains <= 3 && (nlayers == 2 || nlayers == 3) && ldx % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(X) & 15) == 0,
                  DIFFAB_ERR_ARG, "mlp_chain_b6: unsupported operands");
-  MlpChain ch{};
-  for (int i = 0; i < nlayers; ++i) {
-    DIFFAB_REQUIRE(planes[i] && (reinterpret_cast<uintptr_t>(planes[i]) & 15) == 0, DIFFAB_ERR_ARG, "mlp_chain_b6: null / misaligned planes");
-    ch.planes[i] = static_cast<const __bf16*>(planes[i]);
-    ch.bias[i] = bias[i];
+  MlpChainSet set{};
+  for (int c = 0; c < nchains; ++c) {
+    DIFFAB_REQUIRE(Y[c] && n_out[c] >= 1 && n_out[c] <= 128, DIFFAB_ERR_ARG, "mlp_chain_b6: unsupported output");
+    for (int i = 0; i < nlayers; ++i) {
+      const void* pl = planes[3 * c + i];
+      DIFFAB_REQUIRE(pl && (reinterpret_cast<uintptr_t>(pl) & 15) == 0, DIFFAB_ERR_ARG, "mlp_chain_b6: null / misaligned planes");
+      set.c[c].planes[i] = static_cast<const __bf16*>(pl);
+      set.c[c].bias[i] = bias[3 * c + i];
+    }
+    set.c[c].bias_idx0 = bias_idx0;
+    set.c[c].bias_div0 = bias_div0;
+    set.c[c].nlayers = nlayers;
+    set.c[c].n_out = n_out[c];
+    set.Y[c] = Y[c];
+    set.ldy[c] = ldy[c];
   }
-  ch.bias_idx0 = bias_idx0;
-  ch.bias_div0 = bias_div0;
-  ch.nlayers = nlayers;
-  ch.n_out = n_out;
   DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_b6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-  hipLaunchKernelGGL(mlp_chain_b6_kernel, dim3((M + 127) / 128), dim3(512), kChainLdsBytes, st, X, ldx, ch, Y, ldy, M);
+  hipLaunchKernelGGL(mlp_chain_b6_kernel, dim3((M + 127) / 128, nchains), dim3(512), kChainLdsBytes, st, X, ldx, set, M);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
+}
+int launch_mlp_chain_b6(const float* X, int ldx, const void* const* planes, const float* const* bias, const int64_t* bias_idx0, int bias_div0,
+                        int nlayers, int n_out, float* Y, int ldy, int M, hipStream_t st) {
+  const void* pl[3] = {planes[0], planes[1], nlayers == 3 ? planes[2] : nullptr};
+  const float* bs[3] = {bias[0], bias[1], nlayers == 3 ? bias[2] : nullptr};
+  return launch_mlp_chains_b6(X, ldx, 1, pl, bs, bias_idx0, bias_div0, nlayers, &n_out, &Y, &ldy, M, st);
 }
 
 size_t rowgemm128_b6_scratch_bytes(int Kd) { return static_cast<size_t>(3) * 128 * Kd * sizeof(__bf16); }
@@ -303,12 +374,28 @@ int launch_wsplit128_segs(const float* const* W, const int* k_end, int nseg, voi
   return DIFFAB_OK;
 }
 
-// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + bias row) with W given as split planes (launch_wsplit128)
+// Y[M x 128] = act(X[:, 0:Kd] W[:, 0:Kd]^T + bias row) with W given as split planes (launch_wsplit128).
+// parts (optional): rowgemm128_b6_parts_floats(M, Kd) floats of scratch - with it a product of few row tiles (latency-bound: one patch is
+// two work-groups on 256 CUs) runs one work-group per (row tile, 128-k part) and a second launch adds the parts up.
+size_t rowgemm128_b6_parts_floats(int M, int Kd) {
+  return static_cast<size_t>((M + 63) / 64) * ((Kd / b6tile::BK + b6tile::PART_CHUNKS - 1) / b6tile::PART_CHUNKS) * 64 * 128;
+}
 int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
-                          int ldy, int M, int Kd, bool relu, hipStream_t st) {
+                          int ldy, int M, int Kd, bool relu, hipStream_t st, float* parts) {
   DIFFAB_REQUIRE(rowgemm128_b6_ok(X, ldx, Y, ldy, M, Kd) && planes && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, DIFFAB_ERR_ARG,
                  "rowgemm128_b6: unsupported operands");
   const __bf16* Wc = static_cast<const __bf16*>(planes);
+  const int tiles64 = (M + 63) / 64, nparts = (Kd / b6tile::BK + b6tile::PART_CHUNKS - 1) / b6tile::PART_CHUNKS;
+  if (parts && nparts > 1 && tiles64 <= 64 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0) {  // up to 32 patches of 128 residues
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm128_b6_parts_kernel<64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, b6_lds_bytes<64>()));
+    hipLaunchKernelGGL((rowgemm128_b6_parts_kernel<64>), dim3(tiles64, nparts), dim3(256), b6_lds_bytes<64>(), st, X, ldx, Wc, M, Kd, parts);
+    const dim3 sgrid((M * 32 + 255) / 256);
+    if (relu) hipLaunchKernelGGL((rowgemm128_b6_parts_sum_kernel<true, 64>), sgrid, dim3(256), 0, st, parts, nparts, bias, bias_idx, bias_div, Y, ldy, M);
+    else hipLaunchKernelGGL((rowgemm128_b6_parts_sum_kernel<false, 64>), sgrid, dim3(256), 0, st, parts, nparts, bias, bias_idx, bias_div, Y, ldy, M);
+    DIFFAB_LAUNCH_CHECK();
+    return DIFFAB_OK;
+  }
   // 128-row work-groups when they fill the chip (measured at 256 groups: 47 us against 53 for 64-row groups, K = 1024), 64-row
   // groups below that (B <= 128 patches of 128 residues per GPU: twice the groups)
   const int rows_env = (M + 127) / 128 >= 256 ? 128 : 64;

@@ -21,11 +21,19 @@ __device__ __forceinline__ int b6_off(int row, int slot) { return row * BK + 8 *
 template <int ROWS>
 constexpr int lds_bytes() { return 2 * 3 * (128 + ROWS) * BK * 2; }
 
-// b6_lds: lds_bytes<ROWS>() bytes of LDS, 16-byte aligned; ROWS * 4 threads (tid = threadIdx.x); tile_m: index of the row tile
-template <bool RELU, int ROWS>
+// Summation order over k (the same for every launch shape, so that a result does not depend on how many work-groups shared a row tile:
+// the sampler's bitwise shard invariance): k is cut into PARTS of PART_CHUNKS chunks (128 k); a part is accumulated from zero on the
+// matrix cores, the parts are added in ascending order on the VALU (0 + p0 + p1 + ...), the bias last.
+constexpr int PART_CHUNKS = 4;
+
+// b6_lds: lds_bytes<ROWS>() bytes of LDS, 16-byte aligned; ROWS * 4 threads (tid = threadIdx.x); tile_m: index of the row tile.
+// PARTIAL: the work-group computes ONE part (chunks [c_begin, c_begin + PART_CHUNKS) of the Kd / 32) and stores the raw accumulators to
+// part_out[ROWS][128] (no bias, no activation, rows past M included: they are never read); the caller adds the parts up.
+template <bool RELU, int ROWS, bool PARTIAL = false>
 __device__ __forceinline__ void rowgemm128_tile(__bf16* b6_lds, int tid, int tile_m, const float* __restrict__ X, int ldx, const __bf16* __restrict__ Wc,
                                                 const float* __restrict__ bias, const int64_t* __restrict__ bias_idx, int bias_div,
-                                                float* __restrict__ Y, int ldy, int M, int Kd) {
+                                                float* __restrict__ Y, int ldy, int M, int Kd, int c_begin = 0,
+                                                float* __restrict__ part_out = nullptr) {
 #define B6TILE_FENCE() asm volatile("" ::: "memory")
 
   // bias: one vector (bias_idx == nullptr, bias_div == 0), or a table of 128-wide rows indexed by bias_idx[row] or row / bias_div
@@ -35,7 +43,7 @@ __device__ __forceinline__ void rowgemm128_tile(__bf16* b6_lds, int tid, int til
   const int lane = tid & 63, wv = tid >> 6;  // tid = threadIdx.x (a parameter so that a caller inside a loop can pass an opaque copy)
   const int l31 = lane & 31, hk = lane >> 5, rw = wv % NRW, cw = wv / NRW;  // v_mfma_f32_32x32x16_bf16: wave tile 32 rows x 64 columns
   const int m0 = tile_m * ROWS;
-  const int nchunk = Kd / BK;
+  const int nchunk = PARTIAL ? min(Kd / BK, c_begin + PART_CHUNKS) : Kd / BK;  // (one past the last chunk of this work-group)
   // weight staging: a chunk is 3 planes x 128 rows x 64 bytes = 1536 16-byte pieces, a straight copy of 24 KiB
   constexpr int WP = 1536 / T;  // pieces per thread (3 or 6)
   int w_dst[WP];
@@ -91,27 +99,28 @@ __device__ __forceinline__ void rowgemm128_tile(__bf16* b6_lds, int tid, int til
       *reinterpret_cast<bf16x4*>(dst + 2 * ROWS * BK) = l;
     }
   };
-  f32x16 acc[2];  // wave tile: 32 rows x 64 columns = two 32 x 32 accumulators
+  f32x16 acc[2], tot[2];  // wave tile: 32 rows x 64 columns = two 32 x 32 accumulators (the running part | the parts before it)
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[tt][r] = tot[tt][r] = 0.f;
 
 #pragma unroll
-  for (int c = 0; c < 4; ++c) load_x(c, c);
-  load_w(0, 0);
-  load_w(1, 1);
+  for (int c = 0; c < 4; ++c) load_x(c, c_begin + c);
+  load_w(0, c_begin);
+  load_w(1, c_begin + 1);
   B6TILE_FENCE();
   store_w(0, 0);
   store_x(0, 0);
-  load_w(0, 2);  // slot s holds chunk c with c % 2 == s: chunk 0 is staged, its slot takes chunk 2
-  load_x(0, 4);
+  load_w(0, c_begin + 2);  // slot s holds chunk c with c % 2 == s: chunk 0 is staged, its slot takes chunk 2
+  load_x(0, c_begin + 4);
   B6TILE_FENCE();
   __syncthreads();
   // fragments: lane (row or column l31, k half hk) of k-step ks reads the 16-byte slot 2 ks + hk of its row
   const int fx = (l31 >> 2) & 3;
   const int a_off = (32 * rw + l31) * BK, w_off = (64 * cw + l31) * BK;
-  for (int ch0 = 0; ch0 < nchunk; ch0 += 4) {  // ring slots are compile-time indices: four chunks per trip, the tail guarded (uniform)
+  static_assert(PART_CHUNKS == 4, "a trip of the chunk loop is one part");
+  for (int ch0 = c_begin; ch0 < nchunk; ch0 += 4) {  // ring slots are compile-time indices: four chunks per trip, the tail guarded (uniform)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ch = ch0 + u, buf = u & 1;
@@ -143,6 +152,23 @@ __device__ __forceinline__ void rowgemm128_tile(__bf16* b6_lds, int tid, int til
       B6TILE_FENCE();
       __syncthreads();
     }
+    if (!PARTIAL) {  // the part is complete: onto the sum of the parts before it
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          tot[tt][r] += acc[tt][r];
+          acc[tt][r] = 0.f;
+        }
+    }
+  }
+  if (PARTIAL) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        part_out[(32 * rw + (r & 3) + 8 * (r >> 2) + 4 * hk) * 128 + 64 * cw + 32 * tt + l31] = acc[tt][r];
+    return;
   }
   // D 32x32: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); 32 lanes = 128 contiguous bytes of a row
   const bool table = bias_idx != nullptr || bias_div > 0;
@@ -158,7 +184,7 @@ __device__ __forceinline__ void rowgemm128_tile(__bf16* b6_lds, int tid, int til
         const int64_t bi = bias_idx ? bias_idx[row] : row / bias_div;
         bv = bias[bi * 128 + col];
       }
-      float o = acc[tt][r] + bv;
+      float o = tot[tt][r] + bv;
       if (RELU) o = fmaxf(o, 0.f);
       Y[static_cast<int64_t>(row) * ldy + col] = o;
     }

@@ -5,7 +5,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o run -- python
 python3 - <<'PY'
 import csv, json
 rows = list(csv.DictReader(open("/tmp/ks/run_kernel_stats.csv")))
-for r in rows[:7]:
+import os
+for r in rows[:int(os.environ.get("TOP", "7"))]:
     print(f'{r["Name"][:70].replace("void diffab::", ""):72s} {r["Calls"]:>5s} {float(r["AverageNs"]) / 1e3:9.1f} us')
 try:
     d = json.loads([l for l in open("/tmp/ks_bench.json") if l.startswith("{")][-1])
