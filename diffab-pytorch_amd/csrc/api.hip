@@ -187,7 +187,9 @@ static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* 
 static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
                         const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
                         float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false,
-                        bool pair_prepared = false) {
+                        bool pair_prepared = false, const float* sched_beta = nullptr, int t_step = 0, const int* t_dev = nullptr) {
+  // sched_beta (reverse sampler): every patch is at step t_step (or *t_dev): the folded head tables take beta from the schedule and
+  // `beta` is only read by the unfolded path
   const StepBuffers b = carve_step(d, ws);
   const int rows = d->B * d->K, D = d->D;
   // DIFFAB_FLAG_PAIR_PLANES: the pair embedding as two fp16 planes (same bytes), attention's pair-tile products on the f16 matrix
@@ -206,7 +208,7 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
                    "denoiser head: null weight pointer");
     if (!weights_prepared)
       if (int rc = prepare_weights(d, w, b, flags, st)) return rc;
-    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, true)) return rc;
+    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, true, sched_beta, t_step, t_dev)) return rc;
   }
   // dense N = 128 layers of the folded path: bf16x6 from the prepared planes (slot), or the fp32 kernel
   const bool b6 = fold && use_b6_gemm(flags) && rowgemm128_b6_ok(res_ctx, D, b.h1, D, rows, D);
@@ -607,9 +609,10 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
   if (pair_ready)
     if (int rc = launch_pair_split(d, pair_ctx, b0.pair, st)) return rc;
   auto one_step = [&](int t, const int* t_dev) -> int {
-    if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
+    if (!fold)  // (the folded head tables read the schedule themselves: one launch less per step)
+      if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
     if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold,
-                              pair_ready))
+                              pair_ready, fold ? s->beta : nullptr, t, t_dev))
       return rc;
     return launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K, d->V, st,
                                         t_dev);

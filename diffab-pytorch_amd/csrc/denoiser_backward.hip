@@ -1211,6 +1211,287 @@ __global__ __launch_bounds__(256) void ipa_attn_bwd_keys_mfma_kernel(const float
   }
 }
 
+// The key-side pass on the bf16 matrix cores (six-term split, gemm_bf16x6.hip), K = 128, as two kernels of small work-groups.  The
+// products are latency chains (load, split, product, store); with the whole K x K image resident (144 KiB of LDS, one work-group per
+// CU, the three products one after the other: 112 us per layer at 128 patches, measured, and every single stage ablated changed
+// nothing) nothing overlaps them - so the image streams through a 24 KiB slab instead and 4-5 work-groups share a CU.
+//   ipa_attn_bwd_keys_tn_b6_kernel  (patch, head, image):  dk = g^T [q_s | q_pts | 1]  and  dv = P^T [do_s | dog]
+//       contraction over the rows i of image and operand: 32-row slabs in the layout of gemm_tn_b6_kernel (three bf16 planes, 16-byte
+//       chunks XOR-swizzled by row), both fragments through the transposing LDS read
+//   ipa_attn_bwd_keys_nn_b6_kernel  (patch, head):  dq = g [k_s | k_pts | 1]
+//       A fragments straight from global memory (a lane's 8 k values are 32 contiguous bytes of an image row, split in registers),
+//       the operand as planes in LDS, read through the transposing read
+// 96 matrix-pipe cycles per 16 x 16 x 32 block instead of 256 (f32 MFMA).  Same epilogues as ipa_attn_bwd_keys_mfma_kernel.
+namespace {
+typedef short kb_s16x4 __attribute__((ext_vector_type(4)));
+typedef short kb_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kb_bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int KB_IMG = 32 * 128, KB_OPD = 32 * 64;  // bf16 elements of one plane of one slab (image | operand)
+__device__ __forceinline__ int kb_off128(int row, int chunk) { return row * 128 + 8 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+// 64-column rows are 128 bytes: rows of equal parity share their banks, so the 32-byte column-tile of rows {r, r + 2, r + 8, r + 10}
+// (one transposing read) goes to four different chunk pairs
+__device__ __forceinline__ int kb_off64(int row, int chunk) { return row * 64 + 8 * (chunk ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)); }
+__device__ __forceinline__ void kb_split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = static_cast<__bf16>(x);
+  const float r = x - static_cast<float>(h);
+  m = static_cast<__bf16>(r);
+  l = static_cast<__bf16>(r - static_cast<float>(m));
+}
+typedef float kb_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void kb_store_planes(__bf16* dst, int plane, kb_v4 v) {  // 4 consecutive elements of a row -> the three planes
+  kb_bf16x4 hh, mm, ll;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    __bf16 a, b, d;
+    kb_split3(v[c], a, b, d);
+    hh[c] = a; mm[c] = b; ll[c] = d;
+  }
+  *reinterpret_cast<kb_bf16x4*>(dst) = hh;
+  *reinterpret_cast<kb_bf16x4*>(dst + plane) = mm;
+  *reinterpret_cast<kb_bf16x4*>(dst + 2 * plane) = ll;
+}
+__device__ __forceinline__ kb_bf16x8 kb_frag_tr(const __bf16* base, int off0, int off1) {
+  const kb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((kb_s16x4 __attribute__((address_space(3)))*)(base + off0));
+  const kb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((kb_s16x4 __attribute__((address_space(3)))*)(base + off1));
+  const kb_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(kb_bf16x8, v);
+}
+constexpr int KB_TA[6] = {1, 2, 0, 1, 0, 0}, KB_TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi): smallest first
+constexpr int KB_H = 8, KB_DS = 32, KB_NPT = 24, KB_K = 128;
+constexpr int KB_NP = 3 * KB_H * KB_DS + 3 * KB_H * KB_NPT, KB_F = KB_H * KB_DS + KB_H * 64 + KB_H * KB_NPT + KB_H * 8;
+constexpr int KB_OFF_KS = KB_H * KB_DS, KB_OFF_VS = 2 * KB_H * KB_DS, KB_OFF_GQ = 3 * KB_H * KB_DS, KB_OFF_GK = KB_OFF_GQ + KB_H * KB_NPT,
+              KB_OFF_GV = KB_OFF_GK + KB_H * KB_NPT;
+// blockIdx -> (patch, item): the `per` items of a patch (its heads, or (head, image) pairs) write neighbouring pieces of the SAME d proj
+// rows - 128- and 96-byte pieces of one line - so they must meet in ONE L2: consecutive work-groups go round-robin over the 8 XCDs, so
+// the patch is the index that varies fastest in steps of 8 and a patch's items are 8 work-groups apart (measured: see DESIGN 7)
+__device__ __forceinline__ void kb_patch_item(int bid, int B, int per, int& b, int& item) {
+  if (B % 8 == 0) {
+    b = (bid / (8 * per)) * 8 + (bid & 7);
+    item = (bid >> 3) % per;
+  } else {
+    b = bid / per;
+    item = bid % per;
+  }
+}
+// float4 c4 (0..15) of row `i` of a 64-column operand: 0 = [q_s | q_pts | 1], 1 = [do_s | dog | 0], 2 = [k_s | k_pts | 1]
+__device__ __forceinline__ kb_v4 kb_operand(int which, const float* __restrict__ proj, const float* __restrict__ dfeat,
+                                            const float* __restrict__ dogbuf, int64_t row, int h, int c4) {
+  kb_v4 v = {0.f, 0.f, 0.f, 0.f};
+  if (which == 1) {
+    if (c4 < 8) v = *reinterpret_cast<const kb_v4*>(dfeat + row * KB_F + h * KB_DS + 4 * c4);
+    else if (c4 < 14) v = *reinterpret_cast<const kb_v4*>(dogbuf + row * (KB_H * KB_NPT) + h * KB_NPT + 4 * (c4 - 8));
+  } else {
+    const float* pr = proj + row * KB_NP;
+    if (c4 < 8) v = *reinterpret_cast<const kb_v4*>(pr + (which == 0 ? 0 : KB_OFF_KS) + h * KB_DS + 4 * c4);
+    else if (c4 < 14) v = *reinterpret_cast<const kb_v4*>(pr + (which == 0 ? KB_OFF_GQ : KB_OFF_GK) + h * KB_NPT + 4 * (c4 - 8));
+    else if (c4 == 14) v[0] = 1.0f;  // column 56: the plain sum over the contraction index
+  }
+  return v;
+}
+// d k / d q epilogue of one accumulator pair (columns 32..47 | 48..63 of the product: points and the plain sum in column 56)
+// own0 / own1: the row's own point components l15 / 16 + l15 (requested with the kernel's first loads: at the tail their latency was 20
+// of the transposed kernel's 89 us)
+__device__ __forceinline__ void kb_store_points(float* drow, float own0, float own1, float cp, float a0, float a1, int lane, int l15) {
+  const float tot = __shfl(a1, (lane & 48) | 8);  // column 56 = 48 + 8
+  drow[l15] = cp * (a0 - own0 * tot);
+  if (l15 < 8) drow[16 + l15] = cp * (a1 - own1 * tot);
+}
+}  // namespace
+
+// blockIdx.x = (patch, head, image): image 0 = g with [q_s | q_pts | 1] -> d k; image 1 = P with [do_s | dog] -> d v.  256 threads,
+// wave w: output rows (= image columns = keys) 32 w .. 32 w + 31, all 64 columns.  LDS: one slab of image and operand planes (30 KiB).
+__global__ __launch_bounds__(256) void ipa_attn_bwd_keys_tn_b6_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ dfeat, const float* __restrict__ G,
+                                                                      const float* __restrict__ P, const float* __restrict__ dogbuf,
+                                                                      float* __restrict__ dproj, int B) {
+  __shared__ __attribute__((aligned(16))) __bf16 img[3 * KB_IMG];
+  __shared__ __attribute__((aligned(16))) __bf16 opd[3 * KB_OPD];
+  int b, item;
+  kb_patch_item(blockIdx.x, B, 2 * KB_H, b, item);
+  const int which = item & 1, h = item >> 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int64_t prow0 = static_cast<int64_t>(b) * KB_K;
+  const float* src = (which ? P : G) + (static_cast<int64_t>(b) * KB_H + h) * KB_K * KB_K;
+  // the whole image and operand are requested up front (one latency), then staged slab by slab: image thread -> rows tid / 32 + 8 j
+  // (j = 0..3) of each slab, float4 tid % 32; operand thread -> float4 tid + 256 k of the slab's [32][16]
+  const int s_row = tid >> 5, s_f4 = tid & 31;
+  kb_v4 ri[4][4], ro[4][2];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      ri[sl][j] = __builtin_nontemporal_load(reinterpret_cast<const kb_v4*>(src + (32 * sl + s_row + 8 * j) * KB_K + 4 * s_f4));
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int idx = tid + 256 * k2;
+      ro[sl][k2] = kb_operand(which, proj, dfeat, dogbuf, prow0 + 32 * sl + (idx >> 4), h, idx & 15);
+    }
+  }
+  float own[2][4][2];  // d k: the key rows' own points (epilogue)
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* o = proj + (prow0 + 16 * (2 * wv + at) + 4 * g + r) * KB_NP + KB_OFF_GK + h * KB_NPT;
+      own[at][r][0] = which == 0 ? o[l15] : 0.f;
+      own[at][r][1] = (which == 0 && l15 < 8) ? o[16 + l15] : 0.f;
+    }
+  const int q = l15 >> 2, pp = l15 & 3;
+  int offA[2][2], offB[4][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int row = 8 * g + 4 * rd + q;
+#pragma unroll
+    for (int at = 0; at < 2; ++at) offA[at][rd] = kb_off128(row, 2 * (2 * wv + at) + (pp >> 1)) + 4 * (pp & 1);
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) offB[bt][rd] = kb_off64(row, 2 * bt + (pp >> 1)) + 4 * (pp & 1);
+  }
+  kb_v4 acc[2][4];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) acc[at][bt] = kb_v4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    if (sl > 0) __syncthreads();  // every wave is done with the previous slab
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kb_store_planes(img + kb_off128(s_row + 8 * j, s_f4 >> 1) + 4 * (s_f4 & 1), KB_IMG, ri[sl][j]);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int idx = tid + 256 * k2;
+      kb_store_planes(opd + kb_off64(idx >> 4, (idx & 15) >> 1) + 4 * (idx & 1), KB_OPD, ro[sl][k2]);
+    }
+    __syncthreads();
+    kb_bf16x8 fa[2][3], fb[4][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int at = 0; at < 2; ++at) fa[at][p] = kb_frag_tr(img + p * KB_IMG, offA[at][0], offA[at][1]);
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt) fb[bt][p] = kb_frag_tr(opd + p * KB_OPD, offB[bt][0], offB[bt][1]);
+    }
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt)
+          acc[at][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][KB_TA[term]], fb[bt][KB_TB[term]], acc[at][bt], 0, 0, 0);
+  }
+  // acc[at][bt][r]: key 16 (2 wv + at) + 4 g + r, column 16 bt + l15
+  const float scale_s = 0.17677669529663687f, scale_p = -0.5f * 0.16666666666666666f;
+  const float cp = -2.0f * scale_p * gamma[h];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = prow0 + 16 * (2 * wv + at) + 4 * g + r;
+      float* drow = dproj + row * KB_NP;
+      if (which == 0) {
+        drow[KB_OFF_KS + h * KB_DS + l15] = acc[at][0][r] * scale_s;
+        drow[KB_OFF_KS + h * KB_DS + 16 + l15] = acc[at][1][r] * scale_s;
+        kb_store_points(drow + KB_OFF_GK + h * KB_NPT, own[at][r][0], own[at][r][1], cp, acc[at][2][r], acc[at][3][r], lane, l15);
+      } else {
+        drow[KB_OFF_VS + h * KB_DS + l15] = acc[at][0][r];
+        drow[KB_OFF_VS + h * KB_DS + 16 + l15] = acc[at][1][r];
+        drow[KB_OFF_GV + h * KB_NPT + l15] = acc[at][2][r];
+        if (l15 < 8) drow[KB_OFF_GV + h * KB_NPT + 16 + l15] = acc[at][3][r];
+      }
+    }
+}
+
+// blockIdx.x = (patch, head): d q = g [k_s | k_pts | 1].  256 threads, wave w: query rows 32 w .. 32 w + 31.  LDS: the operand's planes
+// [4 slabs of 32 keys][3][32][64] (48 KiB).
+__global__ __launch_bounds__(256) void ipa_attn_bwd_keys_nn_b6_kernel(const float* __restrict__ proj, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ G, float* __restrict__ dproj, int B) {
+  __shared__ __attribute__((aligned(16))) __bf16 opd[4 * 3 * KB_OPD];
+  int b, h;
+  kb_patch_item(blockIdx.x, B, KB_H, b, h);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int64_t prow0 = static_cast<int64_t>(b) * KB_K;
+  const float* Gi = G + (static_cast<int64_t>(b) * KB_H + h) * KB_K * KB_K;
+  // A: lane (row l15 of row tile at, k group g) of k step ks holds g[32 wv + 16 at + l15][32 ks + 8 g .. + 7]: two float4
+  kb_v4 ra[4][2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int at = 0; at < 2; ++at) {
+      const float* p = Gi + (32 * wv + 16 * at + l15) * KB_K + 32 * ks + 8 * g;
+      ra[ks][at][0] = __builtin_nontemporal_load(reinterpret_cast<const kb_v4*>(p));
+      ra[ks][at][1] = __builtin_nontemporal_load(reinterpret_cast<const kb_v4*>(p + 4));
+    }
+  {
+    kb_v4 ro[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+      const int idx = tid + 256 * k8;
+      ro[k8] = kb_operand(2, proj, nullptr, nullptr, prow0 + (idx >> 4), h, idx & 15);
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+      const int idx = tid + 256 * k8, j = idx >> 4;
+      kb_store_planes(opd + (j >> 5) * (3 * KB_OPD) + kb_off64(j & 31, (idx & 15) >> 1) + 4 * (idx & 1), KB_OPD, ro[k8]);
+    }
+  }
+  float own[2][4][2];  // the query rows' own points (epilogue)
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* o = proj + (prow0 + 32 * wv + 16 * at + 4 * g + r) * KB_NP + KB_OFF_GQ + h * KB_NPT;
+      own[at][r][0] = o[l15];
+      own[at][r][1] = l15 < 8 ? o[16 + l15] : 0.f;
+    }
+  const int q = l15 >> 2, pp = l15 & 3;
+  int offB[4][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) offB[bt][rd] = kb_off64(8 * g + 4 * rd + q, 2 * bt + (pp >> 1)) + 4 * (pp & 1);
+  kb_v4 acc[2][4];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) acc[at][bt] = kb_v4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kb_bf16x8 fa[2][3], fb[4][3];
+#pragma unroll
+    for (int at = 0; at < 2; ++at)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 a, bq, cq;
+        kb_split3(ra[ks][at][e >> 2][e & 3], a, bq, cq);
+        fa[at][0][e] = a; fa[at][1][e] = bq; fa[at][2][e] = cq;
+      }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt) fb[bt][p] = kb_frag_tr(opd + (ks * 3 + p) * KB_OPD, offB[bt][0], offB[bt][1]);
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt)
+          acc[at][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][KB_TA[term]], fb[bt][KB_TB[term]], acc[at][bt], 0, 0, 0);
+  }
+  const float scale_s = 0.17677669529663687f, scale_p = -0.5f * 0.16666666666666666f;
+  const float cp = -2.0f * scale_p * gamma[h];  // d q_pts = 2 scale_p gamma (q sum g - sum g k) = cp (sum g k - q sum g)
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = prow0 + 32 * wv + 16 * at + 4 * g + r;
+      float* drow = dproj + row * KB_NP;
+      drow[h * KB_DS + l15] = acc[at][0][r] * scale_s;
+      drow[h * KB_DS + 16 + l15] = acc[at][1][r] * scale_s;
+      kb_store_points(drow + KB_OFF_GQ + h * KB_NPT, own[at][r][0], own[at][r][1], cp, acc[at][2][r], acc[at][3][r], lane, l15);
+    }
+}
+
 // dA_kv[b][h][i][j] = do_s[i] . v_s[j] + dog[i] . v_pts[j] on the MFMA (benchmark head geometry): work-group = (patch, head, 64
 // query rows), the value side [j][v_s (32) | v_pts (24) | 0...] staged once in LDS, A = [do_s | dog] of 16 query rows per wave in
 // registers (K-contiguous float4s, k order permuted identically for both operands).  The pair term do_e . e is added by the row pass.
@@ -1565,11 +1846,17 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
         DIFFAB_REQUIRE(rows % 32 == 0, DIFFAB_ERR_UNSUPPORTED, "attention backward (MFMA path): B K = %d must be a multiple of 32", rows);
         wb_rows = rows / 32;  // one partial row per 32 query rows (launch_pair_stream_bwd)
         // key side straight from the [b][h][i][j] images (g in dAkv, P in Pn): no transposed copies, no VALU row pass at all
+        if (d->K == 128) {  // bf16 matrix cores: d k and d v (transposed products), d q
+          hipLaunchKernelGGL(ipa_attn_bwd_keys_tn_b6_kernel, dim3(d->B * H * 2), dim3(256), 0, st, proj, lw->gamma, dfeat, dAkv, Pn, dogbuf,
+                             dproj, d->B);
+          hipLaunchKernelGGL(ipa_attn_bwd_keys_nn_b6_kernel, dim3(d->B * H), dim3(256), 0, st, proj, lw->gamma, dAkv, dproj, d->B);
+        } else {
         hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<0, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf,
                            dproj, d->K);
         hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<1, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Pn, dogbuf,
                            dproj, d->K);
         hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf, dproj, d->K);
+        }
       } else {
         DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 0>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_mr)));

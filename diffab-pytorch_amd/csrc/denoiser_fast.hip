@@ -1263,24 +1263,26 @@ __global__ __launch_bounds__(64) void fold_embed_table_kernel(const float* __res
 }
 __global__ void fold_beta_table_kernel(const float* __restrict__ beta, const float* __restrict__ Wa, const float* __restrict__ ba,
                                        const float* __restrict__ Wb_, const float* __restrict__ bb, const float* __restrict__ Wc,
-                                       const float* __restrict__ bc, int D, int B, float* __restrict__ tab) {
+                                       const float* __restrict__ bc, int D, int B, float* __restrict__ tab,
+                                       const float* __restrict__ sched_beta, int t, const int* __restrict__ t_dev) {
   const int b = blockIdx.x, hd = blockIdx.y, n = threadIdx.x;  // tab[hd][b][n]
   if (b >= B || n >= D) return;
   const float* W = hd == 0 ? Wa : (hd == 1 ? Wb_ : Wc);
   const float* bias = hd == 0 ? ba : (hd == 1 ? bb : bc);
-  const float be = beta[b];
+  // beta per patch, or (reverse sampler: every patch is at the same step) the schedule's entry t, t from the device under graph replay
+  const float be = sched_beta ? sched_beta[t_dev ? *t_dev : t] : beta[b];
   const float* wr = W + n * (D + 3) + D;
   tab[(static_cast<int64_t>(hd) * B + b) * D + n] = ((be * wr[0] + sinf(be) * wr[1]) + cosf(be) * wr[2]) + bias[n];
 }
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
-                       hipStream_t st, bool emb_tab_ready) {
+                       hipStream_t st, bool emb_tab_ready, const float* sched_beta, int t, const int* t_dev) {
   if (!emb_tab_ready) {  // weights only: the reverse sampler builds it once per trajectory, not once per step
     hipLaunchKernelGGL(fold_embed_table_kernel, dim3(25, (d->D + 7) / 8), dim3(64), 0, st, w->seq_emb, w->res_w0, w->res_b0, d->D, 25, emb_tab);
     DIFFAB_LAUNCH_CHECK();
   }
-  if (beta == nullptr) return DIFFAB_OK;
+  if (beta == nullptr && sched_beta == nullptr) return DIFFAB_OK;
   hipLaunchKernelGGL(fold_beta_table_kernel, dim3(d->B, 3), dim3(d->D), 0, st, beta, w->coord.w0, w->coord.b0, w->orient.w0, w->orient.b0,
-                     w->seq.w0, w->seq.b0, d->D, d->B, beta_tab);
+                     w->seq.w0, w->seq.b0, d->D, d->B, beta_tab, sched_beta, t, t_dev);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

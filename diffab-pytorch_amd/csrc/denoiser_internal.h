@@ -75,7 +75,8 @@ size_t ipa_layer_planes_bytes();
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
-                       hipStream_t st, bool emb_tab_ready = false);  // beta == nullptr: the weights-only embedding table alone
+                       hipStream_t st, bool emb_tab_ready = false,
+                       const float* sched_beta = nullptr, int t = 0, const int* t_dev = nullptr);  // beta = sched_beta[t] for every patch  // beta == nullptr: the weights-only embedding table alone
 
 // attention_split.hip: the attention of one IPA layer as three launches (logits | pair stream | P x V) exchanging the
 // (B, 8, K, K) logits / probabilities through SP - the form the training tape keeps; single key chunk only (K = 64, 128)
