@@ -378,13 +378,17 @@ constexpr int TI = 16;  // query residues per work-group
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
-template <int NT, bool MULTI, bool PLANES = false>
+// TAPE (single-chunk, fp32 pair stream: the forward of a training step): the normalised probabilities and the squared point distances
+// are left in tape_p / tape_d2 ([b][h][i][j], what ipa_logits_kernel<true> + ipa_pair_stream_kernel leave) for the backward.
+template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
-                                                            unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr) {
+                                                            unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr,
+                                                            float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr) {
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
+  static_assert(!TAPE || (!MULTI && !PLANES), "the tape form is the single-chunk fp32-pair kernel");
   const int NC = MULTI ? NC_arg : 1;
   // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
   // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
@@ -617,6 +621,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
           }
           const float d2 = d2v[0] + d2v[1];
           S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
+          if constexpr (TAPE) tape_d2[((static_cast<int64_t>(b) * AH + h) * K + i0 + 4 * q + r) * K + jt * 16 + l15] = d2;
         }
         if (c == 0 && jt == 0) stamp(6);
         if (c == 0 && jt == 3) stamp(7);
@@ -986,6 +991,10 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
         const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
+        if constexpr (TAPE) {  // P[i = l15][16 jt + 4 q ..]: the image holds exp(logit - M), the row's 1 / L is in st_inv
+          const float pinv = st_inv[l15 * AH + h];
+          *reinterpret_cast<f32x4*>(tape_p + ((static_cast<int64_t>(b) * AH + h) * K + i0 + l15) * K + jt * 16 + 4 * q) = pa * pinv;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int stp = jt * 4 + r;
@@ -1439,10 +1448,11 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   }
   // Training tape (sp_keep != nullptr, K = 64 / 128): the attention as three launches that leave the probabilities and the squared point
   // distances on the tape for the backward (attention_split.hip); ws has no tail there.  Everything else: the fused kernel.
-  if (sp_keep != nullptr && attention_split_supported(d)) {
+  if (sp_keep != nullptr && attention_split_supported(d) && !(d->K == 128 && d2_keep != nullptr)) {
     if (int rc = launch_attention_split(d, proj, e, R, t, w->w_bias, w->gamma, feat, sp_keep, st, d2_keep)) return rc;
     return to_out();
   }
+  const bool tape = sp_keep != nullptr && attention_split_supported(d);  // K = 128: the fused kernel writes the tape itself
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
   const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
@@ -1460,7 +1470,12 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                        w->gamma, feat, d->B, nc, g_attn_stamps, esc);                                                                 \
     timer_end(st);                                                                                                                    \
   } while (0)
-  if (use_planes) {
+  if (tape) {
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<8, false, false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<8, false, false, true>), grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat,
+                       d->B, nc, nullptr, nullptr, sp_keep, d2_keep);
+  } else if (use_planes) {
     if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, true);
     else if (nt == 8) ATTN_LAUNCH(8, true, true);
     else if (nc == 1) ATTN_LAUNCH(4, false, true);
