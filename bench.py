@@ -195,6 +195,38 @@ def other_configs(model, dims, flags):
         res["k256_sampling"] = f"failed: {type(ex).__name__}: {ex}"
     gc.collect()
     torch.cuda.empty_cache()
+    try:  # the headline shape with DIFFAB_FLAG_SKIP_UNUSED_ROWS: same samples bit for bit, the last layer's attention only for the row
+        # tiles that hold a generated residue.  NOT the headline: the work skipped depends on the mask (synthetic: one CDR-like segment
+        # of 5..20 residues per patch), the headline runs every row of every layer as the reference does.
+        B, K, steps = 256, 128, 20
+        inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=0, coord_sigma=10.0).items()}
+        seq, x, O = inp["seq_idx"].clone(), inp["translations"].clone(), inp["orientations"].clone()
+        hd, w = model.denoiser.hip_dims(B, K), model.denoiser.hip_weights()
+        sd_dev, tab = model._sched_on_device(), model._reverse_so3().struct()
+        ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
+        _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(inp["generation_mask"]), 2024, 0, B, K, model.T,
+                                          _hip.stream_ptr()), "sample_init")
+        lean = {}
+        for name, fl in (("all_rows", flags), ("skip_unused_rows", flags | _hip.FLAG_SKIP_UNUSED_ROWS)):
+            for n_ in (3, steps):  # warm-up, then timed
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _hip.check(lib.diffab_sample_loop(C.byref(hd), C.byref(w.struct), C.byref(sd_dev.struct), C.byref(tab), _hip.ptr(seq), _hip.ptr(x),
+                                                  _hip.ptr(O), _hip.ptr(inp["res_context_emb"]), _hip.ptr(inp["pair_context_emb"]),
+                                                  _hip.ptr(inp["generation_mask"]), 2024, 0, model.T, model.T - n_, _hip.ptr(ws), ws.numel(), fl,
+                                                  _hip.stream_ptr()), "sample_loop")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            lean[name] = dt / steps * 1e3  # (includes the once-per-call plane split, 0.5 ms over 20 steps, in both)
+        tiles = inp["generation_mask"].view(B, K // 16, 16).any(-1).float().mean().item()
+        res["skip_unused_rows"] = {"patches": B, "K": K, "steps": steps, "ms_per_step_all_rows": lean["all_rows"],
+                                   "ms_per_step": lean["skip_unused_rows"], "last_layer_row_tiles_run": tiles,
+                                   "what": "DIFFAB_FLAG_SKIP_UNUSED_ROWS (opt-in): bitwise the same samples; not the headline"}
+        del inp, seq, x, O, ws
+    except Exception as ex:  # noqa: BLE001
+        res["skip_unused_rows"] = f"failed: {type(ex).__name__}: {ex}"
+    gc.collect()
+    torch.cuda.empty_cache()
     try:  # BASELINE config 1: ONE K=128 patch through the whole 100-step reverse loop (eager launches, and one captured step replayed)
         B, K = 1, 128
         inp = {k: v.cuda() for k, v in syn.patches(B, K, dims, seed=3).items()}

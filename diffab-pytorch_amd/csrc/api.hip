@@ -134,13 +134,14 @@ static StepBuffers carve_step(const diffab_dims* d, void* ws) {
 static int ipa_layer_dispatch(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R,
                               const float* t, float* y, float* ws, uint32_t flags, hipStream_t st, float* sp_keep = nullptr,
                               float* d2_keep = nullptr, const void* planes = nullptr, const float* pair_planes = nullptr,
-                              bool taped = false) {  // taped: ws is a slot of the training tape (the backward reads proj and feat)
+                              bool taped = false,  // taped: ws is a slot of the training tape (the backward reads proj and feat)
+                              const unsigned char* tile_needed = nullptr) {
   DIFFAB_REQUIRE(w && w->gamma && w->wq_s && w->wk_s && w->wv_s && (w->w_bias || d->C == 0) && w->wq_p && w->wk_p && w->wv_p && w->w_out &&
                      w->b_out,
                  DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   if (!(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d))
     return ipa_layer_fast(d, w, x, e, R, t, y, ws, st, sp_keep, d2_keep, planes, pair_planes, (flags & DIFFAB_FLAG_FP32_GEMM) != 0,
-                          taped);
+                          taped, tile_needed);
   return ipa_layer_generic(d, w, x, e, R, t, y, ws, st);
 }
 
@@ -187,7 +188,8 @@ static int prepare_weights(const diffab_dims* d, const diffab_denoiser_weights* 
 static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, const int64_t* seq_t, const float* x_t, const float* O_t,
                         const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
                         float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false,
-                        bool pair_prepared = false, const float* sched_beta = nullptr, int t_step = 0, const int* t_dev = nullptr) {
+                        bool pair_prepared = false, const float* sched_beta = nullptr, int t_step = 0, const int* t_dev = nullptr,
+                        const unsigned char* last_layer_tiles = nullptr) {  // row tiles of the LAST layer whose outputs are read
   // sched_beta (reverse sampler): every patch is at step t_step (or *t_dev): the folded head tables take beta from the schedule and
   // `beta` is only read by the unfolded path
   const StepBuffers b = carve_step(d, ws);
@@ -235,7 +237,8 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   float *cur = b.hA, *nxt = b.hB;
   for (int l = 0; l < d->NL; ++l) {
     const void* planes = (fold && use_b6_gemm(flags)) ? b.planes + l * ipa_layer_planes_bytes() : nullptr;
-    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes, pair_planes))
+    if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes, pair_planes,
+                                    false, l == d->NL - 1 ? last_layer_tiles : nullptr))
       return rc;
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
@@ -321,6 +324,7 @@ static int check_denoiser_weights(const diffab_dims* d, const diffab_denoiser_we
 struct SampleBuffers {
   float *beta, *eps, *O0, *post;
   int* t_dev;  // the current timestep in device memory (graph replay)
+  unsigned char* tiles;  // [B][K / 16]: row tiles with a generated residue (DIFFAB_FLAG_SKIP_UNUSED_ROWS)
   void* step;
   size_t bytes;
 };
@@ -334,6 +338,7 @@ static SampleBuffers carve_sample(const diffab_dims* d, void* ws) {
   s.O0 = c.take<float>(rows * 9);
   s.post = c.take<float>(rows * d->V);
   s.t_dev = c.take<int>(64);
+  s.tiles = c.take<unsigned char>(static_cast<size_t>(d->B) * ((d->K + 15) / 16));
   const size_t step_bytes = carve_step(d, nullptr).bytes;
   s.step = c.take<char>(step_bytes);
   s.bytes = c.bytes();
@@ -608,11 +613,19 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
   const bool pair_ready = use_pair_planes(d, flags, pair_ctx, b0);
   if (pair_ready)
     if (int rc = launch_pair_split(d, pair_ctx, b0.pair, st)) return rc;
+  // DIFFAB_FLAG_SKIP_UNUSED_ROWS: the step's outputs (eps, O0, posterior) are read for GENERATED residues only (reverse_update leaves
+  // the others alone), so the last layer's attention is needed only for row tiles that contain one; every other layer feeds keys and
+  // values of all rows to the next.  Same trajectory, bit for bit; the work skipped depends on the mask, so bench.py's headline keeps it off.
+  const unsigned char* tiles = nullptr;
+  if ((flags & DIFFAB_FLAG_SKIP_UNUSED_ROWS) && fold && d->K % 16 == 0) {
+    if (int rc = launch_tiles_needed(gen_mask, d->B, d->K, sb.tiles, st)) return rc;
+    tiles = sb.tiles;
+  }
   auto one_step = [&](int t, const int* t_dev) -> int {
     if (!fold)  // (the folded head tables read the schedule themselves: one launch less per step)
       if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
     if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold,
-                              pair_ready, fold ? s->beta : nullptr, t, t_dev))
+                              pair_ready, fold ? s->beta : nullptr, t, t_dev, tiles))
       return rc;
     return launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K, d->V, st,
                                         t_dev);

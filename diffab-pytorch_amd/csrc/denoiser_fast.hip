@@ -386,7 +386,8 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr,
-                                                            float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr) {
+                                                            float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr,
+                                                            const unsigned char* __restrict__ tile_needed = nullptr) {
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
   static_assert(!TAPE || (!MULTI && !PLANES), "the tape form is the single-chunk fp32-pair kernel");
   const int NC = MULTI ? NC_arg : 1;
@@ -425,6 +426,9 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
     b = bid / ntile;
     tile = bid % ntile;
   }
+  // tile_needed (reverse sampler, last layer, DIFFAB_FLAG_SKIP_UNUSED_ROWS): the outputs of this layer are read for generated residues
+  // only - a row tile without one leaves at once (uniform; its feature rows keep the previous layer's values, which nothing reads)
+  if (tile_needed != nullptr && !tile_needed[b * ntile + tile]) return;
   const int i0 = tile * TI;
   const int tid = threadIdx.x, lane0 = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // (the wave index as a scalar: the addresses built from it stay in SGPRs, which takes the chunked instantiations from 13 spilled VGPRs
@@ -1399,7 +1403,7 @@ size_t ipa_fast_workspace_floats(const diffab_dims* d) { return ipa_ws_operands_
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, float* sp_keep, float* d2_keep, const void* planes, const float* pair_planes,
-                   bool fp32_gemm, bool taped) {
+                   bool fp32_gemm, bool taped, const unsigned char* tile_needed) {
   const int rows = d->B * d->K, D = d->D;
   float* proj = ws;
   float* feat = ws + static_cast<size_t>(rows) * ANP;
@@ -1467,7 +1471,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
     hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, PLANES_>), grid, dim3(512), lds, st, proj, e_arg, R, t, w->w_bias,          \
-                       w->gamma, feat, d->B, nc, g_attn_stamps, esc);                                                                 \
+                       w->gamma, feat, d->B, nc, g_attn_stamps, esc, nullptr, nullptr, tile_needed);                                  \
     timer_end(st);                                                                                                                    \
   } while (0)
   if (tape) {

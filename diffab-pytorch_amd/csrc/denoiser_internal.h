@@ -23,7 +23,8 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                    const void* planes = nullptr,  // ipa_layer_split_weights() output; nullptr: split per call into the workspace tail
                    const float* pair_planes = nullptr,  // launch_pair_split() output: attention's pair-tile products on f16 MFMA
                    bool fp32_gemm = false,
-                   bool taped = false);  // ws is a slot of the training tape: proj and feat are read by the backward (no scratch use)  // DIFFAB_FLAG_FP32_GEMM: dense products on the f32-input MFMA kernels
+                   bool taped = false,   // ws is a slot of the training tape: proj and feat are read by the backward (no scratch use)
+                   const unsigned char* tile_needed = nullptr);  // [B][K / 16]: row tiles whose outputs are read (nullptr: all)  // DIFFAB_FLAG_FP32_GEMM: dense products on the f32-input MFMA kernels
 // fp16 planes of the pair embedding for the fused attention kernel (K = 64 / 128): pair_planes_floats(d) floats, 256-byte aligned
 bool pair_planes_supported(const diffab_dims* d);
 size_t pair_planes_floats(const diffab_dims* d);
@@ -141,6 +142,7 @@ int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab,
                                  int64_t first_patch, int B, int K, int V, hipStream_t st,
                                  const int* t_dev = nullptr);  // t_dev: read the timestep from device memory (graph replay)
 int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st, const int* t_dev = nullptr);
+int launch_tiles_needed(const uint8_t* gm, int B, int K, unsigned char* out, hipStream_t st);  // [B][K / 16]: any generated residue in the tile
 int launch_set_int(int* p, int v, hipStream_t st);
 int launch_dec_int(int* p, hipStream_t st);
 

@@ -790,6 +790,19 @@ int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
+__global__ void tiles_needed_kernel(const uint8_t* __restrict__ gm, int64_t ntiles, unsigned char* __restrict__ out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;  // (patch, 16-row tile): K % 16 == 0
+  if (i >= ntiles) return;
+  unsigned char any = 0;
+  for (int r = 0; r < 16; ++r) any |= gm[i * 16 + r];
+  out[i] = any != 0;
+}
+int launch_tiles_needed(const uint8_t* gm, int B, int K, unsigned char* out, hipStream_t st) {
+  const int64_t n = static_cast<int64_t>(B) * (K / 16);
+  hipLaunchKernelGGL(tiles_needed_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, gm, n, out);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
 int launch_set_int(int* p, int v, hipStream_t st) {
   hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, p, v);
   DIFFAB_LAUNCH_CHECK();

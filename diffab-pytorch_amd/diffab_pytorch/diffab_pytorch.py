@@ -825,7 +825,8 @@ class DiffAb(_ModuleBase):
                res_context_emb=None, pair_context_emb=None, residue_mask=None, backbone_dihedrals=None, pairwise_dihedrals=None,
                distmat=None, atom_mask=None, chain_idx=None, residue_idx=None, generate_structure: bool = True,
                generate_sequence: bool = True, seed: Optional[int] = None, first_patch: int = 0, t_start: Optional[int] = None,
-               t_stop: int = 0, init: bool = True, flags: int = 0, graph: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+               t_stop: int = 0, init: bool = True, flags: int = 0, graph: Optional[bool] = None,
+               skip_unused_rows: bool = False) -> Dict[str, torch.Tensor]:
         """Reverse diffusion t_start .. t_stop+1 (default T .. 1) on the generated residues (the reference's `sample` is a stub,
         diffab_pytorch.py:770-776; the loop is build-defined).
 
@@ -839,7 +840,10 @@ class DiffAb(_ModuleBase):
         ``graph=True``: replay one captured step as a hipGraph instead of ~45 launches per step (same kernels, bitwise the same
         result; the call then waits for the trajectory).  Off by default: measured at BASELINE config 1 (B = 1, K = 128, 100 steps)
         it changes nothing - 145 ms eager, 146 ms replayed - because the host already runs ahead of the device there; a step is a
-        chain of ~45 dependent kernels on 8-work-group grids (1.45 ms), not 45 launch overheads."""
+        chain of ~45 dependent kernels on 8-work-group grids (1.45 ms), not 45 launch overheads.
+        ``skip_unused_rows=True``: a step's outputs are used for generated residues only, so the LAST layer's attention runs only for the
+        16-row tiles that contain one (`DIFFAB_FLAG_SKIP_UNUSED_ROWS`): bitwise the same samples, less work when few residues are
+        generated (one CDR: 5-7 of the 8 row tiles of the last layer are skipped)."""
         if generation_mask is None:
             raise ValueError("sample() needs generation_mask: which residues to generate")
         if res_context_emb is None or pair_context_emb is None:
@@ -878,6 +882,8 @@ class DiffAb(_ModuleBase):
         ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(dims)))
         if graph:
             flags |= _hip.FLAG_GRAPH_SAMPLER
+        if skip_unused_rows:
+            flags |= _hip.FLAG_SKIP_UNUSED_ROWS
         if init:
             _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, self.T,
                                               _hip.stream_ptr()), "diffab_sample_init")

@@ -76,6 +76,12 @@ extern "C" {
                                          eager trajectory.  The call drains its private replay stream before it returns (the graph
                                          must outlive its launches).  Measured at B = 1, K = 128: no gain (the host already runs
                                          ahead of the device; a step is 45 dependent small-grid kernels), hence opt-in. */
+#define DIFFAB_FLAG_SKIP_UNUSED_ROWS 256u /* diffab_sample_loop (MFMA path, K % 16 == 0): a step's outputs are read for GENERATED residues
+                                         only (diffab_reverse_update leaves the others alone), so the LAST layer's attention runs only
+                                         for the 16-row tiles that contain one (every other layer feeds all rows' keys and values to the
+                                         next).  Bitwise the same trajectory; the work skipped depends on the mask - with one CDR-like
+                                         segment per patch 5-7 of the 8 row tiles of the last layer - so it is opt-in and bench.py's
+                                         headline keeps it off (reported separately). */
 
 /* Model and batch geometry.  Reference ctor: diffab_pytorch.py:629-647. */
 typedef struct {

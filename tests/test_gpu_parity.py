@@ -654,6 +654,32 @@ def test_sample_loop_shard_invariance_and_determinism(hip):
     assert not torch.equal(other["translations"], full["translations"])
 
 
+def test_skip_unused_rows_sampler_is_bitwise_the_full_sampler(hip):
+    """DIFFAB_FLAG_SKIP_UNUSED_ROWS: the last layer's attention only for row tiles with a generated residue = the full loop, bit for bit
+    (MFMA path, K = 128 and the chunked K = 256; a patch without any generated residue, one with all of them; eager and graph replay)."""
+    from diffab_pytorch import DiffAb
+
+    bd = dict(syn.BENCH_DIMS, NL=2)
+    torch.manual_seed(0)
+    big = DiffAb(bd["D"], bd["C"], bd["NL"], bd["DS"], bd["PQ"], bd["PV"], bd["H"]).cuda()
+    for B_, K_ in ((5, 128), (2, 256)):
+        bi = {k: v.cuda() for k, v in syn.patches(B_, K_, bd, seed=31).items()}
+        gm = bi["generation_mask"].clone()
+        gm[0] = False   # nothing to generate: every tile of the last layer is skipped
+        gm[1] = True    # everything generated: nothing is skipped
+        skipped = 1.0 - gm.view(B_, K_ // 16, 16).any(-1).float().mean().item()
+        assert 0.3 < skipped < 0.95, skipped
+        kw = dict(res_context_emb=bi["res_context_emb"], pair_context_emb=bi["pair_context_emb"], generation_mask=gm, seed=9, t_start=40,
+                  t_stop=28)
+        full = big.sample(bi["seq_idx"], bi["translations"], bi["orientations"], **kw)
+        for graph in (False, True):
+            lean = big.sample(bi["seq_idx"], bi["translations"], bi["orientations"], skip_unused_rows=True, graph=graph, **kw)
+            for k in full:
+                assert torch.equal(full[k], lean[k]), (K_, graph, k)
+        assert torch.isfinite(full["translations"]).all()
+        assert torch.equal(full["translations"][0], bi["translations"][0])  # (the patch without generated residues is untouched)
+
+
 def test_graph_sampler_is_bitwise_the_eager_sampler(hip):
     """DIFFAB_FLAG_GRAPH_SAMPLER: one captured reverse step (timestep in device memory) replayed as a hipGraph = the eager loop, bit
     for bit, on the generic path (unit dims) and on the MFMA path at BASELINE config 1's shape (B = 1, K = 128, 100 steps)."""
