@@ -189,7 +189,8 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
                         const float* res_ctx, const float* pair_ctx, const float* beta, float* out_eps, float* out_O0, float* out_post,
                         float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false,
                         bool pair_prepared = false, const float* sched_beta = nullptr, int t_step = 0, const int* t_dev = nullptr,
-                        const unsigned char* last_layer_tiles = nullptr) {  // row tiles of the LAST layer whose outputs are read
+                        const unsigned char* last_layer_tiles = nullptr,  // row tiles of the LAST layer whose outputs are read
+                        bool skip_heads_finish = false) {  // the caller finishes the heads itself from b.vbuf / b.logits (reverse sampler)
   // sched_beta (reverse sampler): every patch is at step t_step (or *t_dev): the folded head tables take beta from the schedule and
   // `beta` is only read by the unfolded path
   const StepBuffers b = carve_step(d, ws);
@@ -275,6 +276,7 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     if (int rc = mlp3(d, &w->orient, b.cat3, b.t1, b.t2, b.vbuf, 3, st)) return rc;
     if (int rc = mlp3(d, &w->seq, b.cat3, b.t1, b.t2, logits, d->V, st)) return rc;
   }
+  if (skip_heads_finish) return DIFFAB_OK;
   return launch_heads_finish(b.vbuf, O_t, logits, d->V, rows, out_O0, out_post, st);
 }
 
@@ -625,10 +627,11 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
     if (!fold)  // (the folded head tables read the schedule themselves: one launch less per step)
       if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
     if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold,
-                              pair_ready, fold ? s->beta : nullptr, t, t_dev, tiles))
+                              pair_ready, fold ? s->beta : nullptr, t, t_dev, tiles, true))
       return rc;
+    // (the heads' epilogue - O0 = O_t exp(hat(v)), the posterior's softmax - runs inside the update kernel, for the generated rows)
     return launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K, d->V, st,
-                                        t_dev);
+                                        t_dev, b0.vbuf, b0.logits);
   };
   // DIFFAB_FLAG_GRAPH_SAMPLER: a step is ~45 launches; at B = 1 (BASELINE config 1) their host cost (3-4 us each) is several times
   // the kernels' own time.  The first step runs eagerly (it also performs the one-time function-attribute calls), the second is

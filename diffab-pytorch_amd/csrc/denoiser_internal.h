@@ -138,9 +138,9 @@ int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const f
 
 // diffusion_kernels.hip
 int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
-                                 const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,
-                                 int64_t first_patch, int B, int K, int V, hipStream_t st,
-                                 const int* t_dev = nullptr);  // t_dev: read the timestep from device memory (graph replay)
+                                 const float* eps_hat, float* O0_hat, float* post, const uint8_t* gm, uint64_t seed,
+                                 int64_t first_patch, int B, int K, int V, hipStream_t st, const int* t_dev = nullptr,
+                                 const float* head_v = nullptr, const float* head_logits = nullptr);  // heads' epilogue done in the kernel  // t_dev: read the timestep from device memory (graph replay)
 int launch_fill_beta(const diffab_sched* s, int t, int B, float* out, hipStream_t st, const int* t_dev = nullptr);
 int launch_tiles_needed(const uint8_t* gm, int B, int K, unsigned char* out, hipStream_t st);  // [B][K / 16]: any generated residue in the tile
 int launch_set_int(int* p, int v, hipStream_t st);

@@ -712,15 +712,33 @@ __global__ void reverse_update_kernel(const float* __restrict__ beta, const floa
 }
 
 // Same update with the noise drawn in-kernel from Philox (the production sampler).
+// head_v / head_logits != nullptr (the folded sampler path): the heads' epilogue of the row - O0 = O_t exp(hat(v)) (diffab_pytorch.py:594-596)
+// and posterior = softmax(logits) (:555), what heads_finish_kernel computes for every row - is done here, for the generated rows only,
+// into O0_hat / post (read back by the same thread below; no __restrict__ on the two for that reason): one launch less per step.
 __global__ void reverse_update_philox_kernel(const float* __restrict__ beta, const float* __restrict__ alpha, const float* __restrict__ omabs,
                                              int t, const float* __restrict__ rev_sigmas, const float* __restrict__ rev_cdf, int n_bins,
                                              float thr, int64_t* __restrict__ seq, float* __restrict__ x, float* __restrict__ O,
-                                             const float* __restrict__ eps_hat, const float* __restrict__ O0_hat,
-                                             const float* __restrict__ post, const uint8_t* __restrict__ gm, uint64_t seed,
-                                             int64_t first_patch, int B, int K, int V, const int* __restrict__ t_dev) {
+                                             const float* __restrict__ eps_hat, float* O0_hat, float* post, const uint8_t* __restrict__ gm,
+                                             uint64_t seed, int64_t first_patch, int B, int K, int V, const int* __restrict__ t_dev,
+                                             const float* __restrict__ head_v, const float* __restrict__ head_logits) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= static_cast<int64_t>(B) * K || !gm[i]) return;
   if (t_dev != nullptr) t = *t_dev;  // graph replay: the timestep lives in device memory (one captured step serves every t)
+  if (head_v != nullptr) {
+    float ex[9], o[9], res[9];
+    so3_rotvec_to_matrix(head_v[i * 3], head_v[i * 3 + 1], head_v[i * 3 + 2], ex);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = O[i * 9 + k];
+    mat3_mul(o, ex, res);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) O0_hat[i * 9 + k] = res[k];
+    float m = -INFINITY;
+    for (int c = 0; c < V; ++c) m = fmaxf(m, head_logits[i * V + c]);
+    float s = 0.f;
+    for (int c = 0; c < V; ++c) s += expf(head_logits[i * V + c] - m);
+    const float inv = 1.0f / s;
+    for (int c = 0; c < V; ++c) post[i * V + c] = expf(head_logits[i * V + c] - m) * inv;
+  }
   const uint32_t patch = static_cast<uint32_t>(first_patch + i / K), res = static_cast<uint32_t>(i % K), st = static_cast<uint32_t>(t);
   const f32x4 zt = philox_normal4(seed, patch, res, st, STREAM_TRANS);
   f32x4 ax = philox_normal4(seed, patch, res, st, STREAM_AXIS);
@@ -761,12 +779,13 @@ __global__ void dec_int_kernel(int* __restrict__ p) { *p -= 1; }
 
 // launchers used by api.hip (sample loop)
 int launch_reverse_update_philox(const diffab_sched* s, const diffab_igso3* tab, int t, int64_t* seq, float* x, float* O,
-                                 const float* eps_hat, const float* O0_hat, const float* post, const uint8_t* gm, uint64_t seed,
-                                 int64_t first_patch, int B, int K, int V, hipStream_t st, const int* t_dev) {
+                                 const float* eps_hat, float* O0_hat, float* post, const uint8_t* gm, uint64_t seed,
+                                 int64_t first_patch, int B, int K, int V, hipStream_t st, const int* t_dev, const float* head_v,
+                                 const float* head_logits) {
   const int64_t n = static_cast<int64_t>(B) * K;
   hipLaunchKernelGGL(reverse_update_philox_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, st, s->beta, s->alpha,
                      s->one_minus_alpha_bar_sqrt, t, tab->sigmas, tab->cdf, tab->n_bins, tab->sigma_threshold, seq, x, O, eps_hat, O0_hat,
-                     post, gm, seed, first_patch, B, K, V, t_dev);
+                     post, gm, seed, first_patch, B, K, V, t_dev, head_v, head_logits);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
