@@ -190,7 +190,9 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
                         float* out_logits, float* out_res_emb, void* ws, uint32_t flags, hipStream_t st, bool weights_prepared = false,
                         bool pair_prepared = false, const float* sched_beta = nullptr, int t_step = 0, const int* t_dev = nullptr,
                         const unsigned char* last_layer_tiles = nullptr,  // row tiles of the LAST layer whose outputs are read
-                        bool skip_heads_finish = false) {  // the caller finishes the heads itself from b.vbuf / b.logits (reverse sampler)
+                        bool skip_heads_finish = false,  // the caller finishes the heads itself from b.vbuf / b.logits (reverse sampler)
+                        const float* beta_traj = nullptr, int traj_rows = 0) {  // [3 heads][traj_rows steps][D]: the heads' folded beta
+                                                                               // columns of EVERY step (row t_step is this step's)
   // sched_beta (reverse sampler): every patch is at step t_step (or *t_dev): the folded head tables take beta from the schedule and
   // `beta` is only read by the unfolded path
   const StepBuffers b = carve_step(d, ws);
@@ -206,23 +208,25 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
   // Folded concatenations (MFMA path): the sequence-embedding half of to_res_emb[0] and the beta-embedding columns of the three
   // head MLPs become bias tables, so neither cat[res_ctx, E[s]] nor cat[h, tau] is written or re-read.
   const bool fold = !(flags & DIFFAB_FLAG_FORCE_GENERIC) && fast_path_supported(d) && rowgemm128_ok(res_ctx, D, b.h1, D, rows, D);
+  // dense N = 128 layers of the folded path: bf16x6 from the prepared planes (slot), or the fp32 kernel; each MLP as one row-resident
+  // kernel (mlp_chain_b6_kernel), one launch per dense layer only where the chain does not apply
+  const bool b6 = fold && use_b6_gemm(flags) && rowgemm128_b6_ok(res_ctx, D, b.h1, D, rows, D);
+  const bool chain = b6 && d->V <= 128;
+  if (!chain) beta_traj = nullptr;  // (the per-call table of every step's head columns is read by the chain kernel only)
   if (fold) {
     DIFFAB_REQUIRE(w->coord.w0 && w->coord.b0 && w->orient.w0 && w->orient.b0 && w->seq.w0 && w->seq.b0, DIFFAB_ERR_ARG,
                    "denoiser head: null weight pointer");
     if (!weights_prepared)
       if (int rc = prepare_weights(d, w, b, flags, st)) return rc;
-    if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, true, sched_beta, t_step, t_dev)) return rc;
+    if (beta_traj == nullptr)
+      if (int rc = launch_fold_tables(d, w, beta, b.emb_tab, b.beta_tab, st, true, sched_beta, t_step, t_dev)) return rc;
   }
-  // dense N = 128 layers of the folded path: bf16x6 from the prepared planes (slot), or the fp32 kernel
-  const bool b6 = fold && use_b6_gemm(flags) && rowgemm128_b6_ok(res_ctx, D, b.h1, D, rows, D);
   const char* mlp = b6 ? b.planes + d->NL * ipa_layer_planes_bytes() : nullptr;
   auto dense128 = [&](int slot, const float* X, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                       bool relu) -> int {
     if (b6) return launch_rowgemm128_b6p(X, D, mlp + slot * mlp_planes_bytes(), bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
     return launch_rowgemm128(X, D, W, ldw, bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
   };
-  // each MLP as one row-resident kernel (mlp_chain_b6_kernel); one launch per dense layer only where the chain does not apply
-  const bool chain = b6 && d->V <= 128;
   if (fold && chain) {
     const void* pl[2] = {mlp, mlp + mlp_planes_bytes()};
     const float* bs[2] = {b.emb_tab, w->res_b2};
@@ -258,11 +262,12 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
         pl[3 * hd] = mlp + (2 + 2 * hd) * mlp_planes_bytes();
         pl[3 * hd + 1] = mlp + (3 + 2 * hd) * mlp_planes_bytes();
         pl[3 * hd + 2] = mlp + (8 + hd) * mlp_planes_bytes();
-        bs[3 * hd] = b.beta_tab + static_cast<size_t>(hd) * d->B * D;
+        bs[3 * hd] = beta_traj ? beta_traj + (static_cast<size_t>(hd) * traj_rows + t_step) * D : b.beta_tab + static_cast<size_t>(hd) * d->B * D;
         bs[3 * hd + 1] = hw[hd]->b2;
         bs[3 * hd + 2] = hw[hd]->b4;
       }
-      if (int rc = launch_mlp_chains_b6(cur, D, 3, pl, bs, nullptr, d->K, 3, nout, outs, nout, rows, st)) return rc;
+      // (beta_traj: one table row for every patch - "row / rows" is 0 for all of them)
+      if (int rc = launch_mlp_chains_b6(cur, D, 3, pl, bs, nullptr, beta_traj ? rows : d->K, 3, nout, outs, nout, rows, st)) return rc;
     }
     for (int hd = 0; hd < 3 && !chain; ++hd) {
       if (int rc = dense128(2 + 2 * hd, cur, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, true))
@@ -323,10 +328,12 @@ static int check_denoiser_weights(const diffab_dims* d, const diffab_denoiser_we
   return DIFFAB_OK;
 }
 
+constexpr int kTrajRows = 1025;  // schedules up to T = 1024 get their per-step head tables built once per call
 struct SampleBuffers {
   float *beta, *eps, *O0, *post;
   int* t_dev;  // the current timestep in device memory (graph replay)
   unsigned char* tiles;  // [B][K / 16]: row tiles with a generated residue (DIFFAB_FLAG_SKIP_UNUSED_ROWS)
+  float* beta_traj;      // [3 heads][kTrajRows][D]: the heads' folded beta columns of every step of a schedule with T < kTrajRows
   void* step;
   size_t bytes;
 };
@@ -341,6 +348,7 @@ static SampleBuffers carve_sample(const diffab_dims* d, void* ws) {
   s.post = c.take<float>(rows * d->V);
   s.t_dev = c.take<int>(64);
   s.tiles = c.take<unsigned char>(static_cast<size_t>(d->B) * ((d->K + 15) / 16));
+  s.beta_traj = c.take<float>(static_cast<size_t>(3) * kTrajRows * d->D);
   const size_t step_bytes = carve_step(d, nullptr).bytes;
   s.step = c.take<char>(step_bytes);
   s.bytes = c.bytes();
@@ -623,11 +631,22 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
     if (int rc = launch_tiles_needed(gen_mask, d->B, d->K, sb.tiles, st)) return rc;
     tiles = sb.tiles;
   }
+  // The heads' folded beta columns depend on (step, head, column) only - every patch of a reverse step has the same beta - so the table
+  // of ALL steps is built once per call (the same kernel and formula as the per-step table, "patch" = step) instead of once per step.
+  // Eager loop only: under graph replay the step index lives in device memory and the chain's bias pointer is a launch argument.
+  const bool chain_path = fold && use_b6_gemm(flags) && d->V <= 128;  // (denoise_step's `chain`)
+  const float* beta_traj = nullptr;
+  if (chain_path && s->T + 1 <= kTrajRows && !(flags & DIFFAB_FLAG_GRAPH_SAMPLER)) {
+    diffab_dims dt = *d;
+    dt.B = s->T + 1;
+    if (int rc = launch_fold_tables(&dt, w, s->beta, nullptr, sb.beta_traj, st, true)) return rc;
+    beta_traj = sb.beta_traj;
+  }
   auto one_step = [&](int t, const int* t_dev) -> int {
     if (!fold)  // (the folded head tables read the schedule themselves: one launch less per step)
       if (int rc = launch_fill_beta(s, t, d->B, sb.beta, st, t_dev)) return rc;
     if (int rc = denoise_step(d, w, seq, x, O, res_ctx, pair_ctx, sb.beta, sb.eps, sb.O0, sb.post, nullptr, nullptr, sb.step, flags, st, fold,
-                              pair_ready, fold ? s->beta : nullptr, t, t_dev, tiles, true))
+                              pair_ready, fold ? s->beta : nullptr, t, t_dev, tiles, true, t_dev ? nullptr : beta_traj, s->T + 1))
       return rc;
     // (the heads' epilogue - O0 = O_t exp(hat(v)), the posterior's softmax - runs inside the update kernel, for the generated rows)
     return launch_reverse_update_philox(s, rev_tab, t, seq, x, O, sb.eps, sb.O0, sb.post, gen_mask, seed, first_patch, d->B, d->K, d->V, st,
