@@ -146,6 +146,27 @@ def cpu_baseline(dims, sd, K, seed, budget_s=30.0):
     }
 
 
+def gpu_clocks():
+    """sclk / mclk / power / power cap of GPU 0 as rocm-smi reports them (a child process; None where the tool or a field is missing).
+    Read before and after the timed blocks so that a slow box can be told from a regression."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([exe, "-d", "0", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"], capture_output=True,
+                             text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+    except Exception as ex:  # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}"[:120]}
+    keep = {}
+    for k, v in card.items():
+        kl = k.lower()
+        if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "performance level")):
+            keep[k] = v
+    return keep
+
+
 def train_bytes_per_patch(K, dims, dpair):
     """Algorithmic HBM bytes of one training step per patch: the pair tensor read once by the forward and once by the
     backward of each layer, the attention tape (probabilities written and read once: 2 x H K^2 4 B per layer),
@@ -397,6 +418,9 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead of the sampling headline: training steps (noise + taped forward + 3 losses + HIP "
                          "backward + gradient all-reduce over RCCL + Adam), 128 patches per GPU unless --batch is given")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed block of --steps steps is run this many times back to back (each bracketed by barrier + synchronize, "
+                         "max over ranks); ms_per_step / value are the MEDIAN block, every block is listed in ms_per_step_runs")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (tests/test_gpu_two_ranks.py); "
                          "exercises the launch contract, sharding, gather and max-over-ranks timing - NOT a scaling measurement")
@@ -404,6 +428,18 @@ def main():
     if args.train and "--batch" not in sys.argv:
         args.batch = 128
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (nothing above has touched the GPU:
+        # `import torch` alone does not initialise HIP), forward its output and leave with its exit code - never exec
+        import socket
+        import subprocess
+
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -472,21 +508,29 @@ def main():
     t_next = run_steps(args.warmup, model.T)
     if dist is not None:  # untimed: RCCL sets up its channels / buffers on the first collective of each kind
         gather_samples({"seq_idx": seq, "translations": x, "orientations": O}, dist)
+    clocks_before = gpu_clocks() if rank == 0 else None
     lib.diffab_kernel_timer_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps, t_next)
-    samples = gather_samples({"seq_idx": seq, "translations": x, "orientations": O}, dist)  # RCCL all-gather when N > 1
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed block (EXACTLY --steps steps + the all-gather, barrier + synchronize on both sides, max over ranks) is run --repeats
+    # times back to back in this process: one number per round cannot tell a 3 % change from the box-to-box spread.
+    runs = []
+    for _rep in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        t_next = run_steps(args.steps, t_next)
+        samples = gather_samples({"seq_idx": seq, "translations": x, "orientations": O}, dist)  # RCCL all-gather when N > 1
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        runs.append(el)
+    elapsed = sorted(runs)[len(runs) // 2]  # median block
     launches, total_ms = C.c_int64(0), C.c_double(0.0)
     _hip.check(lib.diffab_kernel_timer_read(C.byref(launches), C.byref(total_ms)), "kernel_timer_read")
     lib.diffab_kernel_timer_enable(0)
+    clocks_after = gpu_clocks() if rank == 0 else None
     assert samples["translations"].shape[0] == world * B
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     finite = bool(torch.isfinite(x).all() and torch.isfinite(O).all())
 
     if rank == 0:
@@ -511,6 +555,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # every timed block of this process (each: --steps steps + gather, bracketed); ms_per_step / value = the median block
+            "ms_per_step_runs": [r / args.steps * 1e3 for r in runs],
+            "ms_per_step_min": min(runs) / args.steps * 1e3,
+            "ms_per_step_median": elapsed / args.steps * 1e3,
+            "gpu_clocks": {"before": clocks_before, "after": clocks_after},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -157,6 +157,17 @@ def test_bench_two_ranks_launch_contract(tmp_path):
     assert out["config"]["global_batch"] == 16 and out["config"]["patches_per_gpu"] == 8 and "REHEARSAL" in out["config"]["parallelism"]
     assert abs(out["value"] - 2 * 8 * 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]  # whole-job aggregate over both ranks
     assert out["outputs_finite"] and "roofline" in out and "cpu_baseline" not in out  # (the CPU baseline is an N = 1 leg)
+    assert len(out["ms_per_step_runs"]) == 5 and out["ms_per_step_min"] <= out["ms_per_step"] == out["ms_per_step_median"]
+    # the plain form (no launcher, no WORLD_SIZE in the environment): bench.py starts the ranks itself as a child process
+    env_plain = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    plain = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--repeats", "2",
+             "--rehearse-on-one-gpu"]
+    res = subprocess.run(plain, cwd=str(tmp_path), env=env_plain, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and len(out["ms_per_step_runs"]) == 2
     # the training leg under the same launcher
     cmd_t = cmd[:-1] + ["--train", "--rehearse-on-one-gpu"]
     cmd_t[cmd_t.index("--batch") + 1] = "4"
