@@ -240,7 +240,15 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     if (int rc = launch_linear(b.h1, D, w->res_w2, w->res_b2, b.hA, D, rows, D, D, false, st)) return rc;
   }
   float *cur = b.hA, *nxt = b.hB;
-  for (int l = 0; l < d->NL; ++l) {
+  // DIFFAB_FLAG_PERSISTENT_MODULE: the NL layers as one patch-resident launch (ipa_persistent.hip) - the same tile bodies, bitwise the
+  // same result; needs the prepared planes of all layers, the pair planes, and K = 128
+  const bool persistent = (flags & DIFFAB_FLAG_PERSISTENT_MODULE) && fold && use_b6_gemm(flags) && pair_planes != nullptr &&
+                          ipa_module_persistent_supported(d) && last_layer_tiles == nullptr;
+  if (persistent) {
+    if (int rc = launch_ipa_module_persistent(d, b.hA, b.hB, O_t, x_t, b.ipa, b.planes, pair_planes, st)) return rc;
+    cur = (d->NL & 1) ? b.hB : b.hA;
+  }
+  for (int l = 0; l < d->NL && !persistent; ++l) {
     const void* planes = (fold && use_b6_gemm(flags)) ? b.planes + l * ipa_layer_planes_bytes() : nullptr;
     if (int rc = ipa_layer_dispatch(d, &w->layers[l], cur, pair_ctx, O_t, x_t, nxt, b.ipa, flags, st, nullptr, nullptr, planes, pair_planes,
                                     false, l == d->NL - 1 ? last_layer_tiles : nullptr))
@@ -387,6 +395,16 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
 
 int diffab_set_stream_guard(int on) {
   set_stream_order(on != 0);
+  return DIFFAB_OK;
+}
+
+int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes) {
+  set_module_stagger(ticks_10ns, classes);
+  return DIFFAB_OK;
+}
+
+int diffab_debug_set_module_stamps(void* device_buffer) {
+  set_module_stamps(device_buffer);
   return DIFFAB_OK;
 }
 

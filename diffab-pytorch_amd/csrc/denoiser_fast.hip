@@ -22,16 +22,11 @@
 #include "common.h"
 #include "denoiser_internal.h"
 #include "rowgemm_b6_tile.h"
+#include "ipa_attn_tile.h"
 
 namespace diffab {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Compile-time fence for memory operations: keeps the hand-placed prefetch loads where they are written (hipcc otherwise
-// sinks each load next to its first use, leaving one or two in flight and exposing every HBM / L2 round trip).
-#define MEM_FENCE() asm volatile("" ::: "memory")
+// (f32x4 / f32x16 / f32x2 and MEM_FENCE come with ipa_attn_tile.h)
 
 // ================================================================== Y = act(X W^T + b) on MFMA 32x32x2
 constexpr int LBM = 128, LBK = 32, LLD = LBK + 4;  // LDS row stride 36 floats: ds_read_b128 conflict-free
@@ -350,36 +345,8 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
 }
 
 // ================================================================== fused IPA attention (benchmark geometry)
-constexpr int AH = 8, ADS = 32, AP = 8, AC = 64;
-constexpr int ANP = 3 * AH * ADS + 3 * AH * AP * 3;               // 1344 projection columns
-constexpr int AF = AH * ADS + AH * AC + AH * AP * 3 + AH * AP;    // 1024 feature columns
-constexpr int OFF_QS = 0, OFF_KS = 256, OFF_VS = 512, OFF_GQ = 768, OFF_GK = 960, OFF_GV = 1152;
-constexpr int FOFF_OS = 0, FOFF_OE = 256, FOFF_OL = 768, FOFF_ON = 960;
-constexpr int TI = 16;  // query residues per work-group
-
-// LDS strides of the logits/probabilities image: head stride K + 8 (== 8 mod 64 for K % 64 == 0) and row stride
-// 8 (K + 8) + 8 keep both the (head, quarter)-lane and the (row, quarter)-lane ds_read_b128 patterns conflict-free.
-
-// softmax exponentials: v_exp_f32 path (2^(x log2 e)); arguments are <= 0 and the relative error (<~ |x| 1e-7) is far inside the
-// 1e-4 parity bar (measured ~2e-6 on the outputs).  -DDIFFAB_ACCURATE_EXP restores the libm expf expansion (~12 VALU ops each).
-#ifdef DIFFAB_ACCURATE_EXP
-#define FAST_EXP(x) expf(x)
-#else
-#define FAST_EXP(x) __expf(x)
-#endif
-
-// NT: key tiles (16 keys each) per chunk: 8 when K % 128 == 0, else 4; compile-time so per-lane arrays stay in VGPRs.
-// MULTI: more than one chunk.  The single-chunk instantiation (K = 64, 128) has NC == 1 at compile time: the chunk loop and every
-// rescale branch fold away and it is the same straight-line kernel as before the chunk loop existed (the loop costs 13 % at K=128).
-// PLANES: `e` is not the fp32 pair embedding but its two-plane fp16 image written by pair_split_kernel (same
-// bytes: e s = h1 + h2 to 2^-23 of the tensor maximum, fragment order of the bias product), `esc` = {s, 1 / s}; the two products on
-// the pair tile then run on the f16 matrix cores as three exact partial products each (h1 w1, h1 w2, h2 w1 with fp32 accumulation)
-// instead of f32 MFMAs: 96 instead of 512 matrix-pipe cycles per key tile for the bias, 768 instead of 4096 per row for o_e.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-// TAPE (single-chunk, fp32 pair stream: the forward of a training step): the normalised probabilities and the squared point distances
-// are left in tape_p / tape_d2 ([b][h][i][j], what ipa_logits_kernel<true> + ipa_pair_stream_kernel leave) for the backward.
+// The body is ipa_attn_tile.h (a device function, shared with the patch-resident module kernel of ipa_persistent.hip); here one
+// work-group per (patch, 16 query residues), grid = B K / 16.
 template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false>
 __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
@@ -388,33 +355,8 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
                                                             unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr,
                                                             float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr,
                                                             const unsigned char* __restrict__ tile_needed = nullptr) {
-  static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
-  static_assert(!TAPE || (!MULTI && !PLANES), "the tape form is the single-chunk fp32-pair kernel");
-  const int NC = MULTI ? NC_arg : 1;
-  // Keys are processed in NC chunks of KC = 16 NT with an online softmax: the LDS image holds the logits / (unnormalised)
-  // probabilities of ONE chunk, each (row, head) keeps a running maximum M and sum L, and the partial outputs of earlier chunks
-  // are rescaled by exp(M_old - M_new) through the feature rows in global memory.  K = 64 and 128 are the single-chunk case;
-  // K = 192, 256, ... reuse the same 16-row structure instead of needing a K-proportional LDS image.
-  extern __shared__ __attribute__((aligned(16))) float S[];  // [TI][AH][KC+8] (+8 per i)
-  constexpr int KC = NT * 16;
-  constexpr int NS = NT * 4;  // (jt, r) key steps of 4 keys each
-  const int K = NC * KC;
-  const int ntile = K / TI;
-  // diagnostic stamps (stamps == nullptr in every production launch: nothing below executes; diffab_debug_set_attn_stamps,
-  // tools/attn_phase_profile.py).  -DAT_STAMP_REALTIME: the chip-wide 100 MHz counter instead of the per-CU cycle counter.
-  auto stamp = [&](int k) {
-    if (stamps != nullptr) {
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef AT_STAMP_REALTIME
-      const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
-#else
-      const unsigned long long tnow = __builtin_amdgcn_s_memtime();
-#endif
-      if ((threadIdx.x & 63) == 0) stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + k] = tnow;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  stamp(0);
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int ntile = (MULTI ? NC_arg : 1) * NT;  // K / TI
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
   int b, tile;
   const unsigned bid = blockIdx.x;
@@ -429,633 +371,7 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   // tile_needed (reverse sampler, last layer, DIFFAB_FLAG_SKIP_UNUSED_ROWS): the outputs of this layer are read for generated residues
   // only - a row tile without one leaves at once (uniform; its feature rows keep the previous layer's values, which nothing reads)
   if (tile_needed != nullptr && !tile_needed[b * ntile + tile]) return;
-  const int i0 = tile * TI;
-  const int tid = threadIdx.x, lane0 = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // (the wave index as a scalar: the addresses built from it stay in SGPRs, which takes the chunked instantiations from 13 spilled VGPRs
-  // + 56 B of scratch to none)
-  constexpr int HS = KC + 8, IS = AH * (KC + 8) + 8;  // == 8 (mod 64): both ds_read_b128 patterns on the image are conflict-free
-  const int64_t prow0 = static_cast<int64_t>(b) * K;  // first projection row of this patch
-  const float scale_t = 0.57735026918962576f;         // 3^-1/2   (diffab_pytorch.py:387, :439)
-
-  // Per-wave LDS scratch behind the logits image.  Every global load below is issued in full 128-byte lines (consecutive
-  // lanes on consecutive 16-byte chunks): the texture addresser serves one line per lane quad, whereas MFMA-fragment-shaped
-  // loads (adjacent lanes on different rows) cost four lines per quad and made this kernel addresser-bound (4x the issue
-  // time, measured).  Data is re-oriented into fragments through this scratch; a wave reads only what it wrote, and LDS
-  // operations of one wave complete in order, so no barrier is involved.
-  constexpr int KLD = 40, GLD = 28;             // key-tile strides (floats): ds_read_b128 conflict-free
-  constexpr int P1_TILE = 16 * KLD + 16 * GLD;  // 1088 floats per staged key tile
-  constexpr int ELD = 72;                       // pair-tile stride (floats)
-  constexpr int SCR_FLOATS = 2 * 16 * ELD;      // 2304 floats per wave (>= 2 * P1_TILE = 2176)
-#ifndef DIFFAB_E_EARLY
-#define DIFFAB_E_EARLY 1
-#endif
-#ifndef DIFFAB_E_LAG
-#define DIFFAB_E_LAG 2
-#endif
-  constexpr int E_LAG = MULTI ? DIFFAB_E_LAG : 0;    // the next row's tile loads trail the retiring tiles by this many (VGPRs)
-#ifndef DIFFAB_E_EARLY_SINGLE
-#define DIFFAB_E_EARLY_SINGLE 2
-#endif
-  constexpr int E_EARLY = MULTI ? DIFFAB_E_EARLY : DIFFAB_E_EARLY_SINGLE;  // pair tiles of phase 2's first row started under the tail of phase 1
-  float* scr = S + TI * IS + wv * SCR_FLOATS;
-  float* st_fac = S + TI * IS + 8 * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
-  float* st_inv = st_fac + TI * AH;              // [TI][AH] 1 / L after the last chunk (1 before)
-  float* wb_lds = st_inv + TI * AH;              // [4 sg][64 lanes][4]: B fragments of the bias product (same for every wave)
-  if (wv == 0 && !PLANES) {  // Wb[h][16 sg + 4 q + s] for lane (h = l15 < 8, q), zero in the padding columns; first read is behind a barrier
-    const int l15_ = lane0 & 15, q_ = lane0 >> 4;
-#pragma unroll
-    for (int sg = 0; sg < 4; ++sg) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(Wb + (l15_ & 7) * AC + 16 * sg + 4 * q_);
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) v[s_] = l15_ < 8 ? v[s_] : 0.0f;
-      *reinterpret_cast<f32x4*>(wb_lds + (sg * 64 + lane0) * 4) = v;
-    }
-  }
-
-  // e[b, i0 + 2 wv + ii, :, :]: the two pair-embedding rows this wave owns in phase 2.  Streamed once (non-temporal: it
-  // must not evict the K/V-side operands, re-read by the other row tiles of the patch, from L2), in the orientation of
-  // the o_e product: lane (l15, q) holds e[i][j = 16 jt + 4 q + r][c = 4 l15 .. 4 l15 + 3] - 1 KiB contiguous per load.
-  // A chunk of a row (16 NT VGPRs) stays in registers from the bias product to the o_e product.
-  const float* erow[2];
-  erow[0] = e + ((prow0 + i0 + 2 * wv) * K) * AC;
-  erow[1] = erow[0] + static_cast<int64_t>(K) * AC;
-  float Mrun[2] = {-INFINITY, -INFINITY}, Lrun[2] = {0.f, 0.f};  // online-softmax state of (row 2 wv + ii, head l15 & 7)
-  // PLANES: 1 / s_i of the wave's two pair rows, fetched here through the scalar cache (wave-uniform address).  As a vector load at
-  // the top of each row its s_waitcnt - vmcnt retires in order - drained every pair tile in flight, twice per wave and phase 2.
-  float inv_s2[2] = {1.0f, 1.0f};
-  if constexpr (PLANES) {
-    const float* ep = esc + 2 * (prow0 + i0 + 2 * __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
-    inv_s2[0] = ep[1];
-    inv_s2[1] = ep[3];
-  }
-
-#pragma unroll 1
-  for (int c = 0; c < NC; ++c) {
-    const bool last = c == NC - 1;
-    const int64_t krow0 = prow0 + c * KC;  // first key row of this chunk
-    // Re-derive the lane coordinates from an opaque copy each iteration: otherwise every lane-constant address of the three
-    // phases is hoisted out of this loop and stays live through phase 2, which spills (hipcc, ROCm 7.2).
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int l15 = lane & 15, q = lane >> 4;
-    f32x4 ev[2][NT][4];
-    f32x4 wv4[2][2];  // PLANES: the bias weights of lane (head, channel group), requested in phase 1's tail AHEAD of the first pair tiles:
-                      // vmcnt retires in order, so loaded behind them they would cost every wave a pair-tile latency in front of the barrier
-    auto load_e_tile = [&](int ii, int cc_, int jt) {
-      if constexpr (PLANES) {  // four 1 KiB blocks per key tile, lane order: ev[ii][jt][2 p + ks] = fragment (plane p, k-step ks)
-        const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii]) + (cc_ * NT + jt) * 256 + lane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * 64);
-      } else {
-        const f32x4* ep = reinterpret_cast<const f32x4*>(erow[ii] + (cc_ * KC + jt * 16 + 4 * q) * AC + 4 * l15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
-      }
-    };
-    // ---------------------------------------------------------------- phase 1: wave = head
-    {
-      const int h = wv;
-      const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
-      const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
-      // line-shaped loads of one key tile (16 keys): k_s 16 x 128 B (8 lanes per key), gk 16 x 96 B (6 lanes per key)
-      const float* ks_src = proj + (krow0 + (lane >> 3)) * ANP + OFF_KS + h * ADS + 4 * (lane & 7);  // + 8 t keys, + 16 jt keys
-      const int g0 = lane, g1 = lane + 64;  // gk chunk ids (0..95): key = id / 6, chunk = id % 6
-      const float* gk_src0 = proj + (krow0 + g0 / 6) * ANP + OFF_GK + h * 24 + 4 * (g0 % 6);
-      const float* gk_src1 = proj + (krow0 + g1 / 6) * ANP + OFF_GK + h * 24 + 4 * (g1 % 6);
-      const int ks_dst = (lane >> 3) * KLD + 4 * (lane & 7);
-      const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
-      constexpr int SD = MULTI ? 3 : 4;  // register staging depth: SD - 1 key tiles of lookahead
-      static_assert(E_EARLY <= SD, "the early pair tiles are requested in the last E_EARLY iterations, which must not request key tiles any more");
-      f32x4 st[SD][4];
-      auto load_keys = [&](int sb, int jt) {
-        const int64_t o = static_cast<int64_t>(jt) * 16 * ANP;
-        st[sb][0] = *reinterpret_cast<const f32x4*>(ks_src + o);
-        st[sb][1] = *reinterpret_cast<const f32x4*>(ks_src + o + 8 * ANP);
-        st[sb][2] = *reinterpret_cast<const f32x4*>(gk_src0 + o);
-        if (g1 < 96) st[sb][3] = *reinterpret_cast<const f32x4*>(gk_src1 + o);
-      };
-      auto stage_keys = [&](int sb, int lb) {
-        float* t_ = scr + lb * P1_TILE;
-        *reinterpret_cast<f32x4*>(t_ + ks_dst) = st[sb][0];
-        *reinterpret_cast<f32x4*>(t_ + ks_dst + 8 * KLD) = st[sb][1];
-        *reinterpret_cast<f32x4*>(t_ + gk_dst0) = st[sb][2];
-        if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
-      };
-#pragma unroll
-      for (int jt = 0; jt < SD && jt < NT; ++jt) load_keys(jt, jt);
-      // A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s
-      f32x4 qa[2];
-      const float* qrow = proj + (prow0 + i0 + l15) * ANP + OFF_QS + h * ADS + 4 * q;
-      qa[0] = *reinterpret_cast<const f32x4*>(qrow);
-      qa[1] = *reinterpret_cast<const f32x4*>(qrow + 16);
-      // query points of the 4 rows this lane accumulates (rows i0 + 4q + r); the 16 lanes of a quarter share each address
-      f32x4 gq[4][6];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* p = proj + (prow0 + i0 + 4 * q + r) * ANP + OFF_GQ + h * 24;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) gq[r][cc] = *reinterpret_cast<const f32x4*>(p + 4 * cc);
-      }
-      MEM_FENCE();
-      // Software pipeline over the key tiles (fully unrolled, so the fragment sets are renamed, not copied):
-      //   iteration jt:  registers -> LDS for tile jt+2 | LDS -> fragments of tile jt+1 | global -> registers for tile jt+1+SD-1
-      //                  | MFMA + VALU on the fragments of tile jt (read during iteration jt-1).
-      // Every LDS round trip and every L2 round trip is a full iteration (or SD-2 of them) old when its data is needed; before
-      // this the fragment reads of tile jt sat right behind the writes of tile jt+1 and were waited for at once.
-      struct KeyFrag { f32x4 kb0, kb1, gk[6]; };
-      auto read_frags = [&](int jt) {
-        KeyFrag f;
-        const float* t_ = scr + (jt & 1) * P1_TILE;
-        f.kb0 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 4 * q);  // k_s[16 jt + l15][16 sg + 4 q + s]
-        f.kb1 = *reinterpret_cast<const f32x4*>(t_ + l15 * KLD + 16 + 4 * q);
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) f.gk[cc] = *reinterpret_cast<const f32x4*>(t_ + 16 * KLD + l15 * GLD + 4 * cc);
-        return f;
-      };
-      stage_keys(0, 0);
-      KeyFrag cur = read_frags(0);
-      if (NT > 1) stage_keys(1 % SD, 1);
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        if (jt + 2 < NT) stage_keys((jt + 2) % SD, jt & 1);  // tile jt+2 -> the buffer tile jt was read from (LDS ops retire in order)
-        KeyFrag nxt = cur;
-        if (jt + 1 < NT) nxt = read_frags(jt + 1);
-        if (jt + SD < NT) {
-          load_keys(jt % SD, jt + SD);  // slot of tile jt (staged two iterations ago)
-        } else if (jt + E_EARLY >= NT) {
-          if constexpr (PLANES) {
-            if (jt + E_EARLY == NT) {
-              const int hh = lane & 7, qq = lane >> 4;
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) wv4[ks][hf] = *reinterpret_cast<const f32x4*>(Wb + hh * AC + 32 * ks + 8 * qq + 4 * hf);
-            }
-          }
-          load_e_tile(0, c, jt + E_EARLY - NT);  // key stream done: start phase 2's pair-embedding stream under this tile
-        }
-        MEM_FENCE();
-        const f32x4 kb0 = cur.kb0, kb1 = cur.kb1;
-        f32x4 gk[6];
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) gk[cc] = cur.gk[cc];
-        cur = nxt;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0][s], kb0[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1][s], kb1[s], acc, 0, 0, 0);
-        // acc[r] = q_s[i0+4q+r] . k_s[key 16jt+l15]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two coordinates per instruction, two partial sums added at the end
-          f32x2 d2v = {0.f, 0.f};
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc) {
-            // packed subtract spelled in assembly: the compiler splits a vector fsub (and fma(b, -1, a)) into two v_sub_f32
-            f32x2 dlo, dhi;
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
-                : "=v"(dlo)
-                : "v"(__builtin_shufflevector(gq[r][cc], gq[r][cc], 0, 1)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 0, 1)));
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
-                : "=v"(dhi)
-                : "v"(__builtin_shufflevector(gq[r][cc], gq[r][cc], 2, 3)), "v"(__builtin_shufflevector(gk[cc], gk[cc], 2, 3)));
-            d2v = __builtin_elementwise_fma(dlo, dlo, d2v);
-            d2v = __builtin_elementwise_fma(dhi, dhi, d2v);
-          }
-          const float d2 = d2v[0] + d2v[1];
-          S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
-          if constexpr (TAPE) tape_d2[((static_cast<int64_t>(b) * AH + h) * K + i0 + 4 * q + r) * K + jt * 16 + l15] = d2;
-        }
-        if (c == 0 && jt == 0) stamp(6);
-        if (c == 0 && jt == 3) stamp(7);
-      }
-    }
-    if (c == 0) stamp(1);
-    // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
-    {
-      const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
-#ifndef DIFFAB_E_DEPTH0
-#define DIFFAB_E_DEPTH0 3  // tiles of the first row in flight before its bias loop starts; the rest follow one per consumed tile (all 8 at once:
-                           // 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it builds delays every other CU's loads)
-#endif
-      // PLANES: RT = pair tiles of the wave's 2 NT-tile stream held in registers (requested RT tiles ahead of their use): half a row.
-      // (A whole row spills in the chunked kernel, and in the single-chunk one its 24 loads per wave in front of the barrier take
-      // 4.6 k cycles to issue on the waves that finish phase 1 last: 0.326 ms against 0.321 with half a row.)
-      constexpr int RT = NT / 2;
-      constexpr int E_DEPTH0 = PLANES ? RT : (DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT);
-      if constexpr (!PLANES) {
-#pragma unroll
-        for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
-      }
-      f32x4 wb[4];  // single-chunk kernel: bias B fragments in registers; multi-chunk: read from LDS per tile (VGPR pressure)
-      f16x8 wp[2][2];  // PLANES: bias B fragments as two fp16 planes, wp[plane][ks]: lane (head l15, channels 32 ks + 8 q ..), scaled by sw
-      float bscale = scale_t, oscale = 1.0f;
-      if constexpr (PLANES) {
-        float wmax = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) wmax = fmaxf(wmax, fabsf(wv4[ks][hf][s]));
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-        // sw = 2^(7 - exponent(wmax)): the largest weight lands in [128, 256), far from fp16's subnormals and its overflow
-        const int ew = static_cast<int>((__float_as_uint(wmax) >> 23) & 255u);
-        const float sw = (ew == 0 || ew > 230) ? 1.0f : __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ew) << 23);
-        const float isw = (ew == 0 || ew > 230) ? 1.0f : __uint_as_float(static_cast<unsigned>(ew - 7) << 23);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int c8 = 0; c8 < 8; ++c8) {
-            const float x = l15 < 8 ? wv4[ks][c8 >> 2][c8 & 3] * sw : 0.0f;
-            const _Float16 h1 = static_cast<_Float16>(x);
-            wp[0][ks][c8] = h1;
-            wp[1][ks][c8] = static_cast<_Float16>(x - static_cast<float>(h1));
-          }
-        bscale = scale_t * isw;                   // logits: bias = (sum e s_i w sw) / (s_i sw), x 1 / s_i per row below
-        oscale = 1.0f / 256.0f;                   // o_e: probabilities enter scaled by 256
-        // the rest of the first row, requested AFTER the weight loads above have been consumed: vmcnt retires in order, a wait for a
-        // load issued behind these tiles would wait for all of them (measured: 9 k cycles in front of the barrier)
-        asm volatile("" ::"v"(wp[0][0]), "v"(wp[1][0]), "v"(wp[0][1]), "v"(wp[1][1]));
-#pragma unroll
-        for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);
-      } else if constexpr (!MULTI) {
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-          wb[sg] = *reinterpret_cast<const f32x4*>(Wb + h * AC + 16 * sg + 4 * q);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) wb[sg][s] = l15 < 8 ? wb[sg][s] : 0.0f;
-        }
-      }
-      MEM_FENCE();
-      __syncthreads();  // phase-1 logits of all heads are in LDS (and every wave is done with its key-tile scratch)
-      if (c == 0) stamp(2);
-      // tile re-orientation for the bias product: write [key 4 q + r][channel chunk l15], read [key l15][channels 16 sg + 4 q ..]
-      auto stage_e = [&](int ii, int jt) {
-        float* t_ = scr + (jt & 1) * (16 * ELD) + 4 * q * ELD + 4 * l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(t_ + r * ELD) = ev[ii][jt][r];
-      };
-
-      if constexpr (PLANES) {
-        // Key tiles are consumed in pairs (32 keys), each pair completely - bias, softmax bookkeeping, o_e - as soon as it is in
-        // registers (an online softmax inside the row), so a tile's registers are free after ONE use and the next row's tiles are
-        // requested eight tiles ahead of their use from the first step on: the pair stream of the wave's two rows is one continuous
-        // pipeline.  (Two passes per row - all bias products, softmax, all o_e products - left the second row's loads exposed once
-        // the products had moved to the f16 matrix cores: phase 2 had become a wait for HBM latency, 38 k of its 20 k cycles.)
-        // The probabilities go to LDS relative to the running maximum of their step and are rescaled to the row maximum after the row.
-        char* trt = reinterpret_cast<char*>(scr);                                    // [2 tiles][2 planes][16 keys][128 bytes] = 8 KiB
-        const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)));      // ^ 64 ks: 8-byte unit 8 ks + 2 q of row l15
-        const int rrow = 4 * q + (l15 >> 2);
-        const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // ^ 32 ct: unit 4 ct + (l15 & 3) of row rrow
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const int il = 2 * wv + ii;  // local row
-          float* Srow = S + il * IS + h * HS;
-          const float inv_s = inv_s2[ii];  // 1 / s_i: the power-of-two scale of this pair row's planes
-          const float bscale_r = bscale * inv_s, oscale_r = oscale * inv_s;
-          float m_run = -INFINITY, l_run = 0.f, m_hist[NT / 2];
-          f32x4 oe[4];
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int T = 0; T < NT / 2; ++T) {
-            // ---- bias of the two tiles: A fragments straight from the loaded registers (lane = key l15, channels 32 ks + 8 q ..)
-            f32x4 acc[2][2];
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 a1 = __builtin_bit_cast(f16x8, ev[ii][2 * T + tl][ks]), a2 = __builtin_bit_cast(f16x8, ev[ii][2 * T + tl][2 + ks]);
-                f32x4 a_ = {0.f, 0.f, 0.f, 0.f};
-                a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, wp[0][ks], a_, 0, 0, 0);
-                a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[1][ks], a_, 0, 0, 0);
-                a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wp[0][ks], a_, 0, 0, 0);
-                acc[tl][ks] = a_;
-              }
-            float v[8], smax = -INFINITY;
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-              const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                v[4 * tl + r] = sv[r] + bscale_r * (acc[tl][0][r] + acc[tl][1][r]);
-                smax = fmaxf(smax, v[4 * tl + r]);
-              }
-            }
-            smax = fmaxf(smax, __shfl_xor(smax, 16));
-            smax = fmaxf(smax, __shfl_xor(smax, 32));
-            const float m_new = fmaxf(m_run, smax);
-            const float alpha = T == 0 ? 0.0f : FAST_EXP(m_run - m_new);
-            m_run = m_new;
-            m_hist[T] = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-              v[tt] = FAST_EXP(v[tt] - m_new);
-              psum += v[tt];
-            }
-            l_run = l_run * alpha + psum;  // lane-partial; the key quarters are added after the row (alpha is the same in all four)
-            if (T > 0) {
-#pragma unroll
-              for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oe[ct][r] *= alpha;
-            }
-            // ---- probabilities: to LDS for phase 3 (relative to m_hist[T]), and as two fp16 planes (x 256) into the o_e product
-            f16x8 p1, p2;
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-              const float x = 256.0f * v[tt];
-              const _Float16 hh = static_cast<_Float16>(x);
-              p1[tt] = hh;
-              p2[tt] = static_cast<_Float16>(x - static_cast<float>(hh));
-            }
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-              if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q) = f32x4{v[4 * tl], v[4 * tl + 1], v[4 * tl + 2], v[4 * tl + 3]};
-#pragma unroll
-              for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                  *reinterpret_cast<f32x4*>(trt + (tl * 2 + pl) * 2048 + (wr_off ^ (64 * ks))) = ev[ii][2 * T + tl][2 * pl + ks];
-            }
-            {  // the two tiles are in LDS: request the tiles RT ahead in the wave's stream (rest of this row, then the next row)
-              constexpr int dummy_ = 0;
-              (void)dummy_;
-              const int nx = ii * NT + 2 * T + RT;  // compile-time after unrolling
-              if (nx < 2 * NT) {
-                load_e_tile(nx / NT, c, nx % NT);
-                load_e_tile((nx + 1) / NT, c, (nx + 1) % NT);
-                MEM_FENCE();
-              }
-            }
-            // ---- o_e[channel][head] += e^T P: the A operand (8 keys per lane for one channel) through the transposing LDS read
-            f16x8 a[2][4];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-              for (int ct = 0; ct < 4; ++ct) {
-                const int ro = rd_off ^ (32 * ct);
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (0 * 2 + pl) * 2048 + ro));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(trt + (1 * 2 + pl) * 2048 + ro));
-                const s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                a[pl][ct] = __builtin_bit_cast(f16x8, v8);
-              }
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][ct], p1, oe[ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p2, oe[ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) oe[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][ct], p1, oe[ct], 0, 0, 0);
-          }
-          l_run += __shfl_xor(l_run, 16);
-          l_run += __shfl_xor(l_run, 32);
-          // this chunk's (m_run, l_run) joins the row's running (M, L) over the chunks: everything of this chunk is scaled by cf,
-          // everything accumulated before it by fac (single chunk: cf = 1, fac = 0)
-          const float Mnew = MULTI ? fmaxf(Mrun[ii], m_run) : m_run;
-          const float fac = (!MULTI || c == 0) ? 0.0f : expf(Mrun[ii] - Mnew);
-          const float cf = MULTI ? expf(m_run - Mnew) : 1.0f;
-          Mrun[ii] = Mnew;
-          Lrun[ii] = Lrun[ii] * fac + l_run * cf;
-          const float inv = last ? 1.0f / Lrun[ii] : 1.0f;
-          // the probabilities of a step are relative to the running maximum of that step: rescale to the row maximum so far
-#pragma unroll
-          for (int T = 0; T < NT / 2 - (MULTI ? 0 : 1); ++T) {
-            const float f = FAST_EXP(m_hist[T] - Mnew);
-            if (l15 < 8) {
-#pragma unroll
-              for (int tl = 0; tl < 2; ++tl) {
-                f32x4* sp = reinterpret_cast<f32x4*>(Srow + (2 * T + tl) * 16 + 4 * q);
-                f32x4 pv = *sp;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pv[r] *= f;
-                *sp = pv;
-              }
-            }
-          }
-          // D: column = head l15, row 4 q + r <-> channel 16 ct + 4 q + r
-          if (l15 < 8) {
-            float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 4 * q;
-            const float sc = cf * oscale_r;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              f32x4 o = oe[ct];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] *= sc;
-              if (MULTI && c > 0) {
-                const f32x4 old = *reinterpret_cast<const f32x4*>(fo + 16 * ct);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += old[r] * fac;
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] *= inv;
-              *reinterpret_cast<f32x4*>(fo + 16 * ct) = o;
-            }
-            if (q == 0) {
-              st_fac[il * AH + h] = fac;
-              st_inv[il * AH + h] = inv;
-            }
-          }
-        }
-      } else {
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const int il = 2 * wv + ii;  // local row
-        float* Srow = S + il * IS + h * HS;
-        float lg[NT][4];  // logits, then exp(logit - M), of keys j = 16 jt + 4 q + r of this chunk for head h
-        float mx = -INFINITY;
-        stage_e(ii, 0);
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: half the dependent-MFMA latency
-          {
-            if (jt + 1 < NT) stage_e(ii, jt + 1);
-            const float* t_ = scr + (jt & 1) * (16 * ELD) + l15 * ELD + 4 * q;
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-              const f32x4 ea = *reinterpret_cast<const f32x4*>(t_ + 16 * sg);  // e[i][16 jt + l15][16 sg + 4 q + s]
-              const f32x4 wbf = MULTI ? *reinterpret_cast<const f32x4*>(wb_lds + (sg * 64 + lane) * 4) : wb[sg];
-#pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                if (sg & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc2, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s], wbf[s], acc, 0, 0, 0);
-              }
-            }
-          }
-          if (ii == 0 && jt + E_DEPTH0 < NT) {
-            load_e_tile(0, c, jt + E_DEPTH0);
-            MEM_FENCE();
-          }
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(Srow + jt * 16 + 4 * q);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = sv[r] + bscale * (acc[r] + acc2[r]);
-            lg[jt][r] = v;
-            mx = fmaxf(mx, v);
-          }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float Mnew = fmaxf(Mrun[ii], mx);
-        const float fac = c == 0 ? 0.0f : expf(Mrun[ii] - Mnew);  // rescale of everything accumulated before this chunk
-        float sum = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = FAST_EXP(lg[jt][r] - Mnew);
-            lg[jt][r] = p;
-            sum += p;
-          }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        Mrun[ii] = Mnew;
-        Lrun[ii] = Lrun[ii] * fac + sum;
-        const float inv = last ? 1.0f / Lrun[ii] : 1.0f;
-        // ---- exp(logit - M): to LDS for phase 3, and straight into the o_e product as its B operand
-        f32x4 oe[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) oe[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          const f32x4 pv = {lg[jt][0], lg[jt][1], lg[jt][2], lg[jt][3]};
-          if (l15 < 8) *reinterpret_cast<f32x4*>(Srow + jt * 16 + 4 * q) = pv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)  // A: e[i][j = 16 jt + 4 q + r][c = 4 l15 + ct]
-              oe[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[ii][jt][r][ct], pv[r], oe[ct], 0, 0, 0);
-          if (ii == 0 && jt >= E_LAG) {  // retired tiles free their registers: start the next row, E_LAG tiles behind
-            load_e_tile(1, c, jt - E_LAG);
-            MEM_FENCE();
-          }
-        }
-        if (ii == 0) {  // the last E_LAG tiles of the next row are needed last by its bias loop
-#pragma unroll
-          for (int jt = NT - E_LAG; jt < NT; ++jt) load_e_tile(1, c, jt);
-          MEM_FENCE();
-        }
-        // D: column h = l15, row m = 4 q + r' <-> channel 4 m + ct = 16 q + 4 r' + ct
-        if (l15 < 8) {
-          float* fo = feat + (prow0 + i0 + il) * AF + FOFF_OE + h * AC + 16 * q;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            f32x4 v = {oe[0][r], oe[1][r], oe[2][r], oe[3][r]};
-            if (c > 0) {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(fo + 4 * r);
-#pragma unroll
-              for (int s = 0; s < 4; ++s) v[s] += old[s] * fac;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) v[s] *= inv;
-            *reinterpret_cast<f32x4*>(fo + 4 * r) = v;
-          }
-          if (q == 0) {
-            st_fac[il * AH + h] = fac;
-            st_inv[il * AH + h] = inv;
-          }
-        }
-      }
-      }  // !PLANES
-    }
-    if (c == 0) stamp(3);
-
-    // ---------------------------------------------------------------- phase 3: wave = head
-    {
-      constexpr int PFV = 16;  // value prefetch distance, key steps (16 x 160 MFMA cycles ~ the loaded L2 latency)
-      const int h = wv;
-      const int pp = l15 & 7;
-      const float* vbase = proj + (krow0 + 4 * q) * ANP + OFF_VS + h * ADS + 2 * l15;  // + (16 jt + r) rows; d = 2 l15 + dt
-      const float* gbase = proj + (krow0 + 4 * q) * ANP + OFF_GV + h * 24 + 3 * pp;    // point pp, coords 0..2
-      // Point sums: columns 0..7 of ONE MFMA tile hold x of the 8 points, columns 8..15 y (z in a second tile, its upper half
-      // duplicates): 4 f32 MFMAs per key step instead of 5 - this phase is bound by exactly those (32 cycles each).
-      const int xy = l15 >> 3;  // 0: this lane's column is x of point pp, 1: y
-      float2 vs[NS];
-      float gxy[NS], gz[NS];
-      auto load_vals = [&](int stp) {
-        const int64_t o = static_cast<int64_t>((stp >> 2) * 16 + (stp & 3)) * ANP;
-        vs[stp] = *reinterpret_cast<const float2*>(vbase + o);
-        gxy[stp] = gbase[o + xy];
-        gz[stp] = gbase[o + 2];
-      };
-#pragma unroll
-      for (int stp = 0; stp < PFV && stp < NS; ++stp) load_vals(stp);
-      MEM_FENCE();
-      __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS
-      if (c == 0) stamp(4);
-      f32x4 os[2], og[2];  // og[0]: x | y of the points, og[1]: z
-#pragma unroll
-      for (int d = 0; d < 2; ++d) os[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) og[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 16 jt + 4 q + r]
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
-        if constexpr (TAPE) {  // P[i = l15][16 jt + 4 q ..]: the image holds exp(logit - M), the row's 1 / L is in st_inv
-          const float pinv = st_inv[l15 * AH + h];
-          *reinterpret_cast<f32x4*>(tape_p + ((static_cast<int64_t>(b) * AH + h) * K + i0 + l15) * K + jt * 16 + 4 * q) = pa * pinv;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int stp = jt * 4 + r;
-          if (stp + PFV < NS) {
-            load_vals(stp + PFV);
-            MEM_FENCE();
-          }
-          os[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[stp].x, os[0], 0, 0, 0);
-          os[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vs[stp].y, os[1], 0, 0, 0);
-          og[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gxy[stp], og[0], 0, 0, 0);
-          og[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], gz[stp], og[1], 0, 0, 0);
-        }
-      }
-      // D rows i = 4 q + r, column n = l15; earlier chunks' sums are rescaled through the feature row
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int il = 4 * q + r;
-        const int64_t row = prow0 + i0 + il;
-        const float fac = st_fac[il * AH + h], inv = st_inv[il * AH + h];
-        float* fr = feat + row * AF;
-        float2 o2 = make_float2(os[0][r], os[1][r]);
-        float2* po = reinterpret_cast<float2*>(fr + FOFF_OS + h * ADS + 2 * l15);
-        if (c > 0) {
-          const float2 old = *po;
-          o2.x += old.x * fac;
-          o2.y += old.y * fac;
-        }
-        o2.x *= inv;
-        o2.y *= inv;
-        *po = o2;
-        const float gy_lane = __shfl_xor(og[0][r], 8);  // lanes 0..7 hold x of point l15, lanes 8..15 y of point l15 - 8
-        if (l15 < 8) {
-          float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
-          float g0_ = og[0][r], g1_ = gy_lane, g2_ = og[1][r];
-          if (c > 0) {  // running (unnormalised, global-frame) sums are parked in the o_l slot between chunks
-            g0_ += fo[0] * fac;
-            g1_ += fo[1] * fac;
-            g2_ += fo[2] * fac;
-          }
-          if (last) {
-            const float* Rr = R + row * 9;
-            const float* tr = t + row * 3;
-            const float dx = g0_ * inv - tr[0], dy = g1_ * inv - tr[1], dz = g2_ * inv - tr[2];
-            const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
-            const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
-            const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
-            fo[0] = lx; fo[1] = ly; fo[2] = lz;
-            fr[FOFF_ON + h * AP + l15] = sqrtf(lx * lx + ly * ly + lz * lz);
-          } else {
-            fo[0] = g0_; fo[1] = g1_; fo[2] = g2_;
-          }
-        }
-      }
-    }
-    if (!last) __syncthreads();  // the next chunk's phase 1 overwrites the image
-  }
-  stamp(5);
+  ipa_attn_tile<NT, MULTI, PLANES, TAPE>(S, b, tile, bid, proj, e, R, t, Wb, gamma, feat, NC_arg, stamps, esc, tape_p, tape_d2);
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
@@ -1383,12 +699,30 @@ int launch_pair_split(const diffab_dims* d, const float* e, float* planes, hipSt
 // (gemm_bf16x6.hip; same results to fp32 rounding) - the plain-fp32 reference path
 bool use_b6_gemm(uint32_t flags) { return !(flags & DIFFAB_FLAG_FP32_GEMM); }
 static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
-size_t ipa_layer_planes_bytes() { return round256(proj_frames_b6_scratch_bytes()) + round256(rowgemm128_b6_scratch_bytes(AF)); }
+// one layer's prepared weights: [projection planes | to_out planes | small: w_bias 8 x 64, gamma 8 (padded to 64), b_out 128 (fp32)]
+// - the small vectors ride along so that the patch-resident module kernel (ipa_persistent.hip) finds everything of layer l at
+// base + l * ipa_layer_planes_bytes()
+constexpr size_t kLayerSmallFloats = AH * AC + 64 + 128;
+size_t ipa_layer_out_planes_offset() { return round256(proj_frames_b6_scratch_bytes()); }
+size_t ipa_layer_small_offset() { return ipa_layer_out_planes_offset() + round256(rowgemm128_b6_scratch_bytes(AF)); }
+size_t ipa_layer_planes_bytes() { return ipa_layer_small_offset() + round256(kLayerSmallFloats * sizeof(float)); }
+__global__ void layer_small_copy_kernel(const float* __restrict__ w_bias, const float* __restrict__ gamma, const float* __restrict__ b_out,
+                                        float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < AH * AC) out[i] = w_bias[i];
+  else if (i < AH * AC + 64) out[i] = i - AH * AC < AH ? gamma[i - AH * AC] : 0.0f;
+  else if (i < static_cast<int>(kLayerSmallFloats)) out[i] = b_out[i - AH * AC - 64];
+}
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st) {
   DIFFAB_REQUIRE(w && w->wq_s && w->wk_s && w->wv_s && w->wq_p && w->wk_p && w->wv_p && w->w_out, DIFFAB_ERR_ARG, "ipa layer: null weight pointer");
   const float* W6[6] = {w->wq_s, w->wk_s, w->wv_s, w->wq_p, w->wk_p, w->wv_p};
   if (int rc = launch_pjsplit(W6, planes, st)) return rc;
-  return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + round256(proj_frames_b6_scratch_bytes()), st);
+  if (w->w_bias && w->gamma && w->b_out) {
+    hipLaunchKernelGGL(layer_small_copy_kernel, dim3((kLayerSmallFloats + 255) / 256), dim3(256), 0, st, w->w_bias, w->gamma, w->b_out,
+                       reinterpret_cast<float*>(static_cast<char*>(planes) + ipa_layer_small_offset()));
+    DIFFAB_LAUNCH_CHECK();
+  }
+  return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + ipa_layer_out_planes_offset(), st);
 }
 static size_t b6_scratch_floats() { return (ipa_layer_planes_bytes() + 256) / sizeof(float); }
 
@@ -1417,7 +751,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     if (int rc = ipa_layer_split_weights(w, own, st)) return rc;
     planes = own;
   }
-  const void* out_planes = b6 ? static_cast<const char*>(planes) + round256(proj_frames_b6_scratch_bytes()) : nullptr;
+  const void* out_planes = b6 ? static_cast<const char*>(planes) + ipa_layer_out_planes_offset() : nullptr;
   // to_out (diffab_pytorch.py:459-464): feat (rows x 1024) Wo^T + b
   auto to_out = [&]() -> int {
     if (b6 && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
@@ -1459,7 +793,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   const bool tape = sp_keep != nullptr && attention_split_supported(d);  // K = 128: the fused kernel writes the tape itself
   const int nt = (d->K % 128 == 0) ? 8 : 4;  // key tiles per chunk
   const int nc = d->K / (16 * nt);            // key chunks (online softmax across them)
-  const size_t lds = (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4) * sizeof(float);
+  const size_t lds = ipa_attn_lds_bytes(nt);
   const dim3 grid(d->B * (d->K / TI));
   // pair_planes (launch_pair_split): the pair-tile products on the f16 matrix cores, the pair stream read as two fp16 planes
   const bool use_planes = pair_planes != nullptr && pair_planes_supported(d);

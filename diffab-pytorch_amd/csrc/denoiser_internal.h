@@ -73,7 +73,17 @@ int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C
                       float* const* seg_ptrs, const int* seg_ends, int nseg, hipStream_t st);  // db (nullable): += column sums of A
 // split planes of one IPA layer's projection and to_out weights: ipa_layer_planes_bytes() bytes, 256-byte aligned
 size_t ipa_layer_planes_bytes();
+size_t ipa_layer_out_planes_offset();  // the to_out planes inside a layer's block
+size_t ipa_layer_small_offset();       // fp32 copies of w_bias [8][64], gamma [8] (padded to 64), b_out [128] behind the planes
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);
+// ipa_persistent.hip: all NL layers of the IPA module for K = 128 patches as ONE patch-resident launch (one work-group owns a patch
+// through projections -> 8 attention row tiles -> to_out, layer after layer; no inter-CU synchronisation).  xa: input, the result is in
+// (NL odd ? xb : xa).  planes: NL x ipa_layer_planes_bytes(); pair_planes: launch_pair_split(); ws: proj | feat (ipa_fast_workspace_floats)
+bool ipa_module_persistent_supported(const diffab_dims* d);
+int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, const float* R, const float* t, float* ws, const void* planes,
+                                 const float* pair_planes, hipStream_t st);
+void set_module_stagger(int ticks, int classes);  // diagnostics: start-up stagger of the persistent module kernel (10 ns ticks)
+void set_module_stamps(void* device_buffer);      // diagnostics: phase stamps of the persistent module kernel
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)
 int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, const float* beta, float* emb_tab, float* beta_tab,
                        hipStream_t st, bool emb_tab_ready = false,

@@ -1,0 +1,158 @@
+// ipa_persistent.hip - the IPA module (all NL layers) of a batch of K = 128 patches as ONE patch-resident launch.
+//
+// BASELINE.json's execution model: one 512-thread work-group per CDR patch.  A work-group owns its patch from the first layer's
+// projections to the last layer's to_out - per layer: the six projections of its 128 rows (proj_frames_b6_tile.h), the eight 16-row
+// attention tiles (ipa_attn_tile.h), to_out (rowgemm_b6_tile.h) - and the next patch of its queue after that.  Patches never exchange
+// data on this path (every einsum of diffab_pytorch.py:416-457 carries `b`; the layer loop :494-498 is per sample), so there is NO
+// inter-CU synchronisation: a phase hands its rows to the next one through global memory written and read by the SAME work-group
+// (one CU, one vector L1: work-group scope; s_waitcnt vmcnt(0) + s_barrier), and the CUs are free to drift apart - which is the point:
+// started together by 18 separate launches, all 256 CUs stream their pair rows in the same 13-15 us and leave HBM idle for the next 25
+// (profiles/r03_lockstep.md); here the first items are staggered once per launch and nothing ever re-aligns them.
+//
+// Same tile bodies, same arithmetic, same summation orders as the multi-launch path: results are bitwise the same (tested), and with
+// them the sampler's shard invariance.
+#include "common.h"
+#include "denoiser_internal.h"
+#define AT_STAMP_REALTIME 1  // the diagnostic stamps of this file's kernels use the chip-wide 100 MHz counter (comparable between CUs)
+#include "ipa_attn_tile.h"
+#include "proj_frames_b6_tile.h"
+#include "rowgemm_b6_tile.h"
+
+namespace diffab {
+
+namespace {
+constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
+constexpr size_t kModuleLdsBytes =
+    cmax(ipa_attn_lds_bytes(8), cmax(static_cast<size_t>(pjtile::PJ_LDS_BYTES), static_cast<size_t>(b6tile::lds_bytes<128>())));
+
+struct ModuleArgs {
+  float* xa;                 // [B K][128]: the module's input (layer 0 reads it), then every odd layer's output
+  float* xb;                 // [B K][128]: every even layer's output; the result is in (NL odd ? xb : xa)
+  float* proj;               // [B K][1344] workspace
+  float* feat;               // [B K][1024] workspace
+  const float* pair;         // fp16 planes of the pair embedding (launch_pair_split)
+  const float* esc;          // {s, 1 / s} per pair row
+  const float* R;            // [B K][9]
+  const float* t;            // [B K][3]
+  const char* planes;        // per layer: ipa_layer_planes_bytes() (projection planes | to_out planes | w_bias, gamma, b_out)
+  size_t layer_stride, out_off, small_off;
+  unsigned long long* stamps;  // diagnostics (null in production): [item][wave][8] of the attention tiles + [B][NL][4] phase stamps behind them
+  int B, NL;
+  int stagger_ticks, stagger_classes;  // the work-groups of class c = (blockIdx / 8) % classes start c * ticks (10 ns each) late
+};
+}  // namespace
+
+__global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const ModuleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = 128, NTILE = K / TI;
+  const int M = a.B * K;
+  if (a.stagger_ticks > 0 && a.stagger_classes > 1) {
+    // (every wave waits for itself: no barrier needed, the first phase starts with loads only)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = static_cast<unsigned long long>((blockIdx.x >> 3) % a.stagger_classes) * a.stagger_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+  unsigned long long* pstamps = a.stamps ? a.stamps + static_cast<size_t>(a.B) * a.NL * NTILE * 64 : nullptr;
+  auto pstamp = [&](int b, int l, int k) {
+    if (pstamps != nullptr && threadIdx.x == 0) pstamps[(static_cast<size_t>(b) * a.NL + l) * 4 + k] = __builtin_amdgcn_s_memrealtime();
+  };
+#pragma unroll 1
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+#pragma unroll 1
+    for (int l = 0; l < a.NL; ++l) {
+      const char* lp = a.planes + static_cast<size_t>(l) * a.layer_stride;
+      const float* small = reinterpret_cast<const float*>(lp + a.small_off);  // [w_bias 8 x 64][gamma 8, pad to 64][b_out 128]
+      const float* xin = (l & 1) ? a.xb : a.xa;
+      float* xout = (l & 1) ? a.xa : a.xb;
+      pstamp(b, l, 0);
+      {  // ---- the six projections + frames of the patch's 128 rows
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (an opaque copy per phase: lane-constant addresses must not stay live across the phases)
+        pjtile::proj_frames_b6_tile<true, true, false>(reinterpret_cast<__bf16*>(lds), tid, b, 0, 1, xin, reinterpret_cast<const __bf16*>(lp),
+                                                       a.R, a.t, a.proj, M, 0, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      pstamp(b, l, 1);
+      // ---- attention: the eight row tiles of the patch
+      // (a tile's first phase-1 operands - 344 KiB per work-group - are requested inside the PREVIOUS tile's phase 3; the first tile's here)
+      AttnP1Pre<4> pre;
+      {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int piece = 4; piece >= 0; --piece)
+          attn_p1_request<4>(pre, piece, a.proj, static_cast<int64_t>(b) * K, static_cast<int64_t>(b) * K, 0, lane, attn_lane_off(lane), wv);
+      }
+#pragma unroll 1
+      for (int tile = 0; tile < NTILE; ++tile) {
+        ipa_attn_tile<8, false, true, false, true>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R, a.t,
+                                                   small, small + 512, a.feat, 1, a.stamps, a.esc, nullptr, nullptr, &pre,
+                                                   tile + 1 < NTILE ? tile + 1 : NTILE - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the next tile's phase 1 overwrites the image; the last tile's feature rows are complete
+      }
+      pstamp(b, l, 2);
+      {  // ---- to_out
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        b6tile::rowgemm128_tile<false, 128>(reinterpret_cast<__bf16*>(lds), tid, b, a.feat, AF, reinterpret_cast<const __bf16*>(lp + a.out_off),
+                                            small + 576, nullptr, 0, xout, 128, M, AF);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      pstamp(b, l, 3);
+    }
+  }
+}
+
+namespace {
+int g_stagger_ticks = 500, g_stagger_classes = 8;  // 8 classes x 5 us: one attention-tile period (profiles/r03_lockstep.md section 3)
+unsigned long long* g_module_stamps = nullptr;
+}  // namespace
+void set_module_stagger(int ticks, int classes) {
+  g_stagger_ticks = ticks;
+  g_stagger_classes = classes;
+}
+void set_module_stamps(void* p) { g_module_stamps = static_cast<unsigned long long*>(p); }
+
+bool ipa_module_persistent_supported(const diffab_dims* d) { return fast_path_supported(d) && d->K == 128 && d->NL >= 1; }
+
+// planes: d->NL x ipa_layer_planes_bytes() (ipa_layer_split_weights); pair_planes: launch_pair_split(); xa in, result in (NL odd ? xb : xa)
+int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, const float* R, const float* t, float* ws, const void* planes,
+                                 const float* pair_planes, hipStream_t st) {
+  DIFFAB_REQUIRE(ipa_module_persistent_supported(d) && xa && xb && R && t && ws && planes && pair_planes, DIFFAB_ERR_ARG,
+                 "ipa_module_persistent: unsupported operands");
+  const size_t rows = static_cast<size_t>(d->B) * d->K;
+  ModuleArgs a{};
+  a.xa = xa;
+  a.xb = xb;
+  a.proj = ws;
+  a.feat = ws + rows * ANP;
+  a.pair = pair_planes + 64;
+  a.esc = pair_row_scales(d, pair_planes);
+  a.R = R;
+  a.t = t;
+  a.planes = static_cast<const char*>(planes);
+  a.layer_stride = ipa_layer_planes_bytes();
+  a.out_off = ipa_layer_out_planes_offset();
+  a.small_off = ipa_layer_small_offset();
+  a.stamps = g_module_stamps;
+  a.B = d->B;
+  a.NL = d->NL;
+  a.stagger_ticks = g_stagger_ticks;
+  a.stagger_classes = g_stagger_classes;
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = d->B < ncu ? d->B : ncu;  // one work-group per CU (149 KiB of LDS each); more patches than CUs: a work-group walks its queue
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_module_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(kModuleLdsBytes)));
+  timer_begin(st);
+  hipLaunchKernelGGL(ipa_module_persistent_kernel, dim3(grid), dim3(512), kModuleLdsBytes, st, a);
+  timer_end(st);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // namespace diffab

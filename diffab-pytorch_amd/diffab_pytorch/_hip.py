@@ -22,6 +22,7 @@ FLAG_PAIR_F32 = 64  # sample_loop: keep the fp32 pair stream (no fp16 planes)
 FLAG_FP32_GEMM = 128  # forward paths: dense products on the f32-input MFMA kernels instead of the bf16 split
 FLAG_PAIR_PLANES = 32  # K = 64 / 128: pair embedding as two fp16 planes, pair-tile products on the f16 matrix cores (always on in sample_loop)
 FLAG_GRAPH_SAMPLER = 16  # sample_loop: one captured step replayed as a hipGraph (launch-bound small batches)
+FLAG_PERSISTENT_MODULE = 512  # MFMA path, K = 128, pair planes: the IPA module as one patch-resident launch (bitwise the multi-launch result)
 FLAG_SKIP_UNUSED_ROWS = 256  # sample_loop: the last layer's attention only for row tiles with a generated residue (same trajectory)
 
 
@@ -87,6 +88,8 @@ SYMBOLS = {
     "diffab_device_ok": (C.c_int, []),
     "diffab_kernel_timer_enable": (C.c_int, [C.c_int]),
     "diffab_debug_set_attn_stamps": (C.c_int, [_fp]),
+    "diffab_debug_set_module_stagger": (C.c_int, [_i32, _i32]),
+    "diffab_debug_set_module_stamps": (C.c_int, [_fp]),
     "diffab_set_stream_guard": (C.c_int, [C.c_int]),
     "diffab_debug_linear128": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp]),
     "diffab_kernel_timer_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

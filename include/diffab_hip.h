@@ -20,7 +20,7 @@
  *     never synchronise on the host; no hidden global state beyond the stream guard below; the
  *     library never reads the environment.  Two DIAGNOSTIC entry points keep
  *     process-global state and are off by default: diffab_kernel_timer_enable/read
- *     (an event list) and diffab_debug_set_attn_stamps (a stamp-buffer pointer);
+ *     (an event list) and diffab_debug_set_attn_stamps / diffab_debug_set_module_stamps / _stagger (stamp-buffer pointers, two ints);
  *     they are not thread-safe and must not be left enabled in production.
  *     DIFFAB_FLAG_GRAPH_SAMPLER makes diffab_sample_loop drain a private stream
  *     before it returns.  (Kernel variants that were measured and not adopted, the environment
@@ -76,6 +76,12 @@ extern "C" {
                                          eager trajectory.  The call drains its private replay stream before it returns (the graph
                                          must outlive its launches).  Measured at B = 1, K = 128: no gain (the host already runs
                                          ahead of the device; a step is 45 dependent small-grid kernels), hence opt-in. */
+#define DIFFAB_FLAG_PERSISTENT_MODULE 512u /* MFMA path with pair planes, K = 128 (diffab_sample_loop, or a single call with
+                                         DIFFAB_FLAG_PAIR_PLANES): the NL layers of the IPA module (reference diffab_pytorch.py:494-498)
+                                         run as ONE patch-resident launch - a 512-thread work-group owns a patch through projections,
+                                         eight attention row tiles and to_out, layer after layer, with no inter-CU synchronisation
+                                         (patches never exchange data) - instead of 3 NL chip-wide launches.  Same tile bodies:
+                                         bitwise the multi-launch result.  Ignored where it does not apply. */
 #define DIFFAB_FLAG_SKIP_UNUSED_ROWS 256u /* diffab_sample_loop (MFMA path, K % 16 == 0): a step's outputs are read for GENERATED residues
                                          only (diffab_reverse_update leaves the others alone), so the LAST layer's attention runs only
                                          for the 16-row tiles that contain one (every other layer feeds all rows' keys and values to the
@@ -164,6 +170,11 @@ int diffab_kernel_timer_enable(int on);
 /* Diagnostics only: while a device buffer of (work-groups x 8 waves x 8) uint64 is registered, the fused attention kernel
  * writes s_memtime stamps at its phase boundaries into it (tools/attn_phase_profile.py).  NULL (default) disables it. */
 int diffab_debug_set_attn_stamps(void* device_buffer);
+/* Diagnostics of the patch-resident module kernel (DIFFAB_FLAG_PERSISTENT_MODULE): its start-up stagger (work-groups of class
+ * (index / 8) % classes start class x ticks late, ticks of 10 ns; default 8 x 500 = one attention-tile period spread over 8 classes),
+ * and a stamp buffer of (B NL 8 tiles x 8 waves x 8) + (B NL 4) uint64 filled with 100 MHz s_memrealtime stamps (NULL: off). */
+int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes);
+int diffab_debug_set_module_stamps(void* device_buffer);
 /* The cross-stream ordering guard described under "Streams" above: on (default) / off, process-wide. */
 int diffab_set_stream_guard(int on);
 /* Diagnostics / accuracy tests: Y[M x 128] = X[M x Kd] W[128 x Kd]^T + bias through ONE of the two dense kernels of the MFMA path -
