@@ -408,6 +408,11 @@ int diffab_debug_set_module_stamps(void* device_buffer) {
   return DIFFAB_OK;
 }
 
+int diffab_debug_set_attn_variant(int32_t v) {
+  set_attn_variant(v);
+  return DIFFAB_OK;
+}
+
 int diffab_debug_set_attn_stamps(void* device_buffer) {
   set_attn_stamps(device_buffer);
   return DIFFAB_OK;
@@ -641,6 +646,16 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
   const bool pair_ready = use_pair_planes(d, flags, pair_ctx, b0);
   if (pair_ready)
     if (int rc = launch_pair_split(d, pair_ctx, b0.pair, st)) return rc;
+  // The IPA module as ONE patch-resident launch per step (ipa_persistent.hip; bitwise the 3 NL launches it replaces, so the choice never
+  // shows in the samples) when the batch fills the chip with one work-group per patch: B = 256 is 2.60 ms per step against 2.70.  Fewer
+  // patches than CUs leave CUs idle for the whole module (B = 8: 2.07 ms against 0.47), a ragged last round of patches costs a module
+  // time for a few of them - those shapes keep the per-layer launches.
+  if (!(flags & DIFFAB_FLAG_MULTI_LAUNCH) && pair_ready && fold && use_b6_gemm(flags) && ipa_module_persistent_supported(d)) {
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int rounds = (d->B + ncu - 1) / ncu;
+    if (d->B >= ncu && static_cast<double>(d->B) >= 0.85 * rounds * ncu) flags |= DIFFAB_FLAG_PERSISTENT_MODULE;
+  }
   // DIFFAB_FLAG_SKIP_UNUSED_ROWS: the step's outputs (eps, O0, posterior) are read for GENERATED residues only (reverse_update leaves
   // the others alone), so the last layer's attention is needed only for row tiles that contain one; every other layer feeds keys and
   // values of all rows to the next.  Same trajectory, bit for bit; the work skipped depends on the mask, so bench.py's headline keeps it off.

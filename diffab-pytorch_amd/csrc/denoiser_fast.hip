@@ -347,8 +347,8 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
 // ================================================================== fused IPA attention (benchmark geometry)
 // The body is ipa_attn_tile.h (a device function, shared with the patch-resident module kernel of ipa_persistent.hip); here one
 // work-group per (patch, 16 query residues), grid = B K / 16.
-template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false>
-__global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
+template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
@@ -371,10 +371,12 @@ __global__ __launch_bounds__(512) void ipa_attn_fast_kernel(const float* __restr
   // tile_needed (reverse sampler, last layer, DIFFAB_FLAG_SKIP_UNUSED_ROWS): the outputs of this layer are read for generated residues
   // only - a row tile without one leaves at once (uniform; its feature rows keep the previous layer's values, which nothing reads)
   if (tile_needed != nullptr && !tile_needed[b * ntile + tile]) return;
-  ipa_attn_tile<NT, MULTI, PLANES, TAPE>(S, b, tile, bid, proj, e, R, t, Wb, gamma, feat, NC_arg, stamps, esc, tape_p, tape_d2);
+  ipa_attn_tile<NT, MULTI, PLANES, TAPE, NW>(S, b, tile, bid, proj, e, R, t, Wb, gamma, feat, NC_arg, stamps, esc, tape_p, tape_d2);
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
+static int g_attn_variant = 0;                       // diagnostics only (diffab_debug_set_attn_variant): 1 = four-wave work-groups
+void set_attn_variant(int v) { g_attn_variant = v; }
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);
 }
@@ -813,6 +815,16 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     hipLaunchKernelGGL((ipa_attn_fast_kernel<8, false, false, true>), grid, dim3(512), lds, st, proj, e, R, t, w->w_bias, w->gamma, feat,
                        d->B, nc, nullptr, nullptr, sp_keep, d2_keep);
+  } else if (use_planes && g_attn_variant == 1) {
+    // four-wave work-groups, two per CU, 64-key chunks (ipa_attn_tile.h, NW = 4)
+    const int nc4 = d->K / 64;
+    const size_t lds4 = ipa_attn_lds_bytes(4, 4, true);
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<4, true, true, false, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds4)));
+    timer_begin(st);
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<4, true, true, false, 4>), grid, dim3(256), lds4, st, proj, e_arg, R, t, w->w_bias, w->gamma, feat,
+                       d->B, nc4, g_attn_stamps, esc, nullptr, nullptr, tile_needed);
+    timer_end(st);
   } else if (use_planes) {
     if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, true);
     else if (nt == 8) ATTN_LAUNCH(8, true, true);

@@ -103,6 +103,7 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
                            const float* gamma, float* feat, float* SP, hipStream_t st, float* D2 = nullptr);
 
 void set_stream_order(bool on);  // api.hip: the cross-stream ordering guard (common.h StreamOrder)
+void set_attn_variant(int v);  // diagnostics: 1 = the four-wave / two-groups-per-CU form of the plane attention kernel
 void set_attn_stamps(void* device_buffer);  // diagnostics: per-wave s_memtime stamps of the attention kernel's phases
 
 // api.hip: opt-in hipEvent bracket around the dominant (attention) kernel

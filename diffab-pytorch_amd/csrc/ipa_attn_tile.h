@@ -52,9 +52,10 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 // (profiles/r05_persistent.md: 261 per wave and item = 19.9 us of the item's 40), so operands are fetched as FULL 1 KiB wave
 // instructions in memory order ("line-shaped": consecutive lanes on consecutive 16-byte chunks) and re-oriented through LDS.
 //
-// Phase 1's first operands of an item - the first SD key tiles of the wave's head (k_s 16 x 128 B + gk 16 x 96 B per tile), the q_s
-// fragments and the query points of the item's 16 rows (16 x 96 B, line-shaped like a gk tile) - as registers that can be requested
-// AHEAD of the item: the patch-resident kernel issues them inside the previous item's phase 3 (CARRY).
+// Phase 1's first operands of an item: the first SD key tiles of the wave's head (k_s 16 x 128 B + gk 16 x 96 B per tile), the q_s
+// fragments and the query points of the item's 16 rows (16 x 96 B, line-shaped like a gk tile).  (Requested inside the PREVIOUS item's
+// phase 3 by the patch-resident kernel - measured: phase 1 -3 us, phase 3 +2.2, phase 2 +1: the memory pipe is busy either way -
+// and dropped; profiles/r05_persistent.md.)
 template <int SD>
 struct AttnP1Pre {
   f32x4 st[SD][4];
@@ -100,18 +101,19 @@ __device__ __forceinline__ void attn_p1_request(AttnP1Pre<SD>& pre, const int pi
 // One (patch b, 16-row tile) item of the fused attention: the body of ipa_attn_fast_kernel (denoiser_fast.hip: one item per work-group)
 // and of the patch-resident module kernel (ipa_persistent.hip: a work-group walks the eight row tiles of ITS patch, layer after layer).
 // 512 threads; S: the dynamic LDS (ipa_attn_lds_bytes(NT)); stamp_id: the slot of this item in the diagnostic stamp buffer.
-// CARRY (single-chunk form only): `carry` holds this item's phase-1 operands on entry (attn_p1_request pieces 0 .. SD, issued by
-// the caller or by the previous item) and item `next_tile`'s on exit.
-template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, bool CARRY = false>
+// NW: waves of the work-group (8: wave = head in phases 1 and 3, two rows in phase 2; 4: two heads / four rows per wave - the form that
+// fits two work-groups on a CU: with the 64-key chunk image its LDS is 79.5 KiB, and the two groups' phases interleave on the CU's pipes).
+template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8>
 __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b, const int tile, const unsigned stamp_id,
                                               const float* __restrict__ proj, const float* __restrict__ e,
                                               const float* __restrict__ R, const float* __restrict__ t,
                                               const float* __restrict__ Wb, const float* __restrict__ gamma,
                                               float* __restrict__ feat, int NC_arg,
                                               unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr,
-                                              float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr,
-                                              AttnP1Pre<(MULTI ? 3 : 4)>* carry = nullptr, const int next_tile = 0) {
-  static_assert(!CARRY || !MULTI, "operands are carried between items of the single-chunk form");
+                                              float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr) {
+  static_assert(NW == 8 || (NW == 4 && PLANES && !TAPE), "the four-wave form exists for the plane kernels");
+  constexpr int HPW = AH / NW;  // heads per wave (phases 1 and 3)
+  constexpr int RPW = TI / NW;  // query rows per wave (phase 2)
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
   static_assert(!TAPE || (!MULTI && !PLANES), "the tape form is the single-chunk fp32-pair kernel");
   const int NC = MULTI ? NC_arg : 1;
@@ -166,10 +168,10 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
 #endif
   constexpr int E_EARLY = MULTI ? DIFFAB_E_EARLY : DIFFAB_E_EARLY_SINGLE;  // pair tiles of phase 2's first row started under the tail of phase 1
   float* scr = S + TI * IS + wv * SCR_FLOATS;
-  float* st_fac = S + TI * IS + 8 * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
+  float* st_fac = S + TI * IS + NW * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
   float* st_inv = st_fac + TI * AH;              // [TI][AH] 1 / L after the last chunk (1 before)
   float* wb_lds = st_inv + TI * AH;              // [4 sg][64 lanes][4]: B fragments of the bias product (same for every wave)
-  float* gq_lds = wb_lds + 4 * 64 * 4 + wv * (TI * 24);  // per wave: the item's query points of its head, [16 rows][24] as loaded
+  float* gq_lds = wb_lds + (PLANES ? 0 : 4 * 64 * 4) + wv * (TI * 24);  // per wave: the item's query points of its head, [16 rows][24] as loaded
   if (wv == 0 && !PLANES) {  // Wb[h][16 sg + 4 q + s] for lane (h = l15 < 8, q), zero in the padding columns; first read is behind a barrier
     const int l15_ = lane0 & 15, q_ = lane0 >> 4;
 #pragma unroll
@@ -185,17 +187,23 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
   // must not evict the K/V-side operands, re-read by the other row tiles of the patch, from L2), in the orientation of
   // the o_e product: lane (l15, q) holds e[i][j = 16 jt + 4 q + r][c = 4 l15 .. 4 l15 + 3] - 1 KiB contiguous per load.
   // A chunk of a row (16 NT VGPRs) stays in registers from the bias product to the o_e product.
-  const float* erow[2];
-  erow[0] = e + ((prow0 + i0 + 2 * wv) * K) * AC;
-  erow[1] = erow[0] + static_cast<int64_t>(K) * AC;
-  float Mrun[2] = {-INFINITY, -INFINITY}, Lrun[2] = {0.f, 0.f};  // online-softmax state of (row 2 wv + ii, head l15 & 7)
+  const float* erow[RPW];
+  float Mrun[RPW], Lrun[RPW];  // online-softmax state of (row RPW wv + ii, head l15 & 7)
+#pragma unroll
+  for (int ii = 0; ii < RPW; ++ii) {
+    erow[ii] = e + ((prow0 + i0 + RPW * wv + ii) * K) * AC;
+    Mrun[ii] = -INFINITY;
+    Lrun[ii] = 0.f;
+  }
   // PLANES: 1 / s_i of the wave's two pair rows, fetched here through the scalar cache (wave-uniform address).  As a vector load at
   // the top of each row its s_waitcnt - vmcnt retires in order - drained every pair tile in flight, twice per wave and phase 2.
-  float inv_s2[2] = {1.0f, 1.0f};
+  float inv_s2[RPW];
+#pragma unroll
+  for (int ii = 0; ii < RPW; ++ii) inv_s2[ii] = 1.0f;
   if constexpr (PLANES) {
-    const float* ep = esc + 2 * (prow0 + i0 + 2 * __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
-    inv_s2[0] = ep[1];
-    inv_s2[1] = ep[3];
+    const float* ep = esc + 2 * (prow0 + i0 + RPW * __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+#pragma unroll
+    for (int ii = 0; ii < RPW; ++ii) inv_s2[ii] = ep[2 * ii + 1];
   }
 
 #pragma unroll 1
@@ -207,7 +215,7 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int l15 = lane & 15, q = lane >> 4;
-    f32x4 ev[2][NT][4];
+    f32x4 ev[RPW][NT][4];
     f32x4 wv4[2][2];  // PLANES: the bias weights of lane (head, channel group), requested in phase 1's tail AHEAD of the first pair tiles:
                       // vmcnt retires in order, so loaded behind them they would cost every wave a pair-tile latency in front of the barrier
     auto load_e_tile = [&](int ii, int cc_, int jt) {
@@ -221,9 +229,10 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         for (int r = 0; r < 4; ++r) ev[ii][jt][r] = __builtin_nontemporal_load(ep + r * (AC / 4));
       }
     };
-    // ---------------------------------------------------------------- phase 1: wave = head
-    {
-      const int h = wv;
+    // ---------------------------------------------------------------- phase 1: wave = head (NW = 4: two heads, one after the other)
+#pragma unroll
+    for (int hw = 0; hw < HPW; ++hw) {
+      const int h = HPW * wv + hw;
       const float scale_s = 0.17677669529663687f;                    // 32^-1/2  (:353)
       const float coef_p = -0.5f * 0.16666666666666666f * gamma[h];  // -1/2 (4.5*8)^-1/2 gamma_h  (:372, :431-436)
       // line-shaped loads of one key tile (16 keys): k_s 16 x 128 B (8 lanes per key), gk 16 x 96 B (6 lanes per key)
@@ -232,8 +241,7 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
       const int gk_dst0 = 16 * KLD + (g0 / 6) * GLD + 4 * (g0 % 6), gk_dst1 = 16 * KLD + (g1 / 6) * GLD + 4 * (g1 % 6);
       constexpr int SD = MULTI ? 3 : 4;  // register staging depth: SD - 1 key tiles of lookahead
       static_assert(E_EARLY <= SD, "the early pair tiles are requested in the last E_EARLY iterations, which must not request key tiles any more");
-      AttnP1Pre<SD> pre_own;
-      AttnP1Pre<SD>& pre = CARRY ? *carry : pre_own;
+      AttnP1Pre<SD> pre;
       f32x4 (&st)[SD][4] = pre.st;
       const AttnLaneOff lo = attn_lane_off(lane);
       auto load_keys = [&](int sb, int jt) { attn_tile_request(st[sb], proj, krow0 + 16 * jt, OFF_KS, OFF_GK, lo, h); };
@@ -245,11 +253,10 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         if (g1 < 96) *reinterpret_cast<f32x4*>(t_ + gk_dst1) = st[sb][3];
       };
       // the first SD key tiles; A operand: q_s rows i0 + l15, k = 16 sg + 4 q + s; the 16 rows' query points
-      if constexpr (!CARRY) {  // (the query side first: its LDS round trip runs while the key tiles arrive)
-        attn_p1_request<SD>(pre, SD, proj, prow0, krow0, i0, lane, lo, h);
+      // (the query side first: its LDS round trip runs while the key tiles arrive)
+      attn_p1_request<SD>(pre, SD, proj, prow0, krow0, i0, lane, lo, h);
 #pragma unroll
-        for (int piece = 0; piece < SD && piece < NT; ++piece) attn_p1_request<SD>(pre, piece, proj, prow0, krow0, i0, lane, lo, h);
-      }
+      for (int piece = 0; piece < SD && piece < NT; ++piece) attn_p1_request<SD>(pre, piece, proj, prow0, krow0, i0, lane, lo, h);
       f32x4 (&qa)[2] = pre.qa;
       MEM_FENCE();
       // query points of the 4 rows this lane accumulates (rows i0 + 4q + r): through the wave's LDS tile - 2 vector-memory instructions
@@ -286,7 +293,7 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         if (jt + 1 < NT) nxt = read_frags(jt + 1);
         if (jt + SD < NT) {
           load_keys(jt % SD, jt + SD);  // slot of tile jt (staged two iterations ago)
-        } else if (jt + E_EARLY >= NT) {
+        } else if (jt + E_EARLY >= NT && hw == HPW - 1) {
           if constexpr (PLANES) {
             if (jt + E_EARLY == NT) {
               const int hh = lane & 7, qq = lane >> 4;
@@ -331,8 +338,8 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
           S[(4 * q + r) * IS + h * HS + jt * 16 + l15] = scale_t * (acc[r] * scale_s + coef_p * d2);
           if constexpr (TAPE) tape_d2[((static_cast<int64_t>(b) * AH + h) * K + i0 + 4 * q + r) * K + jt * 16 + l15] = d2;
         }
-        if (c == 0 && jt == 0) stamp(6);
-        if (c == 0 && jt == 3) stamp(7);
+        if (c == 0 && jt == 0 && hw == 0) stamp(6);
+        if (c == 0 && jt == 3 && hw == 0) stamp(7);
       }
     }
     if (c == 0) stamp(1);
@@ -415,8 +422,8 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         const int rrow = 4 * q + (l15 >> 2);
         const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // ^ 32 ct: unit 4 ct + (l15 & 3) of row rrow
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const int il = 2 * wv + ii;  // local row
+        for (int ii = 0; ii < RPW; ++ii) {
+          const int il = RPW * wv + ii;  // local row
           float* Srow = S + il * IS + h * HS;
           const float inv_s = inv_s2[ii];  // 1 / s_i: the power-of-two scale of this pair row's planes
           const float bscale_r = bscale * inv_s, oscale_r = oscale * inv_s;
@@ -490,7 +497,7 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
               constexpr int dummy_ = 0;
               (void)dummy_;
               const int nx = ii * NT + 2 * T + RT;  // compile-time after unrolling
-              if (nx < 2 * NT) {
+              if (nx < RPW * NT) {
                 load_e_tile(nx / NT, c, nx % NT);
                 load_e_tile((nx + 1) / NT, c, (nx + 1) % NT);
                 MEM_FENCE();
@@ -667,9 +674,10 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
     }
     if (c == 0) stamp(3);
 
-    // ---------------------------------------------------------------- phase 3: wave = head
-    {
-      const int h = wv;
+    // ---------------------------------------------------------------- phase 3: wave = head (NW = 4: two heads, one after the other)
+#pragma unroll
+    for (int hw = 0; hw < HPW; ++hw) {
+      const int h = HPW * wv + hw;
       const int pp = l15 & 7;
       // Point sums: columns 0..7 of ONE MFMA tile hold x of the 8 points, columns 8..15 y (z in a second tile, its upper half
       // duplicates): 4 f32 MFMAs per key step instead of 5 - this phase is bound by exactly those (32 cycles each).
@@ -710,8 +718,10 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
 #pragma unroll
       for (int jt = 0; jt < SD3; ++jt) load_vals(jt, jt);
       MEM_FENCE();
-      __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS (the first value tiles arrive during the wait)
-      if (c == 0) stamp(4);
+      if (hw == 0) {
+        __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS (the first value tiles arrive during the wait)
+        if (c == 0) stamp(4);
+      }
       stage_vals(0, 0);
       ValFrag vcur = read_vfrags(0);
       if (NT > 1) stage_vals(1 % SD3, 1);
@@ -728,12 +738,6 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         if (jt + 1 < NT) vnxt = read_vfrags(jt + 1);
         if (jt + SD3 < NT) {
           load_vals(jt % SD3, jt + SD3);
-          MEM_FENCE();
-        } else if constexpr (CARRY) {  // the value stream is complete: the next item's phase-1 operands, a piece per key tile
-          constexpr int SDc = MULTI ? 3 : 4;
-          const int piece = jt + SD3 - NT;  // 0 .. SD3 - 1
-          if (piece == 0) attn_p1_request<SDc>(*carry, SDc, proj, prow0, prow0, next_tile * TI, lane3, lo3, wv);
-          if (piece < SDc) attn_p1_request<SDc>(*carry, piece, proj, prow0, prow0, next_tile * TI, lane3, lo3, wv);
           MEM_FENCE();
         }
         const f32x4 pa = *reinterpret_cast<const f32x4*>(Prow + jt * 16);
@@ -797,8 +801,8 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
 }
 
 // dynamic LDS of one item: logits image + per-wave scratch + softmax state + bias fragments + per-wave query-point tiles
-constexpr size_t ipa_attn_lds_bytes(int nt) {
-  return (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + 8 * 2 * 16 * 72 + 2 * TI * AH + 4 * 64 * 4 + 8 * TI * 24) * sizeof(float);
+constexpr size_t ipa_attn_lds_bytes(int nt, int nw = 8, bool planes = false) {
+  return (static_cast<size_t>(TI) * (AH * (16 * nt + 8) + 8) + nw * 2 * 16 * 72 + 2 * TI * AH + (planes ? 0 : 4 * 64 * 4) + nw * TI * 24) * sizeof(float);
 }
 
 }  // namespace diffab

@@ -75,21 +75,10 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       __syncthreads();
       pstamp(b, l, 1);
       // ---- attention: the eight row tiles of the patch
-      // (a tile's first phase-1 operands - 344 KiB per work-group - are requested inside the PREVIOUS tile's phase 3; the first tile's here)
-      AttnP1Pre<4> pre;
-      {
-        int lane = threadIdx.x & 63;
-        asm volatile("" : "+v"(lane));
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll
-        for (int piece = 4; piece >= 0; --piece)
-          attn_p1_request<4>(pre, piece, a.proj, static_cast<int64_t>(b) * K, static_cast<int64_t>(b) * K, 0, lane, attn_lane_off(lane), wv);
-      }
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
-        ipa_attn_tile<8, false, true, false, true>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R, a.t,
-                                                   small, small + 512, a.feat, 1, a.stamps, a.esc, nullptr, nullptr, &pre,
-                                                   tile + 1 < NTILE ? tile + 1 : NTILE - 1);
+        ipa_attn_tile<8, false, true, false>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R, a.t, small,
+                                             small + 512, a.feat, 1, a.stamps, a.esc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the next tile's phase 1 overwrites the image; the last tile's feature rows are complete
       }

@@ -23,6 +23,7 @@ FLAG_FP32_GEMM = 128  # forward paths: dense products on the f32-input MFMA kern
 FLAG_PAIR_PLANES = 32  # K = 64 / 128: pair embedding as two fp16 planes, pair-tile products on the f16 matrix cores (always on in sample_loop)
 FLAG_GRAPH_SAMPLER = 16  # sample_loop: one captured step replayed as a hipGraph (launch-bound small batches)
 FLAG_PERSISTENT_MODULE = 512  # MFMA path, K = 128, pair planes: the IPA module as one patch-resident launch (bitwise the multi-launch result)
+FLAG_MULTI_LAUNCH = 1024  # sample_loop: never choose the patch-resident module launch (bitwise the same samples either way)
 FLAG_SKIP_UNUSED_ROWS = 256  # sample_loop: the last layer's attention only for row tiles with a generated residue (same trajectory)
 
 
@@ -88,6 +89,7 @@ SYMBOLS = {
     "diffab_device_ok": (C.c_int, []),
     "diffab_kernel_timer_enable": (C.c_int, [C.c_int]),
     "diffab_debug_set_attn_stamps": (C.c_int, [_fp]),
+    "diffab_debug_set_attn_variant": (C.c_int, [_i32]),
     "diffab_debug_set_module_stagger": (C.c_int, [_i32, _i32]),
     "diffab_debug_set_module_stamps": (C.c_int, [_fp]),
     "diffab_set_stream_guard": (C.c_int, [C.c_int]),

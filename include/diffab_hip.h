@@ -81,7 +81,11 @@ extern "C" {
                                          run as ONE patch-resident launch - a 512-thread work-group owns a patch through projections,
                                          eight attention row tiles and to_out, layer after layer, with no inter-CU synchronisation
                                          (patches never exchange data) - instead of 3 NL chip-wide launches.  Same tile bodies:
-                                         bitwise the multi-launch result.  Ignored where it does not apply. */
+                                         bitwise the multi-launch result.  Ignored where it does not apply.  diffab_sample_loop
+                                         chooses it by itself when the batch fills the chip (B >= number of CUs), see
+                                         DIFFAB_FLAG_MULTI_LAUNCH; with DIFFAB_FLAG_SKIP_UNUSED_ROWS the per-layer launches stay. */
+#define DIFFAB_FLAG_MULTI_LAUNCH 1024u /* diffab_sample_loop: keep one launch per kernel of an IPA layer even where the patch-resident module
+                                          launch would be chosen (B >= number of CUs, K = 128); the two forms are bitwise equal */
 #define DIFFAB_FLAG_SKIP_UNUSED_ROWS 256u /* diffab_sample_loop (MFMA path, K % 16 == 0): a step's outputs are read for GENERATED residues
                                          only (diffab_reverse_update leaves the others alone), so the LAST layer's attention runs only
                                          for the 16-row tiles that contain one (every other layer feeds all rows' keys and values to the
@@ -173,6 +177,7 @@ int diffab_debug_set_attn_stamps(void* device_buffer);
 /* Diagnostics of the patch-resident module kernel (DIFFAB_FLAG_PERSISTENT_MODULE): its start-up stagger (work-groups of class
  * (index / 8) % classes start class x ticks late, ticks of 10 ns; default 8 x 500 = one attention-tile period spread over 8 classes),
  * and a stamp buffer of (B NL 8 tiles x 8 waves x 8) + (B NL 4) uint64 filled with 100 MHz s_memrealtime stamps (NULL: off). */
+int diffab_debug_set_attn_variant(int32_t v); /* A/B switch of the plane attention kernel: 0 default, 1 four-wave work-groups (two per CU) */
 int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes);
 int diffab_debug_set_module_stamps(void* device_buffer);
 /* The cross-stream ordering guard described under "Streams" above: on (default) / off, process-wide. */

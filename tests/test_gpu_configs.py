@@ -121,6 +121,30 @@ def oracle_reverse_step(model, inp, sl, seed, t):
     return orc.reverse_update(t, c["seq_idx"], c["translations"], c["orientations"], den, c["generation_mask"], sched, z, rotvec, us)
 
 
+def test_patch_resident_module_is_bitwise_the_per_layer_launches(hip):
+    """DIFFAB_FLAG_PERSISTENT_MODULE (one work-group owns a patch through the six layers of the IPA module, the form diffab_sample_loop
+    chooses by itself when the batch fills the chip) against the 3 NL launches per step it replaces: same tile bodies, so the samples
+    are equal bit for bit - forced on at a small batch (8 work-groups), chosen automatically at B = 256 against DIFFAB_FLAG_MULTI_LAUNCH,
+    with more patches than CUs (a work-group walks two patches), eager and graph-replayed."""
+    dims, model = bench_model(100)
+    for B, fl_a, fl_b, steps in ((8, _hip.FLAG_PERSISTENT_MODULE, 0, 6), (256, 0, _hip.FLAG_MULTI_LAUNCH, 4),
+                                 (300, _hip.FLAG_PERSISTENT_MODULE, _hip.FLAG_MULTI_LAUNCH, 2)):
+        inp = device_patches(B, 128, dims, seed=40 + B)
+        kw = dict(res_context_emb=inp["res_context_emb"], pair_context_emb=inp["pair_context_emb"], generation_mask=inp["generation_mask"],
+                  seed=5, t_stop=100 - steps)
+        a = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=fl_a, **kw)
+        b = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=fl_b, **kw)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (B, k)
+        assert not torch.equal(a["translations"], inp["translations"])
+        if B == 8:
+            g = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=fl_a, graph=True, **kw)
+            for k in a:
+                assert torch.equal(a[k], g[k]), ("graph", k)
+    del inp
+    torch.cuda.empty_cache()
+
+
 def test_config2_b256_k128_100_steps(hip):
     dims, model = bench_model(100)
     inp = device_patches(256, 128, dims, seed=2)

@@ -27,6 +27,8 @@ hd, w = model.denoiser.hip_dims(B, K), model.denoiser.hip_weights()
 sd_dev, tab = model._sched_on_device(), model._reverse_so3().struct()
 ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
 gm, rc, pc = inp["generation_mask"], inp["res_context_emb"], inp["pair_context_emb"]
+if os.environ.get("VARIANT"):
+    lib.diffab_debug_set_attn_variant(int(os.environ["VARIANT"]))  # 2: no operands carried between the items of the persistent kernel
 if os.environ.get("STAGGER"):
     tk, cl = (int(v) for v in os.environ["STAGGER"].split(","))
     lib.diffab_debug_set_module_stagger(tk, cl)

@@ -19,5 +19,5 @@ for d in dirs:
 res = {k: {c: s / n for c, (s, n) in cs.items()} for k, cs in acc.items() if "diffab" in k}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 for k, cs in res.items():
-    if "attn" in k or "proj_frames" in k or "rowgemm" in k or "gemm" in k:
+    if "attn" in k or "proj_frames" in k or "rowgemm" in k or "gemm" in k or "module" in k:
         print(k, {c: round(v, 1) for c, v in cs.items()})
