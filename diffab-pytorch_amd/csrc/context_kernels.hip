@@ -68,6 +68,12 @@ __global__ void softplus_table_kernel(const float* __restrict__ coefw, int n, fl
   if (gid < n) out[gid] = softplus_f(coefw[gid]);
 }
 
+int launch_softplus_table(const float* coefw, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(softplus_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, coefw, n, out);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 // one block per pair row (b, i, j), one thread per atom pair: exp(-softplus(coef[s_i*21+s_j]) d^2) * atom_mask_i * atom_mask_j (:288-295).
 // distmat == nullptr: the distance is taken from the coordinates, d = |xyz[b,i,a1] - xyz[b,j,a2]| (what the reference's data layer
 // computes with protstruc and then leaves out of its batches, data.py:76 / preprocess_pdb.py:61): the 14.7 MB/patch distance
@@ -286,6 +292,88 @@ __global__ void pair_cat_bwd_kernel(const float* __restrict__ dcat, int ldc, con
   }
 }
 
+// The same with the two table gradients summed per work-group in LDS first ((441 + 2 max_dist + 1) x C floats: 130 KiB at C = 64) and
+// flushed once: the 506 table rows take 64 x 2 atomics from EVERY pair row, and as global atomics on so few addresses that was the
+// single most expensive kernel of the encoder backward (1.3 ms per 11-patch chunk, profiles/r05_encode_context_bwd_kernel_stats_before.csv).
+__global__ __launch_bounds__(256) void pair_cat_bwd_lds_kernel(const float* __restrict__ dcat, int ldc, const float* __restrict__ df,
+                                                               const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m,
+                                                               const int64_t* __restrict__ resid, int resid_bstride,
+                                                               const int64_t* __restrict__ chain, int K, int C, int max_dist, int64_t row0,
+                                                               int64_t nrows, float* __restrict__ g_pair, float* __restrict__ g_rel,
+                                                               float* __restrict__ ddf) {
+  extern __shared__ float tab[];  // [441][C] pair | [2 max_dist + 1][C] relpos
+  const int n_pair = kAA * kAA * C, n_rel = (2 * max_dist + 1) * C;
+  for (int i = threadIdx.x; i < n_pair + n_rel; i += blockDim.x) tab[i] = 0.0f;
+  __syncthreads();
+  const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;  // rows in flight per pass (4 at C = 64)
+  const int c0 = threadIdx.x % C, rsub = threadIdx.x / C;
+  for (int64_t lr = static_cast<int64_t>(blockIdx.x) * rpb + rsub; lr < nrows && rsub < rpb; lr += static_cast<int64_t>(gridDim.x) * rpb) {
+    const int64_t row = row0 + lr;
+    const int64_t b = row / (static_cast<int64_t>(K) * K);
+    const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+    const int64_t ri = b * K + i, rj = b * K + j;
+    const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+    int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
+    rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
+    const float same = static_cast<float>(chain[ri] * chain[rj]);
+    const float* g = dcat + lr * ldc;
+    for (int c = c0; c < C; c += blockDim.x) {  // (one trip: blockDim.x >= C)
+      atomicAdd(&tab[(si * kAA + sj) * C + c], g[c]);
+      if (same != 0.0f) atomicAdd(&tab[n_pair + (rel + max_dist) * C + c], g[C + c] * same);
+      ddf[lr * C + c] = df[lr * C + c] > 0.0f ? g[2 * C + c] : 0.0f;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_pair; i += blockDim.x)
+    if (tab[i] != 0.0f) atomicAdd(g_pair + i, tab[i]);
+  for (int i = threadIdx.x; i < n_rel; i += blockDim.x)
+    if (tab[n_pair + i] != 0.0f) atomicAdd(g_rel + i, tab[n_pair + i]);
+}
+
+// The folded backward of mlp[0] (pair_embed_fused.hip): with g = d (mlp[0] pre-activation) [rows][C], the two embedding-table segments
+// of the concatenation need only G1[s_i 21 + s_j] += g and G2[rel] += same g (summed per work-group in LDS, flushed once); everything
+// about aa_pair_emb, relpos_emb and the first 2 C columns of mlp[0].weight follows from G1 / G2 by 441- and 65-row products.
+__global__ __launch_bounds__(1024) void pair_table_scatter_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq,
+                                                                 const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
+                                                                 int resid_bstride, const int64_t* __restrict__ chain, int K, int C, int max_dist,
+                                                                 int64_t row0, int64_t nrows, float* __restrict__ G1, float* __restrict__ G2) {
+  extern __shared__ float tab[];  // [441][C] | [2 max_dist + 1][C]
+  const int n_pair = kAA * kAA * C, n_rel = (2 * max_dist + 1) * C;
+  for (int i = threadIdx.x; i < n_pair + n_rel; i += blockDim.x) tab[i] = 0.0f;
+  __syncthreads();
+  const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;
+  const int c0 = threadIdx.x % C, rsub = threadIdx.x / C;
+  for (int64_t lr = static_cast<int64_t>(blockIdx.x) * rpb + rsub; lr < nrows && rsub < rpb; lr += static_cast<int64_t>(gridDim.x) * rpb) {
+    const int64_t row = row0 + lr;
+    const int64_t b = row / (static_cast<int64_t>(K) * K);
+    const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+    const int64_t ri = b * K + i, rj = b * K + j;
+    const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+    int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
+    rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
+    const float same = static_cast<float>(chain[ri] * chain[rj]);
+    const float v = g[lr * C + c0];
+    atomicAdd(&tab[(si * kAA + sj) * C + c0], v);
+    if (same != 0.0f) atomicAdd(&tab[n_pair + (rel + max_dist) * C + c0], v * same);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_pair; i += blockDim.x)
+    if (tab[i] != 0.0f) atomicAdd(G1 + i, tab[i]);
+  for (int i = threadIdx.x; i < n_rel; i += blockDim.x)
+    if (tab[n_pair + i] != 0.0f) atomicAdd(G2 + i, tab[n_pair + i]);
+}
+// enc[lr][0:18] = AngularEncoding(2) of the row's two pairwise dihedrals (what pair_cat_kernel puts behind the three C-wide segments), [18:20] = 0
+__global__ void pair_enc_kernel(const float* __restrict__ pdih, int64_t row0, int64_t nrows, float* __restrict__ enc) {
+  const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;  // (row, dihedral)
+  if (gid >= nrows * 2) return;
+  const int64_t lr = gid >> 1;
+  const int t = static_cast<int>(gid & 1);
+  float e[9];
+  angular_encode(pdih[(row0 + lr) * 2 + t], 2, e);
+  for (int k = 0; k < 9; ++k) enc[lr * 20 + t * 9 + k] = e[k];
+  if (t == 1) { enc[lr * 20 + 18] = 0.0f; enc[lr * 20 + 19] = 0.0f; }
+}
+
 // d softplus(coef)[si*21+sj][p] += ddin[row][p] * d din / d c,  din = exp(-c d^2) mask  =>  d din / d c = -d^2 din
 __global__ void pair_dist_bwd_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const float* __restrict__ distmat,
                                      const float* __restrict__ xyz, const float* __restrict__ din, const float* __restrict__ ddin, int K,
@@ -317,6 +405,67 @@ __global__ void pair_dist_bwd_kernel(const int64_t* __restrict__ seq, const uint
       atomicAdd(grow + p, ddin[lr * ld + p] * (-(d * d) * v));
     }
   }
+}
+
+// The same per (b, i) group of K pair rows: the group's rows share s_i, so its gradient lands in 21 rows of the table - summed in LDS
+// ([21][A A] floats) and flushed once per group: 21 A A global atomics per K rows instead of K A A (the kernel above took 4.4 ms per
+// backward at B = 128: 118 M atomics on 99 k addresses).  Four rows in flight per pass (blockDim = 4 x 256).
+__global__ __launch_bounds__(1024) void pair_dist_bwd_group_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m,
+                                                                   const float* __restrict__ distmat, const float* __restrict__ xyz,
+                                                                   const float* __restrict__ din, const float* __restrict__ ddin, int K, int A,
+                                                                   int64_t row0, int ld, float* __restrict__ g_coef_sp) {
+  extern __shared__ float tab[];  // [21][A A]
+  const int AA2 = A * A;
+  for (int i = threadIdx.x; i < kAA * AA2; i += blockDim.x) tab[i] = 0.0f;
+  __syncthreads();
+  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * K;  // first row of the group inside this launch
+  const int64_t grow0 = row0 + lrow0;                           // global pair row (b, i, 0)
+  const int64_t bi = grow0 / K;                                 // b K + i
+  const int64_t b = bi / K;
+  const int64_t ri = bi;
+  const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri];
+  const int sub = threadIdx.x >> 8, p0 = threadIdx.x & 255;
+  for (int p = p0; p < AA2; p += 256) {  // (one trip for A <= 16)
+    const int a1 = p / A, a2 = p % A;
+    float xa0 = 0.f, xa1 = 0.f, xa2 = 0.f;
+    if (!distmat) {
+      const float* pa = xyz + (ri * A + a1) * 3;
+      xa0 = pa[0]; xa1 = pa[1]; xa2 = pa[2];
+    }
+    // four rows per thread in flight (sixteen per work-group): a row costs five dependent-free loads, and one row at a time left the
+    // group waiting for an L2 round trip per pass
+    for (int j0 = sub; j0 < K; j0 += 16) {
+      float v[4], gd[4], dd[4];
+      int sj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + 4 * u;
+        v[u] = 0.0f; gd[u] = 0.0f; dd[u] = 0.0f; sj[u] = 0;
+        if (j < K) {
+          const int64_t rj = b * K + j, lr = lrow0 + j;
+          sj[u] = static_cast<int>((seq_m && !seq_m[rj]) ? kUNK : seq[rj]);
+          v[u] = din[lr * ld + p];
+          gd[u] = ddin[lr * ld + p];
+          if (distmat) {
+            const float d = distmat[(grow0 + j) * AA2 + p];
+            dd[u] = d * d;
+          } else {
+            const float* pb = xyz + (rj * A + a2) * 3;
+            const float dx = xa0 - pb[0], dy = xa1 - pb[1], dz = xa2 - pb[2];
+            const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+            dd[u] = d * d;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (v[u] != 0.0f) atomicAdd(&tab[sj[u] * AA2 + p], gd[u] * (-dd[u] * v[u]));  // v == 0: masked atom pair (or underflow), no gradient
+    }
+  }
+  __syncthreads();
+  float* grow = g_coef_sp + si * kAA * AA2;
+  for (int i = threadIdx.x; i < kAA * AA2; i += blockDim.x)
+    if (tab[i] != 0.0f) atomicAdd(grow + i, tab[i]);
 }
 
 // g_coef[n] += g_coef_sp[n] * softplus'(coef[n])   (sigmoid; 1 beyond F.softplus's threshold of 20)
@@ -397,6 +546,7 @@ static int pair_chunk_patches(const diffab_ctx_dims* d) {
 
 size_t diffab_pair_embedding_workspace_bytes(const diffab_ctx_dims* d) {
   if (check_ctx(d, "pair_embedding_workspace_bytes")) return 0;
+  if (pair_embed_fused_supported(d)) return (pair_embed_fused_prep_floats(d) + 64) * sizeof(float);
   const size_t rows = static_cast<size_t>(pair_chunk_patches(d)) * d->K * d->K;
   const size_t wpad = static_cast<size_t>(d->C) * (round4(d->A * d->A) + round4(3 * d->C + 18)) + static_cast<size_t>(kAA) * kAA * d->A * d->A;
   return (rows * (round4(d->A * d->A) + 4 * d->C + round4(3 * d->C + 18)) + wpad + 64) * sizeof(float);
@@ -414,6 +564,10 @@ static int pair_embedding_impl(const diffab_ctx_dims* d, const diffab_pair_emb_w
                  DIFFAB_ERR_ARG, "pair_embedding_fwd: null pointer");
   DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_fwd: workspace");
   hipStream_t st = as_stream(stream);
+  if (pair_embed_fused_supported(d))  // C = 64, K % 128 == 0: the whole forward as one kernel (pair_embed_fused.hip)
+    return launch_pair_embed_fused(d, w, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
+                                   sequence_context_mask, out, static_cast<float*>(workspace), nullptr, nullptr, nullptr, nullptr, 0,
+                                   static_cast<int64_t>(d->B) * d->K * d->K, st);
   const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18, AA2p = round4(AA2), Wp = round4(W);
   const int bc = pair_chunk_patches(d);
   const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
@@ -531,8 +685,115 @@ static int pair_bwd_chunk_patches(const diffab_ctx_dims* d) {
   return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
 }
 
+// ---- the backward where the fused forward applies: per chunk ONE recompute launch that leaves the four hidden activations on a tape,
+// then the chain of 64-wide linear backward steps on the taped rows; the 210-wide concatenation and its gradient are never built
+// (pair_table_scatter_kernel + four small products), only the 225-wide distance features are, for distance_embedding[0]'s gradients.
+static int fused_bwd_chunk_patches(const diffab_ctx_dims* d) {
+  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (8 * d->C + 2 * round4(d->A * d->A) + 20) * sizeof(float);
+  const size_t n = (static_cast<size_t>(2) << 30) / per_patch;  // ~2 GiB of row buffers at a time (30 K = 128 patches)
+  return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
+}
+static size_t fused_bwd_workspace_floats(const diffab_ctx_dims* d) {
+  const size_t R = static_cast<size_t>(fused_bwd_chunk_patches(d)) * d->K * d->K;
+  const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
+  return R * (8 * d->C + 2 * AA2p + 20) + 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + static_cast<size_t>(kAA) * kAA * d->A * d->A +
+         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + 1024;
+}
+
+static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
+                                    const int64_t* seq_idx, const float* distmat, const float* xyz, const float* pairwise_dihedrals,
+                                    const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                                    const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, float* ws, hipStream_t st) {
+  const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18, AA2p = round4(AA2), Wp = round4(W);
+  const int bc = fused_bwd_chunk_patches(d);
+  const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
+  const size_t R = static_cast<size_t>(bc) * per_patch;
+  Carver cv(ws);
+  float* h1 = cv.take<float>(R * C);
+  float* df = cv.take<float>(R * C);
+  float* m1 = cv.take<float>(R * C);
+  float* m2 = cv.take<float>(R * C);
+  float* dA = cv.take<float>(R * C);
+  float* dB = cv.take<float>(R * C);
+  float* ddf = cv.take<float>(R * C);
+  float* dh1 = cv.take<float>(R * C);
+  float* din = cv.take<float>(R * AA2p);
+  float* ddin = cv.take<float>(R * AA2p);
+  float* enc = cv.take<float>(R * 20);
+  float* dw0p = cv.take<float>(static_cast<size_t>(C) * AA2p);   // padded first-layer weights and their gradients
+  float* mw0p = cv.take<float>(static_cast<size_t>(C) * Wp);
+  float* gdw0p = cv.take<float>(static_cast<size_t>(C) * (AA2p + Wp));  // gdw0p | gmw0p adjacent
+  float* gmw0p = gdw0p + static_cast<size_t>(C) * AA2p;
+  float* g_sp = cv.take<float>(static_cast<size_t>(kAA) * kAA * AA2);
+  float* G1 = cv.take<float>(static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C);  // G1 | G2 adjacent
+  float* G2 = G1 + static_cast<size_t>(kAA) * kAA * C;
+  float* prep = cv.take<float>(pair_embed_fused_prep_floats(d));
+  auto mut = [](const float* p) { return const_cast<float*>(p); };
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((C * AA2p + 255) / 256), dim3(256), 0, st, w->dw0, AA2, C, dw0p, AA2p);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((C * Wp + 255) / 256), dim3(256), 0, st, w->mw0, W, C, mw0p, Wp);
+  DIFFAB_LAUNCH_CHECK();
+  DIFFAB_HIP_CHECK(hipMemsetAsync(gdw0p, 0, sizeof(float) * static_cast<size_t>(C) * (AA2p + Wp), st));
+  DIFFAB_HIP_CHECK(hipMemsetAsync(g_sp, 0, sizeof(float) * static_cast<size_t>(kAA) * kAA * AA2, st));
+  DIFFAB_HIP_CHECK(hipMemsetAsync(G1, 0, sizeof(float) * static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C, st));
+  const size_t tab_bytes = static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C * sizeof(float);
+  DIFFAB_REQUIRE(tab_bytes <= 150 * 1024, DIFFAB_ERR_UNSUPPORTED, "pair_embedding_bwd: embedding tables too large for the LDS scatter");
+  const float* coef_sp = nullptr;
+  for (int b0 = 0; b0 < d->B; b0 += bc) {
+    const int nb = (d->B - b0) < bc ? (d->B - b0) : bc;
+    const int64_t row0 = b0 * per_patch, nrows = nb * per_patch;
+    const int rows = static_cast<int>(nrows);
+    // ---- forward recompute: one launch, the hidden activations (after their ReLUs) on the tape
+    if (int rc = launch_pair_embed_fused(d, w, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx,
+                                         atom_mask, sequence_context_mask, nullptr, prep, h1, df, m1, m2, row0, nrows, st, &coef_sp))
+      return rc;
+    // ---- mlp[4], mlp[2]
+    hipLaunchKernelGGL(pair_mask_bwd_kernel, dim3(static_cast<unsigned>((nrows * C + 255) / 256)), dim3(256), 0, st, d_out, atom_mask, d->K,
+                       d->A, C, row0, nrows, dA);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = bwd_linear_masked(dA, C, m2, C, w->mw4, mut(g->mw4), mut(g->mb4), dB, C, rows, C, C, m2, st)) return rc;
+    if (int rc = bwd_linear_masked(dB, C, m1, C, w->mw2, mut(g->mw2), mut(g->mb2), dA, C, rows, C, C, m1, st)) return rc;
+    // ---- mlp[0] without its concatenation: dA = d (pre-activation).  Columns [2C, 3C) and [3C, 3C + 18) of the weight gradient are
+    // plain products with df and the dihedral encoding; the table segments go through G1 / G2 after the loop
+    hipLaunchKernelGGL(pair_enc_kernel, dim3(static_cast<unsigned>((nrows * 2 + 255) / 256)), dim3(256), 0, st, pairwise_dihedrals, row0, nrows,
+                       enc);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = bwd_gemm_tn(dA, C, df, C, gmw0p + 2 * C, Wp, rows, C, C, mut(g->mb0), st)) return rc;
+    if (int rc = bwd_gemm_tn(dA, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) return rc;
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_table_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(tab_bytes)));
+    // (64 work-groups of 1024 threads: every group flushes its private tables onto the SAME 32 k addresses at the end - with 256 groups
+    // that flush, not the scatter, was the kernel's time)
+    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(64), dim3(1024), tab_bytes, st, dA, seq_idx, sequence_context_mask, residue_idx,
+                       residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, G1, G2);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = bwd_gemm_nn_masked(dA, C, mw0p + 2 * C, Wp, ddf, C, rows, C, C, df, st)) return rc;  // distance_embedding ends with a ReLU (:212-217)
+    // ---- distance_embedding[2], [0]
+    if (int rc = bwd_linear_masked(ddf, C, h1, C, w->dw2, mut(g->dw2), mut(g->db2), dh1, C, rows, C, C, h1, st)) return rc;
+    hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq_idx, sequence_context_mask, distmat, xyz,
+                       atom_mask, coef_sp, d->K, d->A, row0, nrows, din, AA2p);
+    DIFFAB_LAUNCH_CHECK();
+    if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
+    hipLaunchKernelGGL(pair_dist_bwd_group_kernel, dim3(static_cast<unsigned>(nrows / d->K)), dim3(1024), sizeof(float) * kAA * AA2, st, seq_idx,
+                       sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, AA2p, g_sp);
+    DIFFAB_LAUNCH_CHECK();
+  }
+  // ---- the table segments: d aa_pair_emb += G1 W_a, d W_a += G1^T aa_pair_emb (W_a = mlp[0].weight[:, 0:C]); the same for relpos_emb / G2
+  const int n1 = kAA * kAA, n2 = 2 * d->max_dist + 1;
+  if (int rc = bwd_gemm_nn(G1, C, mw0p, Wp, mut(g->aa_pair_emb), C, n1, C, C, true, st)) return rc;
+  if (int rc = bwd_gemm_tn(G1, C, w->aa_pair_emb, C, gmw0p, Wp, n1, C, C, nullptr, st)) return rc;
+  if (int rc = bwd_gemm_nn(G2, C, mw0p + C, Wp, mut(g->relpos_emb), C, n2, C, C, true, st)) return rc;
+  if (int rc = bwd_gemm_tn(G2, C, w->relpos_emb, C, gmw0p + C, Wp, n2, C, C, nullptr, st)) return rc;
+  hipLaunchKernelGGL(unpad_add_kernel, dim3((C * AA2 + 255) / 256), dim3(256), 0, st, gdw0p, AA2p, AA2, C, mut(g->dw0));
+  hipLaunchKernelGGL(unpad_add_kernel, dim3((C * W + 255) / 256), dim3(256), 0, st, gmw0p, Wp, W, C, mut(g->mw0));
+  hipLaunchKernelGGL(softplus_bwd_kernel, dim3((kAA * kAA * AA2 + 255) / 256), dim3(256), 0, st, w->pair2distcoef, g_sp, kAA * kAA * AA2,
+                     mut(g->pair2distcoef));
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 size_t diffab_pair_embedding_bwd_workspace_bytes(const diffab_ctx_dims* d) {
   if (check_ctx(d, "pair_embedding_bwd_workspace_bytes")) return 0;
+  if (pair_embed_fused_supported(d)) return fused_bwd_workspace_floats(d) * sizeof(float) + 32 * 256;
   const size_t rows = static_cast<size_t>(pair_bwd_chunk_patches(d)) * d->K * d->K;
   const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
   const size_t wpad = 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + 2 * static_cast<size_t>(kAA) * kAA * d->A * d->A;
@@ -556,6 +817,9 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
                  DIFFAB_ERR_ARG, "pair_embedding_bwd: null pointer");
   DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_bwd_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_bwd: workspace");
   hipStream_t st = as_stream(stream);
+  if (pair_embed_fused_supported(d))
+    return pair_embedding_bwd_fused(d, w, g, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx,
+                                    atom_mask, sequence_context_mask, d_out, static_cast<float*>(workspace), st);
   const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18, AA2p = round4(AA2), Wp = round4(W);
   const int bc = pair_bwd_chunk_patches(d);
   const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
@@ -610,15 +874,23 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
     if (int rc = bwd_linear(dB, C, m1, C, w->mw2, mut(g->mw2), mut(g->mb2), dA, C, rows, C, C, false, st)) return rc;
     if (int rc = bwd_relu_mask(dA, m1, nrows * C, st)) return rc;
     if (int rc = bwd_linear(dA, C, cat, Wp, mw0p, gmw0p, mut(g->mb0), dcat, Wp, rows, C, Wp, false, st)) return rc;
-    hipLaunchKernelGGL(pair_cat_bwd_kernel, dim3(static_cast<unsigned>(nrows)), dim3(64), 0, st, dcat, Wp, df, seq_idx, sequence_context_mask,
-                       residue_idx, residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, mut(g->aa_pair_emb),
-                       mut(g->relpos_emb), ddf);
+    const size_t tab_bytes = static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C * sizeof(float);
+    if (tab_bytes <= 150 * 1024 && C <= 256) {
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_cat_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(tab_bytes)));
+      hipLaunchKernelGGL(pair_cat_bwd_lds_kernel, dim3(256), dim3(256), tab_bytes, st, dcat, Wp, df, seq_idx, sequence_context_mask, residue_idx,
+                         residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, mut(g->aa_pair_emb), mut(g->relpos_emb), ddf);
+    } else {
+      hipLaunchKernelGGL(pair_cat_bwd_kernel, dim3(static_cast<unsigned>(nrows)), dim3(64), 0, st, dcat, Wp, df, seq_idx,
+                         sequence_context_mask, residue_idx, residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0,
+                         mut(g->aa_pair_emb), mut(g->relpos_emb), ddf);
+    }
     DIFFAB_LAUNCH_CHECK();
     if (int rc = bwd_linear(ddf, C, h1, C, w->dw2, mut(g->dw2), mut(g->db2), dh1, C, rows, C, C, false, st)) return rc;
     if (int rc = bwd_relu_mask(dh1, h1, nrows * C, st)) return rc;
     if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
-    hipLaunchKernelGGL(pair_dist_bwd_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq_idx, sequence_context_mask,
-                       distmat, xyz, din, ddin, d->K, d->A, row0, nrows, AA2p, g_sp);
+    hipLaunchKernelGGL(pair_dist_bwd_group_kernel, dim3(static_cast<unsigned>(nrows / d->K)), dim3(1024), sizeof(float) * kAA * AA2, st, seq_idx,
+                       sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, AA2p, g_sp);
     DIFFAB_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(unpad_add_kernel, dim3((C * AA2 + 255) / 256), dim3(256), 0, st, gdw0p, AA2p, AA2, C, mut(g->dw0));

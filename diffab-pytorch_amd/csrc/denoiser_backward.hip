@@ -101,7 +101,9 @@ __device__ __forceinline__ int seg_of(const GemmSegs& sg, int col, int* begin) {
 typedef float nn_f32x4 __attribute__((ext_vector_type(4)));
 template <bool ACC>
 __global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
-                                                           float* __restrict__ C, int ldc, int M, int N, int K, GemmSegs segs) {
+                                                           float* __restrict__ C, int ldc, int M, int N, int K, GemmSegs segs,
+                                                           const float* __restrict__ relu_act = nullptr, int ld_act = 0) {
+  // relu_act (nullable): C = (A B) masked by relu_act > 0 - the ReLU backward of the layer below, fused into this product's epilogue
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * 64 + 16 * wv, n0 = blockIdx.x * 64;
   const int arow = min(m0 + l15, M - 1);  // rows past M are clamped (never stored)
@@ -143,22 +145,34 @@ __global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restri
     if (gm >= M) continue;
     nn_f32x4* cp = reinterpret_cast<nn_f32x4*>(C + static_cast<int64_t>(gm) * ldc + n0 + 4 * l15);
     nn_f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    if (relu_act != nullptr) {
+      const nn_f32x4 av = *reinterpret_cast<const nn_f32x4*>(relu_act + static_cast<int64_t>(gm) * ld_act + n0 + 4 * l15);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = av[c] > 0.0f ? v[c] : 0.0f;
+    }
     if (ACC) v += *cp;
     *cp = v;
   }
 }
 
+static int relu_mask(float* dY, const float* act, int64_t n, hipStream_t st);
 static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st,
-                   const GemmSegs* segs = nullptr) {
+                   const GemmSegs* segs = nullptr, const float* relu_act = nullptr, int ld_act = 0) {
   GemmSegs sg{};
   if (segs) sg = *segs;
   const bool mfma = lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && N % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+                    (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                    (relu_act == nullptr || (ld_act % 4 == 0 && (reinterpret_cast<uintptr_t>(relu_act) & 15) == 0));
+  if (relu_act != nullptr && (!mfma || acc)) {  // the fused mask exists on the aligned, non-accumulating path: otherwise two launches
+    DIFFAB_REQUIRE(!acc && ld_act == N && ldc == N, DIFFAB_ERR_ARG, "gemm_nn: masked product needs dense operands off the aligned path");
+    if (int rc = gemm_nn(A, lda, B, ldb, C, ldc, M, N, K, false, st, segs)) return rc;
+    return relu_mask(C, relu_act, static_cast<int64_t>(M) * N, st);
+  }
   dim3 grid((N + TB - 1) / TB, (M + TB - 1) / TB);
   DIFFAB_REQUIRE(sg.nseg == 0 || mfma, DIFFAB_ERR_ARG, "gemm_nn: segmented operand needs the aligned path");
   if (mfma) {
-    if (acc) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, sg);
-    else hipLaunchKernelGGL(gemm_nn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, sg);
+    if (acc) hipLaunchKernelGGL(gemm_nn_mfma_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, sg, nullptr, 0);
+    else hipLaunchKernelGGL(gemm_nn_mfma_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, sg, relu_act, ld_act);
   } else {
     if (acc) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
     else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K);
@@ -304,6 +318,25 @@ int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W
   return linear_bwd(dY, ldy, X, ldx, W, dW, db, dX, lddx, M, N, Kd, acc_dx, st);
 }
 int bwd_relu_mask(float* dY, const float* act, int64_t n, hipStream_t st) { return relu_mask(dY, act, n, st); }
+// dX = (dY W) masked by relu_act > 0 (the ReLU below the layer), dW += dY^T X, db += colsum dY: bwd_linear + bwd_relu_mask in one product
+int bwd_linear_masked(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M,
+                      int N, int Kd, const float* relu_act, hipStream_t st) {
+  bool db_done = false;
+  if (int rc = gemm_tn(dY, ldy, X, ldx, dW, Kd, M, N, Kd, st, nullptr, db, &db_done)) return rc;
+  if (db && !db_done)
+    if (int rc = colsum(dY, ldy, M, N, db, st)) return rc;
+  return gemm_nn(dY, ldy, W, Kd, dX, lddx, M, Kd, N, false, st, nullptr, relu_act, lddx);
+}
+int bwd_gemm_nn_masked(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* relu_act,
+                       hipStream_t st) {
+  return gemm_nn(A, lda, B, ldb, C, ldc, M, N, K, false, st, nullptr, relu_act, ldc);
+}
+int bwd_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db, hipStream_t st) {
+  bool db_done = false;
+  if (int rc = gemm_tn(A, lda, B, ldb, C, ldc, M, N1, N2, st, nullptr, db, &db_done)) return rc;
+  if (db && !db_done) return colsum(A, lda, M, N1, db, st);
+  return DIFFAB_OK;
+}
 int bwd_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st) {
   return gemm_nn(A, lda, B, ldb, C, ldc, M, N, K, acc, st);
 }

@@ -376,7 +376,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ipa_attn_fast_kernel
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
 static int g_attn_variant = 0;                       // diagnostics only (diffab_debug_set_attn_variant): 1 = four-wave work-groups
-void set_attn_variant(int v) { g_attn_variant = v; }
+void set_pair_embed_fused(bool on);  // pair_embed_fused.hip
+void set_attn_variant(int v) {       // A/B switches for tests and tools: bit 0 four-wave attention work-groups, bit 2 unfused pair embedding
+  g_attn_variant = v & 1;
+  set_pair_embed_fused(!(v & 4));
+}
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);
 }

@@ -89,6 +89,18 @@ int launch_fold_tables(const diffab_dims* d, const diffab_denoiser_weights* w, c
                        hipStream_t st, bool emb_tab_ready = false,
                        const float* sched_beta = nullptr, int t = 0, const int* t_dev = nullptr);  // beta = sched_beta[t] for every patch  // beta == nullptr: the weights-only embedding table alone
 
+// pair_embed_fused.hip: PairEmbedding forward as one kernel (C = 64, K % 128 == 0, A <= 16); context_kernels.hip falls back to its
+// unfused launches elsewhere.  prep: pair_embed_fused_prep_floats(d) floats (prepared planes and tables, rebuilt per call); tapes
+// (all or none): the four hidden activations [nrows][64] of rows [row0, row0 + nrows) for the backward; out == nullptr: tapes only
+bool pair_embed_fused_supported(const diffab_ctx_dims* d);
+size_t pair_embed_fused_prep_floats(const diffab_ctx_dims* d);
+int launch_pair_embed_fused(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
+                            const float* xyz, const float* pairwise_dihedrals, const int64_t* residue_idx, int32_t residue_idx_batch_stride,
+                            const int64_t* chain_idx, const float* atom_mask, const uint8_t* sequence_context_mask, float* out, float* prep,
+                            float* tape_h1, float* tape_df, float* tape_m1, float* tape_m2, int64_t row0, int64_t nrows, hipStream_t st,
+                            const float** coef_sp_out = nullptr);
+int launch_softplus_table(const float* coefw, int n, float* out, hipStream_t st);  // softplus(pair2distcoef) (context_kernels.hip)
+
 // attention_split.hip: the attention of one IPA layer as three launches (logits | pair stream | P x V) exchanging the
 // (B, 8, K, K) logits / probabilities through SP - the form the training tape keeps; single key chunk only (K = 64, 128)
 bool attention_split_supported(const diffab_dims* d);
@@ -142,6 +154,13 @@ int ipa_layer_bwd(const diffab_dims* d1, const diffab_ipa_layer_weights* lw, con
 int bwd_linear(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M, int N,
                int Kd, bool acc_dx, hipStream_t st);
 int bwd_relu_mask(float* dY, const float* act, int64_t n, hipStream_t st);
+// bwd_linear whose input gradient is masked by relu_act > 0 (rows lddx apart) in the product's epilogue; C = (A B) masked likewise
+int bwd_linear_masked(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M,
+                      int N, int Kd, const float* relu_act, hipStream_t st);
+int bwd_gemm_nn_masked(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* relu_act,
+                       hipStream_t st);
+// C[N1 x N2] (rows ldc apart) += A[M x N1]^T B[M x N2]; db (nullable) += column sums of A
+int bwd_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db, hipStream_t st);
 int bwd_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st);
 int launch_losses_fwd(const float* pp, const float* tp, const float* pe, const float* te, const float* pO, const float* tO, const uint8_t* gm,
                       const uint8_t* rm, int B, int K, int V, float* out3, hipStream_t st,

@@ -989,6 +989,64 @@ def test_encode_context_gradients_vs_goldens(hip, golden):
     assert float(params["residue_context_embedding.chain_embedding.weight"].grad[0].abs().max()) == 0.0
 
 
+def test_fused_pair_embedding_k128_vs_unfused_and_oracle(hip):
+    """The one-kernel PairEmbedding forward and its folded backward (csrc/pair_embed_fused.hip: C = 64, K % 128 == 0) at the benchmark
+    model, K = 128: forward against the oracle, forward and every pair_context_embedding.* gradient against the unfused HIP launches
+    (which the K = 12 goldens pin to the reference), and the gradients against autograd of the oracle on one patch; distances from
+    xyz and from the materialised tensor."""
+    from diffab_pytorch import DiffAb
+
+    d = syn.BENCH_DIMS
+    B, K, A_ = 2, 128, 15
+    model = DiffAb(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    sd = syn.context_state_dict(d["D"], d["C"], A_, 32, seed=11)
+    sd["pair_context_embedding.pair2distcoef.weight"] = 0.3 * torch.randn(441, A_ * A_, generator=torch.Generator().manual_seed(5))
+    model.load_state_dict(sd, strict=False)
+    cbc = syn.context_batch(B, K, A_, seed=12)
+    cb = {k: v.cuda() for k, v in cbc.items()}
+    g = torch.Generator(device="cuda").manual_seed(2)
+    Gp = torch.randn(B, K, K, d["C"], device="cuda", generator=g)
+    names = [n for n, _ in model.named_parameters() if n.startswith("pair_context_embedding.")]
+    assert len(names) == 13
+
+    def run(distmat, variant):
+        hip.diffab_debug_set_attn_variant(variant)
+        try:
+            model.zero_grad()
+            _, pair = model.encode_context(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], distmat,
+                                           cb["pairwise_dihedrals"], cb["atom_mask"], cb["chain_idx"], cb["residue_idx"],
+                                           cb["generation_mask"], cb["residue_mask"])
+            (pair * Gp).sum().backward()
+            return pair.detach().clone(), {n: dict(model.named_parameters())[n].grad.detach().clone() for n in names}
+        finally:
+            hip.diffab_debug_set_attn_variant(0)
+
+    for distmat in (None, cb["distmat"]):
+        pf, gf = run(distmat, 0)
+        pu, gu = run(distmat, 4)
+        assert maxrel(pf, pu) < 2e-6, maxrel(pf, pu)
+        worst = max(((n, maxrel(gf[n], gu[n])) for n in names), key=lambda t_: t_[1])
+        print("fused vs unfused PairEmbedding (%s): forward %.1e, worst gradient %s %.1e" % ("xyz" if distmat is None else "distmat",
+                                                                                            maxrel(pf, pu), worst[0], worst[1]))
+        assert worst[1] < 1e-4, worst
+    # the oracle (and its autograd) on patch 0, distances from the materialised tensor
+    csd = {k: v.clone().requires_grad_(k.startswith("pair_context_embedding.")) for k, v in sd.items()}
+    b1 = {k: (v[:1] if v.shape[0] == B else v) for k, v in cbc.items()}
+    _, pair_o = orc.encode_context(csd, b1, True, True)
+    assert maxrel(pf[:1], pair_o.detach()) < 1e-5, maxrel(pf[:1], pair_o.detach())
+    (pair_o * Gp[:1].cpu()).sum().backward()
+    hip.diffab_debug_set_attn_variant(0)
+    model.zero_grad()
+    cb1 = {k: (v[:1].contiguous() if v.shape[0] == B else v) for k, v in cb.items()}
+    _, pair1 = model.encode_context(cb1["seq_idx"], cb1["xyz"], cb1["orientations"], cb1["backbone_dihedrals"], cb1["distmat"],
+                                    cb1["pairwise_dihedrals"], cb1["atom_mask"], cb1["chain_idx"], cb1["residue_idx"], cb1["generation_mask"],
+                                    cb1["residue_mask"])
+    (pair1 * Gp[:1]).sum().backward()
+    for n in names:
+        r = maxrel(dict(model.named_parameters())[n].grad, csd[n].grad)
+        assert r < 2e-4, (n, r)
+
+
 def test_full_training_step_updates_every_parameter(hip):
     """DiffAb.training_step on the reference's batch dict (no precomputed contexts): encode_context is part of the graph, so one
     Adam step moves all parameters - the 559 641 of the two context encoders included."""

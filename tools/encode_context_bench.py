@@ -1,5 +1,6 @@
 """Timing of DiffAb.encode_context at the benchmark model: B patches of K residues, A=15 atoms;
-with the materialised distance tensor (reference signature) and with distances taken from xyz inside the pair kernel."""
+with the materialised distance tensor (reference signature) and with distances taken from xyz inside the pair kernel.
+usage: encode_context_bench.py [B] [K] [--backward]   (--backward: forward + backward of both encoders from random cotangents, xyz form)"""
 import os
 import sys
 import time
@@ -10,8 +11,10 @@ import torch  # noqa: E402
 
 from diffab_pytorch import DiffAb, synthetic as syn  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+BACKWARD = "--backward" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(argv[0]) if len(argv) > 0 else 32
+K = int(argv[1]) if len(argv) > 1 else 128
 d = syn.BENCH_DIMS
 model = DiffAb(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
 model.load_state_dict(syn.context_state_dict(d["D"], d["C"], 15, 32, seed=1), strict=False)
@@ -29,3 +32,25 @@ for name, dm in (("distmat", cb["distmat"]), ("xyz", None)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"encode_context[{name}] B={B} K={K}: {dt*1e3:.2f} ms = {dt*1e3/B:.4f} ms/patch; distmat stream {B*K*K*225*4/dt/1e9:.0f} GB/s-equivalent")
+
+if BACKWARD:
+    g = torch.Generator(device="cuda").manual_seed(3)
+    c_res = torch.randn(B, K, d["D"], device="cuda", generator=g)
+    c_pair = torch.randn(B, K, K, d["C"], device="cuda", generator=g)
+
+    def fb():
+        for p_ in model.parameters():
+            p_.grad = None
+        r_, p_ = model.encode_context(*args(None))
+        torch.autograd.backward([r_, p_], [c_res, c_pair])
+
+    for _ in range(2):
+        fb()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        fb()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"encode_context[xyz] forward + backward B={B} K={K}: {dt*1e3:.2f} ms = {dt*1e3/B:.4f} ms/patch")
