@@ -421,6 +421,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed block of --steps steps is run this many times back to back (each bracketed by barrier + synchronize, "
                          "max over ranks); ms_per_step / value are the MEDIAN block, every block is listed in ms_per_step_runs")
+    ap.add_argument("--multi-launch", action="store_true",
+                    help="DIFFAB_FLAG_MULTI_LAUNCH: one launch per kernel of an IPA layer instead of the patch-resident module launch the "
+                         "sampler chooses at this batch size (bitwise the same samples; for profiles of the separate kernels)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (tests/test_gpu_two_ranks.py); "
                          "exercises the launch contract, sharding, gather and max-over-ranks timing - NOT a scaling measurement")
@@ -483,7 +486,7 @@ def main():
     sd_dev = model._sched_on_device()
     tab = model._reverse_so3().struct()
     ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
-    flags = _hip.FLAG_FORCE_GENERIC if args.generic else 0
+    flags = _hip.FLAG_FORCE_GENERIC if args.generic else (_hip.FLAG_MULTI_LAUNCH if args.multi_launch else 0)
     seed = 2024
     _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, model.T,
                                       _hip.stream_ptr()), "sample_init")

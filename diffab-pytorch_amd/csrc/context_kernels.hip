@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void pair_cat_bwd_lds_kernel(const float* __re
 // The folded backward of mlp[0] (pair_embed_fused.hip): with g = d (mlp[0] pre-activation) [rows][C], the two embedding-table segments
 // of the concatenation need only G1[s_i 21 + s_j] += g and G2[rel] += same g (summed per work-group in LDS, flushed once); everything
 // about aa_pair_emb, relpos_emb and the first 2 C columns of mlp[0].weight follows from G1 / G2 by 441- and 65-row products.
-__global__ __launch_bounds__(1024) void pair_table_scatter_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq,
+__global__ __launch_bounds__(256) void pair_table_scatter_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq,
                                                                  const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
                                                                  int resid_bstride, const int64_t* __restrict__ chain, int K, int C, int max_dist,
                                                                  int64_t row0, int64_t nrows, float* __restrict__ G1, float* __restrict__ G2) {
@@ -343,16 +343,20 @@ __global__ __launch_bounds__(1024) void pair_table_scatter_kernel(const float* _
   __syncthreads();
   const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;
   const int c0 = threadIdx.x % C, rsub = threadIdx.x / C;
-  for (int64_t lr = static_cast<int64_t>(blockIdx.x) * rpb + rsub; lr < nrows && rsub < rpb; lr += static_cast<int64_t>(gridDim.x) * rpb) {
-    const int64_t row = row0 + lr;
-    const int64_t b = row / (static_cast<int64_t>(K) * K);
-    const int i = static_cast<int>((row / K) % K), j = static_cast<int>(row % K);
+  // (row0 is a multiple of K K and nrows < 2^31: the (b, i, j) of a row from 32-bit divisions - as 64-bit divisions by run-time values
+  // the index arithmetic was most of this kernel)
+  const int64_t b00 = row0 / (static_cast<int64_t>(K) * K);
+  const unsigned KK = static_cast<unsigned>(K) * static_cast<unsigned>(K), nr = static_cast<unsigned>(nrows);
+  for (unsigned lr = blockIdx.x * rpb + rsub; lr < nr && rsub < rpb; lr += gridDim.x * rpb) {
+    const unsigned bl = lr / KK, rem = lr - bl * KK;
+    const int i = static_cast<int>(rem / static_cast<unsigned>(K)), j = static_cast<int>(rem - static_cast<unsigned>(i) * K);
+    const int64_t b = b00 + bl;
     const int64_t ri = b * K + i, rj = b * K + j;
     const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
     int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
     rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
     const float same = static_cast<float>(chain[ri] * chain[rj]);
-    const float v = g[lr * C + c0];
+    const float v = g[static_cast<size_t>(lr) * C + c0];
     atomicAdd(&tab[(si * kAA + sj) * C + c0], v);
     if (same != 0.0f) atomicAdd(&tab[n_pair + (rel + max_dist) * C + c0], v * same);
   }
@@ -761,9 +765,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
     if (int rc = bwd_gemm_tn(dA, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) return rc;
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_table_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          static_cast<int>(tab_bytes)));
-    // (64 work-groups of 1024 threads: every group flushes its private tables onto the SAME 32 k addresses at the end - with 256 groups
-    // that flush, not the scatter, was the kernel's time)
-    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(64), dim3(1024), tab_bytes, st, dA, seq_idx, sequence_context_mask, residue_idx,
+    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(256), tab_bytes, st, dA, seq_idx, sequence_context_mask, residue_idx,
                        residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, G1, G2);
     DIFFAB_LAUNCH_CHECK();
     if (int rc = bwd_gemm_nn_masked(dA, C, mw0p + 2 * C, Wp, ddf, C, rows, C, C, df, st)) return rc;  // distance_embedding ends with a ReLU (:212-217)
