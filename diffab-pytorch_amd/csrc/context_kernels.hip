@@ -112,6 +112,66 @@ __global__ void pair_dist_kernel(const int64_t* __restrict__ seq, const uint8_t*
   }
 }
 
+// The same rows per (b, i) group of K pair rows (the fused backward's one remaining use of the materialised features): the group's
+// coordinates, masks and residue types are staged in LDS once, the (row, p) elements are walked in memory order (coalesced 4-byte
+// stores), no 64-bit division, no dependent index load per row - 482 us per 393 k rows for the kernel above was 0.7 TB/s.
+__global__ __launch_bounds__(256) void pair_dist_group_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m,
+                                                              const float* __restrict__ distmat, const float* __restrict__ xyz,
+                                                              const float* __restrict__ amask, const float* __restrict__ coef_sp, int K, int A,
+                                                              int64_t row0, float* __restrict__ out, int ldo) {
+  extern __shared__ float gl[];  // xj [K][A 3] | mj [K][A] | xi [A 3] | mi [A] | sj [K] (int)
+  const int AA2 = A * A;
+  float* xj = gl;
+  float* mj = xj + K * A * 3;
+  float* xi = mj + K * A;
+  float* mi = xi + A * 3;
+  int* sjs = reinterpret_cast<int*>(mi + A);
+  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * K;  // first row of the group inside this launch
+  const int64_t grow0 = row0 + lrow0;
+  const int64_t bi = grow0 / K, b = bi / K;
+  const int64_t ri = bi;
+  const int si = static_cast<int>((seq_m && !seq_m[ri]) ? kUNK : seq[ri]);
+  for (int idx = threadIdx.x; idx < K * A; idx += blockDim.x) {
+    const int64_t rj = b * K + idx / A;
+    mj[idx] = amask[rj * A + idx % A];
+    if (xyz) {
+      const float* p = xyz + (rj * A + idx % A) * 3;
+      xj[idx * 3] = p[0]; xj[idx * 3 + 1] = p[1]; xj[idx * 3 + 2] = p[2];
+    }
+  }
+  for (int idx = threadIdx.x; idx < A; idx += blockDim.x) {
+    mi[idx] = amask[ri * A + idx];
+    if (xyz) {
+      const float* p = xyz + (ri * A + idx) * 3;
+      xi[idx * 3] = p[0]; xi[idx * 3 + 1] = p[1]; xi[idx * 3 + 2] = p[2];
+    }
+  }
+  for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    const int64_t rj = b * K + j;
+    sjs[j] = static_cast<int>((seq_m && !seq_m[rj]) ? kUNK : seq[rj]);
+  }
+  __syncthreads();
+  const unsigned total = static_cast<unsigned>(K) * static_cast<unsigned>(ldo);
+  for (unsigned idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const unsigned j = idx / static_cast<unsigned>(ldo), p = idx - j * static_cast<unsigned>(ldo);
+    float v = 0.0f;
+    if (p < static_cast<unsigned>(AA2)) {
+      const unsigned a1 = p / static_cast<unsigned>(A), a2 = p - a1 * A;
+      float d;
+      if (distmat) {
+        d = distmat[(grow0 + j) * AA2 + p];
+      } else {
+        const float* pa = xi + 3 * a1;
+        const float* pb = xj + (j * A + a2) * 3;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        d = sqrtf((dx * dx + dy * dy) + dz * dz);
+      }
+      v = expf(-1.0f * coef_sp[static_cast<size_t>(si * kAA + sjs[j]) * AA2 + p] * (d * d)) * (mi[a1] * mj[j * A + a2]);
+    }
+    out[(lrow0 + j) * ldo + p] = v;
+  }
+}
+
 // one block per pair row: [aa_pair_emb (C) | relpos_emb * chain_i*chain_j (C) | dist_feat (C) | dihedral enc (2*9)]
 __global__ void pair_cat_kernel(const int64_t* __restrict__ seq, const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
                                 int resid_bstride, const int64_t* __restrict__ chain, const float* __restrict__ pdih,
@@ -337,28 +397,48 @@ __global__ __launch_bounds__(256) void pair_table_scatter_kernel(const float* __
                                                                  const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
                                                                  int resid_bstride, const int64_t* __restrict__ chain, int K, int C, int max_dist,
                                                                  int64_t row0, int64_t nrows, float* __restrict__ G1, float* __restrict__ G2) {
-  extern __shared__ float tab[];  // [441][C] | [2 max_dist + 1][C]
+  extern __shared__ float tab[];  // [441][C] | [2 max_dist + 1][C] | row constants of the current block of 256 rows
   const int n_pair = kAA * kAA * C, n_rel = (2 * max_dist + 1) * C;
+  int* r_idx = reinterpret_cast<int*>(tab + n_pair + n_rel);  // [256] table row of aa_pair_emb
+  int* r_rel = r_idx + 256;                                    // [256] table row of relpos_emb
+  float* r_same = reinterpret_cast<float*>(r_rel + 256);       // [256] chain_i chain_j
   for (int i = threadIdx.x; i < n_pair + n_rel; i += blockDim.x) tab[i] = 0.0f;
-  __syncthreads();
-  const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;
-  const int c0 = threadIdx.x % C, rsub = threadIdx.x / C;
-  // (row0 is a multiple of K K and nrows < 2^31: the (b, i, j) of a row from 32-bit divisions - as 64-bit divisions by run-time values
-  // the index arithmetic was most of this kernel)
+  // (row0 is a multiple of K K and nrows < 2^31: the (b, i, j) of a row from 32-bit divisions; as 64-bit divisions by run-time values,
+  // behind dependent index loads, one row per wave and pass, the index arithmetic was this kernel's time)
   const int64_t b00 = row0 / (static_cast<int64_t>(K) * K);
   const unsigned KK = static_cast<unsigned>(K) * static_cast<unsigned>(K), nr = static_cast<unsigned>(nrows);
-  for (unsigned lr = blockIdx.x * rpb + rsub; lr < nr && rsub < rpb; lr += gridDim.x * rpb) {
-    const unsigned bl = lr / KK, rem = lr - bl * KK;
-    const int i = static_cast<int>(rem / static_cast<unsigned>(K)), j = static_cast<int>(rem - static_cast<unsigned>(i) * K);
-    const int64_t b = b00 + bl;
-    const int64_t ri = b * K + i, rj = b * K + j;
-    const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
-    int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
-    rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
-    const float same = static_cast<float>(chain[ri] * chain[rj]);
-    const float v = g[static_cast<size_t>(lr) * C + c0];
-    atomicAdd(&tab[(si * kAA + sj) * C + c0], v);
-    if (same != 0.0f) atomicAdd(&tab[n_pair + (rel + max_dist) * C + c0], v * same);
+  const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;  // rows scattered per pass (4 at C = 64)
+  const int c0 = threadIdx.x % C, rsub = threadIdx.x / C;
+  for (unsigned blk = blockIdx.x * 256u; blk < nr; blk += gridDim.x * 256u) {
+    __syncthreads();  // the previous block's constants are consumed (first trip: the tables are zero)
+    {  // lanes = rows: every thread the constants of one row (coalesced index loads)
+      const unsigned lr = blk + threadIdx.x;
+      if (lr < nr) {
+        const unsigned bl = lr / KK, rem = lr - bl * KK;
+        const int i = static_cast<int>(rem / static_cast<unsigned>(K)), j = static_cast<int>(rem - static_cast<unsigned>(i) * K);
+        const int64_t b = b00 + bl;
+        const int64_t ri = b * K + i, rj = b * K + j;
+        const int64_t si = (seq_m && !seq_m[ri]) ? kUNK : seq[ri], sj = (seq_m && !seq_m[rj]) ? kUNK : seq[rj];
+        int64_t rel = resid[b * resid_bstride + i] - resid[b * resid_bstride + j];
+        rel = rel < -max_dist ? -max_dist : (rel > max_dist ? max_dist : rel);
+        r_idx[threadIdx.x] = static_cast<int>(si * kAA + sj);
+        r_rel[threadIdx.x] = static_cast<int>(rel) + max_dist;
+        r_same[threadIdx.x] = static_cast<float>(chain[ri] * chain[rj]);
+      }
+    }
+    __syncthreads();
+    if (rsub < rpb) {  // lanes = channels: rpb rows per pass, four passes' loads in flight
+#pragma unroll 4
+      for (int r = rsub; r < 256; r += rpb) {
+        const unsigned lr = blk + r;
+        if (lr < nr) {
+          const float v = g[static_cast<size_t>(lr) * C + c0];
+          const float same = r_same[r];
+          atomicAdd(&tab[r_idx[r] * C + c0], v);
+          if (same != 0.0f) atomicAdd(&tab[n_pair + r_rel[r] * C + c0], v * same);
+        }
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n_pair; i += blockDim.x)
@@ -693,14 +773,14 @@ static int pair_bwd_chunk_patches(const diffab_ctx_dims* d) {
 // then the chain of 64-wide linear backward steps on the taped rows; the 210-wide concatenation and its gradient are never built
 // (pair_table_scatter_kernel + four small products), only the 225-wide distance features are, for distance_embedding[0]'s gradients.
 static int fused_bwd_chunk_patches(const diffab_ctx_dims* d) {
-  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (8 * d->C + 2 * round4(d->A * d->A) + 20) * sizeof(float);
+  const size_t per_patch = static_cast<size_t>(d->K) * d->K * (9 * d->C + 2 * round4(d->A * d->A) + 20) * sizeof(float);
   const size_t n = (static_cast<size_t>(2) << 30) / per_patch;  // ~2 GiB of row buffers at a time (30 K = 128 patches)
   return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
 }
 static size_t fused_bwd_workspace_floats(const diffab_ctx_dims* d) {
   const size_t R = static_cast<size_t>(fused_bwd_chunk_patches(d)) * d->K * d->K;
   const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
-  return R * (8 * d->C + 2 * AA2p + 20) + 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + static_cast<size_t>(kAA) * kAA * d->A * d->A +
+  return R * (9 * d->C + 2 * AA2p + 20) + 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + static_cast<size_t>(kAA) * kAA * d->A * d->A +
          static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + 1024;
 }
 
@@ -719,6 +799,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
   float* m2 = cv.take<float>(R * C);
   float* dA = cv.take<float>(R * C);
   float* dB = cv.take<float>(R * C);
+  float* dC = cv.take<float>(R * C);
   float* ddf = cv.take<float>(R * C);
   float* dh1 = cv.take<float>(R * C);
   float* din = cv.take<float>(R * AA2p);
@@ -739,7 +820,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
   DIFFAB_HIP_CHECK(hipMemsetAsync(gdw0p, 0, sizeof(float) * static_cast<size_t>(C) * (AA2p + Wp), st));
   DIFFAB_HIP_CHECK(hipMemsetAsync(g_sp, 0, sizeof(float) * static_cast<size_t>(kAA) * kAA * AA2, st));
   DIFFAB_HIP_CHECK(hipMemsetAsync(G1, 0, sizeof(float) * static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C, st));
-  const size_t tab_bytes = static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C * sizeof(float);
+  const size_t tab_bytes = static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C * sizeof(float) + 3 * 256 * sizeof(float);
   DIFFAB_REQUIRE(tab_bytes <= 150 * 1024, DIFFAB_ERR_UNSUPPORTED, "pair_embedding_bwd: embedding tables too large for the LDS scatter");
   const float* coef_sp = nullptr;
   for (int b0 = 0; b0 < d->B; b0 += bc) {
@@ -754,26 +835,41 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
     hipLaunchKernelGGL(pair_mask_bwd_kernel, dim3(static_cast<unsigned>((nrows * C + 255) / 256)), dim3(256), 0, st, d_out, atom_mask, d->K,
                        d->A, C, row0, nrows, dA);
     DIFFAB_LAUNCH_CHECK();
-    if (int rc = bwd_linear_masked(dA, C, m2, C, w->mw4, mut(g->mw4), mut(g->mb4), dB, C, rows, C, C, m2, st)) return rc;
-    if (int rc = bwd_linear_masked(dB, C, m1, C, w->mw2, mut(g->mw2), mut(g->mb2), dA, C, rows, C, C, m1, st)) return rc;
-    // ---- mlp[0] without its concatenation: dA = d (pre-activation).  Columns [2C, 3C) and [3C, 3C + 18) of the weight gradient are
-    // plain products with df and the dihedral encoding; the table segments go through G1 / G2 after the loop
+    // ---- the dX chain: four 64 x 64 products, each masked by the ReLU below it in the product's epilogue
+    //      dA = d out (masked) -> dB = d mlp[2] pre-activation -> dC = d mlp[0] pre-activation -> ddf -> dh1
+    if (int rc = bwd_gemm_nn_masked(dA, C, w->mw4, C, dB, C, rows, C, C, m2, st)) return rc;
+    if (int rc = bwd_gemm_nn_masked(dB, C, w->mw2, C, dC, C, rows, C, C, m1, st)) return rc;
+    if (int rc = bwd_gemm_nn_masked(dC, C, mw0p + 2 * C, Wp, ddf, C, rows, C, C, df, st)) return rc;  // distance_embedding ends with a ReLU (:212-217)
+    if (int rc = bwd_gemm_nn_masked(ddf, C, w->dw2, C, dh1, C, rows, C, C, h1, st)) return rc;
+    // ---- the four 64 x 64 weight gradients (+ bias gradients) of mlp[4], mlp[2], mlp[0][:, 2C:3C], distance_embedding[2] in one launch
+    {
+      const float* As[4] = {dA, dB, dC, ddf};
+      const float* Bs[4] = {m2, m1, df, h1};
+      float* Cs[4] = {mut(g->mw4), mut(g->mw2), gmw0p + 2 * C, mut(g->dw2)};
+      const int ldcs[4] = {C, C, Wp, C};
+      float* dbs[4] = {mut(g->mb4), mut(g->mb2), mut(g->mb0), mut(g->db2)};
+      if (int rc = bwd_tn64_set(4, As, Bs, Cs, ldcs, dbs, nrows, st)) return rc;
+    }
+    // ---- the rest of mlp[0] without its concatenation: the dihedral-encoding columns [3C, 3C + 18) are a plain product; the table
+    // segments go through G1 / G2 after the loop
     hipLaunchKernelGGL(pair_enc_kernel, dim3(static_cast<unsigned>((nrows * 2 + 255) / 256)), dim3(256), 0, st, pairwise_dihedrals, row0, nrows,
                        enc);
     DIFFAB_LAUNCH_CHECK();
-    if (int rc = bwd_gemm_tn(dA, C, df, C, gmw0p + 2 * C, Wp, rows, C, C, mut(g->mb0), st)) return rc;
-    if (int rc = bwd_gemm_tn(dA, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) return rc;
+    if (int rc = bwd_gemm_tn(dC, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) return rc;
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_table_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          static_cast<int>(tab_bytes)));
-    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(256), tab_bytes, st, dA, seq_idx, sequence_context_mask, residue_idx,
+    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(256), tab_bytes, st, dC, seq_idx, sequence_context_mask, residue_idx,
                        residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, G1, G2);
     DIFFAB_LAUNCH_CHECK();
-    if (int rc = bwd_gemm_nn_masked(dA, C, mw0p + 2 * C, Wp, ddf, C, rows, C, C, df, st)) return rc;  // distance_embedding ends with a ReLU (:212-217)
-    // ---- distance_embedding[2], [0]
-    if (int rc = bwd_linear_masked(ddf, C, h1, C, w->dw2, mut(g->dw2), mut(g->db2), dh1, C, rows, C, C, h1, st)) return rc;
-    hipLaunchKernelGGL(pair_dist_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq_idx, sequence_context_mask, distmat, xyz,
-                       atom_mask, coef_sp, d->K, d->A, row0, nrows, din, AA2p);
-    DIFFAB_LAUNCH_CHECK();
+    // ---- distance_embedding[0]: the only place the 225-wide features are materialised
+    {
+      const size_t gl_bytes = (static_cast<size_t>(d->K) * d->A * 4 + d->A * 4 + d->K) * sizeof(float);
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dist_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(gl_bytes)));
+      hipLaunchKernelGGL(pair_dist_group_kernel, dim3(static_cast<unsigned>(nrows / d->K)), dim3(256), gl_bytes, st, seq_idx, sequence_context_mask,
+                         distmat, xyz, atom_mask, coef_sp, d->K, d->A, row0, din, AA2p);
+      DIFFAB_LAUNCH_CHECK();
+    }
     if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
     hipLaunchKernelGGL(pair_dist_bwd_group_kernel, dim3(static_cast<unsigned>(nrows / d->K)), dim3(1024), sizeof(float) * kAA * AA2, st, seq_idx,
                        sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, AA2p, g_sp);

@@ -331,6 +331,88 @@ int bwd_gemm_nn_masked(const float* A, int lda, const float* B, int ldb, float* 
                        hipStream_t st) {
   return gemm_nn(A, lda, B, ldb, C, ldc, M, N, K, false, st, nullptr, relu_act, ldc);
 }
+// ---- C_p[64 x 64] += A_p^T B_p for up to four operand pairs of [M x 64] rows (M very large): the PairEmbedding backward's weight
+// gradients, M = 491 k pair rows per chunk.  The 128 x 128-tile bf16x6 kernel spends 196 us on each (three quarters of its tile and all
+// of its split-plane staging wasted on a 64 x 64 output: 1.3 TB/s); here a work-group streams 32-row slabs of both operands through
+// LDS and every thread keeps a 4 x 4 block of the product in registers (plain fp32 FMAs: 8 GFLOP per product is nothing), partial
+// sums joined by atomics; db_p (nullable) += column sums of A_p.
+struct Tn64Set {
+  const float* A[4];
+  const float* B[4];
+  float* C[4];
+  float* db[4];
+  int ldc[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void tn64_kernel(Tn64Set set, int M, int rows_per_group) {
+  __shared__ __attribute__((aligned(16))) float As[32 * 64], Bs[32 * 64];
+  const int pi = blockIdx.y;
+  const float* __restrict__ A = pi == 0 ? set.A[0] : pi == 1 ? set.A[1] : pi == 2 ? set.A[2] : set.A[3];
+  const float* __restrict__ B = pi == 0 ? set.B[0] : pi == 1 ? set.B[1] : pi == 2 ? set.B[2] : set.B[3];
+  float* __restrict__ C = pi == 0 ? set.C[0] : pi == 1 ? set.C[1] : pi == 2 ? set.C[2] : set.C[3];
+  float* __restrict__ db = pi == 0 ? set.db[0] : pi == 1 ? set.db[1] : pi == 2 ? set.db[2] : set.db[3];
+  const int ldc = pi == 0 ? set.ldc[0] : pi == 1 ? set.ldc[1] : pi == 2 ? set.ldc[2] : set.ldc[3];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;  // thread (ty, tx): rows 4 ty .. of C (columns of A), columns 4 tx .. of C
+  const int64_t m_lo = static_cast<int64_t>(blockIdx.x) * rows_per_group;
+  const int64_t m_hi = m_lo + rows_per_group < M ? m_lo + rows_per_group : M;
+  float acc[4][4], cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  for (int64_t m = m_lo; m < m_hi; m += 32) {
+    // slab of 32 rows x 64 floats = 512 float4 per operand: two per thread (rows past m_hi are zero)
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int idx = tid + 256 * rep, r = idx >> 4, c4 = idx & 15;
+      v4 va = {0.f, 0.f, 0.f, 0.f}, vb = va;
+      if (m + r < m_hi) {
+        va = *reinterpret_cast<const v4*>(A + (m + r) * 64 + 4 * c4);
+        vb = *reinterpret_cast<const v4*>(B + (m + r) * 64 + 4 * c4);
+      }
+      *reinterpret_cast<v4*>(As + r * 64 + 4 * c4) = va;
+      *reinterpret_cast<v4*>(Bs + r * 64 + 4 * c4) = vb;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const v4 a = *reinterpret_cast<const v4*>(As + r * 64 + 4 * ty);
+      const v4 b = *reinterpret_cast<const v4*>(Bs + r * 64 + 4 * tx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cs[i] += a[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(C + static_cast<int64_t>(4 * ty + i) * ldc + 4 * tx + j, acc[i][j]);
+    if (db != nullptr && tx == 0) atomicAdd(db + 4 * ty + i, cs[i]);
+  }
+}
+// n <= 4 products C_p[64 x 64] (rows ldc_p apart) += A_p^T B_p, A_p, B_p dense [M x 64], 16-byte aligned; db_p nullable
+int bwd_tn64_set(int n, const float* const* A, const float* const* B, float* const* C, const int* ldc, float* const* db, int64_t M,
+                 hipStream_t st) {
+  DIFFAB_REQUIRE(n >= 1 && n <= 4 && M >= 1 && M < (1ll << 31), DIFFAB_ERR_ARG, "tn64: bad arguments");
+  Tn64Set set{};
+  set.n = n;
+  for (int i = 0; i < n; ++i) {
+    DIFFAB_REQUIRE(A[i] && B[i] && C[i] && (reinterpret_cast<uintptr_t>(A[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(B[i]) & 15) == 0,
+                   DIFFAB_ERR_ARG, "tn64: null / misaligned operand");
+    set.A[i] = A[i]; set.B[i] = B[i]; set.C[i] = C[i]; set.ldc[i] = ldc[i]; set.db[i] = db ? db[i] : nullptr;
+  }
+  const int groups = 512;  // 512 x n work-groups, two or more per CU: the slab loads of one hide behind the FMAs of the other
+  int rpg = static_cast<int>((M + groups - 1) / groups);
+  rpg = (rpg + 31) / 32 * 32;
+  hipLaunchKernelGGL(tn64_kernel, dim3(static_cast<unsigned>((M + rpg - 1) / rpg), n), dim3(256), 0, st, set, static_cast<int>(M), rpg);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
 int bwd_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db, hipStream_t st) {
   bool db_done = false;
   if (int rc = gemm_tn(A, lda, B, ldb, C, ldc, M, N1, N2, st, nullptr, db, &db_done)) return rc;

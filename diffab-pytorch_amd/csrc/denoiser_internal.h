@@ -159,6 +159,9 @@ int bwd_linear_masked(const float* dY, int ldy, const float* X, int ldx, const f
                       int N, int Kd, const float* relu_act, hipStream_t st);
 int bwd_gemm_nn_masked(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* relu_act,
                        hipStream_t st);
+// n <= 4 products C_p[64 x 64] (rows ldc_p apart) += A_p^T B_p of dense [M x 64] operands in one launch; db_p (nullable) += colsum A_p
+int bwd_tn64_set(int n, const float* const* A, const float* const* B, float* const* C, const int* ldc, float* const* db, int64_t M,
+                 hipStream_t st);
 // C[N1 x N2] (rows ldc apart) += A[M x N1]^T B[M x N2]; db (nullable) += column sums of A
 int bwd_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db, hipStream_t st);
 int bwd_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st);
