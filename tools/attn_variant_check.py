@@ -30,16 +30,18 @@ R = torch.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ *
                  1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_), 2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_),
                  1 - 2 * (x_ * x_ + y_ * y_)], -1).view(Bs, K, 3, 3).contiguous()
 outs = {}
-for v in (0, 1):
+VARIANTS = tuple(int(v) for v in os.environ.get("VARIANTS", "0,1").split(","))  # diffab_debug_set_attn_variant values to compare
+for v in VARIANTS:
     lib.diffab_debug_set_attn_variant(v)
     outs[v] = layer(x, e, R, t, flags=_hip.FLAG_PAIR_PLANES).clone()
 lib.diffab_debug_set_attn_variant(0)
 ref = layer(x, e, R, t, flags=0)  # fp32 pair stream
 torch.cuda.synchronize()
 den = float(ref.abs().max())
-print(f"one IPA layer, {Bs} patches: |variant1 - variant0| / max = {float((outs[1] - outs[0]).abs().max()) / den:.3e}; "
-      f"variant0 vs fp32-pair kernel {float((outs[0] - ref).abs().max()) / den:.3e}; variant1 vs fp32-pair kernel "
-      f"{float((outs[1] - ref).abs().max()) / den:.3e}; finite {bool(torch.isfinite(outs[1]).all())}", flush=True)
+v0, v1 = VARIANTS[0], VARIANTS[-1]
+print(f"one IPA layer, {Bs} patches: |variant{v1} - variant{v0}| / max = {float((outs[v1] - outs[v0]).abs().max()) / den:.3e} "
+      f"(bitwise equal: {torch.equal(outs[v1], outs[v0])}); variant{v0} vs fp32-pair kernel {float((outs[v0] - ref).abs().max()) / den:.3e}; "
+      f"variant{v1} vs fp32-pair kernel {float((outs[v1] - ref).abs().max()) / den:.3e}; finite {bool(torch.isfinite(outs[v1]).all())}", flush=True)
 
 dims = d
 model = DiffAb(dims["D"], dims["C"], dims["NL"], dims["DS"], dims["PQ"], dims["PV"], dims["H"]).cuda()
@@ -55,12 +57,12 @@ _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(xx), _hip.ptr(O), _hip
 def loop(t_hi, n):
     _hip.check(lib.diffab_sample_loop(C.byref(hd), C.byref(w.struct), C.byref(sd_dev.struct), C.byref(tab), _hip.ptr(seq), _hip.ptr(xx),
                                       _hip.ptr(O), _hip.ptr(rc), _hip.ptr(pc), _hip.ptr(gm), 2024, 0, t_hi, t_hi - n, _hip.ptr(ws), ws.numel(),
-                                      0, _hip.stream_ptr()), "sample_loop")
+                                      _hip.FLAG_MULTI_LAUNCH, _hip.stream_ptr()), "sample_loop")
 
 
-res = {0: [], 1: []}
+res = {v: [] for v in VARIANTS}
 for rep in range(5):
-    for v in (0, 1):
+    for v in VARIANTS:
         lib.diffab_debug_set_attn_variant(v)
         loop(model.T, 3)
         torch.cuda.synchronize()
@@ -74,7 +76,7 @@ for rep in range(5):
         lib.diffab_kernel_timer_enable(0)
         res[v].append((dt, ms_.value / max(n_.value, 1)))
 lib.diffab_debug_set_attn_variant(0)
-for v in (0, 1):
+for v in VARIANTS:
     r = sorted(res[v][1:])
     print(f"  variant {v}: ms per step median {r[len(r) // 2][0]:.4f} (min {r[0][0]:.4f}); attention launch median {r[len(r) // 2][1] * 1e3:.1f} us; "
           f"blocks {['%.3f' % a for a, _ in res[v]]}; finite {bool(torch.isfinite(xx).all())}", flush=True)
