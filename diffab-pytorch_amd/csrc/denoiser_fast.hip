@@ -377,10 +377,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ipa_attn_fast_kernel
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
 static int g_attn_variant = 0;                       // diagnostics only (diffab_debug_set_attn_variant): 1 = four-wave work-groups
 void set_pair_embed_fused(bool on);  // pair_embed_fused.hip
-void set_attn_variant(int v) {       // A/B switches for tests and tools: bit 0 four-wave attention work-groups, bit 2 unfused pair embedding
-  g_attn_variant = v & 1;
+void set_attn_variant(int v) {       // A/B switches for tests and tools (include/diffab_hip.h)
+  g_attn_variant = v & 9;  // 1: four-wave attention work-groups; 8: the two big dense products of a layer as six-term bf16 products
   set_pair_embed_fused(!(v & 4));
 }
+bool dense_h3_enabled() { return g_attn_variant != 8; }
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);
 }
@@ -711,7 +712,12 @@ static size_t round256(size_t b) { return (b + 255) & ~static_cast<size_t>(255);
 constexpr size_t kLayerSmallFloats = AH * AC + 64 + 128;
 size_t ipa_layer_out_planes_offset() { return round256(proj_frames_b6_scratch_bytes()); }
 size_t ipa_layer_small_offset() { return ipa_layer_out_planes_offset() + round256(rowgemm128_b6_scratch_bytes(AF)); }
-size_t ipa_layer_planes_bytes() { return ipa_layer_small_offset() + round256(kLayerSmallFloats * sizeof(float)); }
+// behind the small vectors: the same two weight sets as two-piece fp16 planes + 1 / scale per output column (gemm_f16x3.hip) - what the
+// forward paths use; the bf16 planes in front stay for the A/B switch and for the callers that still hand them to the bf16x6 tiles
+size_t ipa_layer_h3_pj_offset() { return ipa_layer_small_offset() + round256(kLayerSmallFloats * sizeof(float)); }
+size_t ipa_layer_h3_out_offset() { return ipa_layer_h3_pj_offset() + round256(proj_frames_h3_planes_bytes()); }
+size_t ipa_layer_h3_wis_offset() { return ipa_layer_h3_out_offset() + round256(rowgemm128_h3_planes_bytes(AF)); }  // [1344 projections | 128 to_out]
+size_t ipa_layer_planes_bytes() { return ipa_layer_h3_wis_offset() + round256((ANP + 128) * sizeof(float)); }
 __global__ void layer_small_copy_kernel(const float* __restrict__ w_bias, const float* __restrict__ gamma, const float* __restrict__ b_out,
                                         float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,15 +734,23 @@ int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hip
                        reinterpret_cast<float*>(static_cast<char*>(planes) + ipa_layer_small_offset()));
     DIFFAB_LAUNCH_CHECK();
   }
-  return launch_wsplit128(w->w_out, AF, AF, static_cast<char*>(planes) + ipa_layer_out_planes_offset(), st);
+  char* pl = static_cast<char*>(planes);
+  float* wis = reinterpret_cast<float*>(pl + ipa_layer_h3_wis_offset());
+  if (int rc = launch_pjsplit_h3(W6, pl + ipa_layer_h3_pj_offset(), wis, st)) return rc;
+  if (int rc = launch_wsplit128_h3(w->w_out, AF, AF, pl + ipa_layer_h3_out_offset(), wis + ANP, st)) return rc;
+  return launch_wsplit128(w->w_out, AF, AF, pl + ipa_layer_out_planes_offset(), st);
 }
 static size_t b6_scratch_floats() { return (ipa_layer_planes_bytes() + 256) / sizeof(float); }
 
-// workspace of one layer: proj | feat | 128 | three-launch attention's logits (K = 64 / 128) | per-call weight planes | operand planes
-// of the logits product (proj_planes.hip) | patch centroids
-static size_t ipa_ws_operands_offset(const diffab_dims* d) {
+// workspace of one layer: proj | feat | 128 | three-launch attention's logits (K = 64 / 128) | per-call weight planes | k parts of
+// to_out (small batches: launch_rowgemm128_h3p) | operand planes of the logits product (proj_planes.hip) | patch centroids
+static size_t ipa_ws_parts_offset(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K;
   const size_t o = rows * (ANP + AF) + 128 + (attention_split_supported(d) ? attention_split_workspace_floats(d) : 0) + b6_scratch_floats();
+  return (o + 63) & ~static_cast<size_t>(63);
+}
+static size_t ipa_ws_operands_offset(const diffab_dims* d) {
+  const size_t o = ipa_ws_parts_offset(d) + rowgemm128_h3_parts_floats(d->B * d->K, AF);
   return (o + 63) & ~static_cast<size_t>(63);
 }
 size_t ipa_fast_workspace_floats(const diffab_dims* d) { return ipa_ws_operands_offset(d); }
@@ -758,8 +772,15 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     planes = own;
   }
   const void* out_planes = b6 ? static_cast<const char*>(planes) + ipa_layer_out_planes_offset() : nullptr;
+  // the three-term fp16 form of the two products (gemm_f16x3.hip) unless the A/B switch asks for the six-term bf16 form
+  const bool h3 = b6 && dense_h3_enabled();
+  const char* plc = static_cast<const char*>(planes);
+  const float* wis = b6 ? reinterpret_cast<const float*>(plc + ipa_layer_h3_wis_offset()) : nullptr;
   // to_out (diffab_pytorch.py:459-464): feat (rows x 1024) Wo^T + b
   auto to_out = [&]() -> int {
+    if (h3 && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
+      return launch_rowgemm128_h3p(feat, AF, plc + ipa_layer_h3_out_offset(), wis + ANP, w->b_out, nullptr, 0, y, D, rows, AF, false, st,
+                                   taped ? nullptr : ws + ipa_ws_parts_offset(d));
     if (b6 && rowgemm128_b6_ok(feat, AF, y, D, rows, AF))
       // (inference: the projections are dead once the attention has run, their rows take the k parts of a small batch; on the
       // training tape they are kept for the backward)
@@ -774,7 +795,9 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   bool vec = aligned16(x);
   for (int s = 0; s < 6; ++s) vec = vec && aligned16(segs.W[s]);
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
-  if (b6) {
+  if (h3) {
+    if (int rc = launch_proj_frames_h3p(x, plc + ipa_layer_h3_pj_offset(), wis, R, t, proj, rows, st)) return rc;
+  } else if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {
     const size_t pj_lds = (2 * PJB * PJLD + PJROWS * 12) * sizeof(float);

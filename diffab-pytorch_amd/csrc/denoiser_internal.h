@@ -56,6 +56,8 @@ int launch_wsplit128_segs(const float* const* W, const int* k_end, int nseg, voi
 int launch_rowgemm128_b6p(const float* X, int ldx, const void* planes, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                           int ldy, int M, int Kd, bool relu, hipStream_t st, float* parts = nullptr);
 size_t rowgemm128_b6_parts_floats(int M, int Kd);  // scratch of the k-parts form (few row tiles)
+size_t rowgemm128_h3_parts_floats(int M, int Kd);
+bool dense_h3_enabled();  // false: diffab_debug_set_attn_variant(8), the six-term bf16 form of the projections and to_out
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                          int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st);
 bool use_b6_gemm(uint32_t flags = 0);  // false with DIFFAB_FLAG_FP32_GEMM (experimental builds: or DIFFAB_FP32_GEMM=1 in the environment)
@@ -75,6 +77,18 @@ int launch_gemm_tn_b6(const float* A, int lda, const float* B, int ldb, float* C
 size_t ipa_layer_planes_bytes();
 size_t ipa_layer_out_planes_offset();  // the to_out planes inside a layer's block
 size_t ipa_layer_small_offset();       // fp32 copies of w_bias [8][64], gamma [8] (padded to 64), b_out [128] behind the planes
+size_t ipa_layer_h3_pj_offset();       // gemm_f16x3.hip: the projections' two-piece fp16 planes,
+size_t ipa_layer_h3_out_offset();      //   to_out's,
+size_t ipa_layer_h3_wis_offset();      //   and 1 / scale per output column: [1344 | 128] floats
+// gemm_f16x3.hip: the two big dense products of a layer as three-term fp16 split products (half the matrix-pipe work of bf16x6)
+size_t rowgemm128_h3_planes_bytes(int Kd);
+size_t proj_frames_h3_planes_bytes();
+int launch_wsplit128_h3(const float* W, int ldw, int Kd, void* planes, float* wis, hipStream_t st, int nrows = 128);
+int launch_pjsplit_h3(const float* const* W6, void* planes, float* wis, hipStream_t st);
+int launch_rowgemm128_h3p(const float* X, int ldx, const void* planes, const float* wis, const float* bias, const int64_t* bias_idx, int bias_div,
+                          float* Y, int ldy, int M, int Kd, bool relu, hipStream_t st, float* parts = nullptr);
+int launch_proj_frames_h3p(const float* x, const void* planes, const float* wis, const float* R, const float* t, float* proj, int rows,
+                           hipStream_t st);
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);
 // ipa_persistent.hip: all NL layers of the IPA module for K = 128 patches as ONE patch-resident launch (one work-group owns a patch
 // through projections -> 8 attention row tiles -> to_out, layer after layer; no inter-CU synchronisation).  xa: input, the result is in

@@ -1,8 +1,8 @@
 // ipa_persistent.hip - the IPA module (all NL layers) of a batch of K = 128 patches as ONE patch-resident launch.
 //
 // BASELINE.json's execution model: one 512-thread work-group per CDR patch.  A work-group owns its patch from the first layer's
-// projections to the last layer's to_out - per layer: the six projections of its 128 rows (proj_frames_b6_tile.h), the eight 16-row
-// attention tiles (ipa_attn_tile.h), to_out (rowgemm_b6_tile.h) - and the next patch of its queue after that.  Patches never exchange
+// projections to the last layer's to_out - per layer: the six projections of its 128 rows (proj_frames_h3_tile.h), the eight 16-row
+// attention tiles (ipa_attn_tile.h), to_out (rowgemm_h3_tile.h) - and the next patch of its queue after that.  Patches never exchange
 // data on this path (every einsum of diffab_pytorch.py:416-457 carries `b`; the layer loop :494-498 is per sample), so there is NO
 // inter-CU synchronisation: a phase hands its rows to the next one through global memory written and read by the SAME work-group
 // (one CU, one vector L1: work-group scope; s_waitcnt vmcnt(0) + s_barrier), and the CUs are free to drift apart - which is the point:
@@ -15,15 +15,15 @@
 #include "denoiser_internal.h"
 #define AT_STAMP_REALTIME 1  // the diagnostic stamps of this file's kernels use the chip-wide 100 MHz counter (comparable between CUs)
 #include "ipa_attn_tile.h"
-#include "proj_frames_b6_tile.h"
-#include "rowgemm_b6_tile.h"
+#include "proj_frames_h3_tile.h"
+#include "rowgemm_h3_tile.h"
 
 namespace diffab {
 
 namespace {
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 constexpr size_t kModuleLdsBytes =
-    cmax(ipa_attn_lds_bytes(8), cmax(static_cast<size_t>(pjtile::PJ_LDS_BYTES), static_cast<size_t>(b6tile::lds_bytes<128>())));
+    cmax(ipa_attn_lds_bytes(8), cmax(static_cast<size_t>(pjh3::PJ_LDS_BYTES), static_cast<size_t>(h3tile::lds_bytes<128>())));
 
 struct ModuleArgs {
   float* xa;                 // [B K][128]: the module's input (layer 0 reads it), then every odd layer's output
@@ -35,7 +35,7 @@ struct ModuleArgs {
   const float* R;            // [B K][9]
   const float* t;            // [B K][3]
   const char* planes;        // per layer: ipa_layer_planes_bytes() (projection planes | to_out planes | w_bias, gamma, b_out)
-  size_t layer_stride, out_off, small_off;
+  size_t layer_stride, pj_off, out_off, wis_off, small_off;  // offsets of the fp16 planes, 1 / scale vectors and small vectors in a layer's block
   unsigned long long* stamps;  // diagnostics (null in production): [item][wave][8] of the attention tiles + [B][NL][4] phase stamps behind them
   int B, NL;
   int stagger_ticks, stagger_classes;  // the work-groups of class c = (blockIdx / 8) % classes start c * ticks (10 ns each) late
@@ -68,8 +68,9 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       {  // ---- the six projections + frames of the patch's 128 rows
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (an opaque copy per phase: lane-constant addresses must not stay live across the phases)
-        pjtile::proj_frames_b6_tile<true, true, false>(reinterpret_cast<__bf16*>(lds), tid, b, 0, 1, xin, reinterpret_cast<const __bf16*>(lp),
-                                                       a.R, a.t, a.proj, M, 0, 0, 0, 0);
+        pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b, 0, 1, xin,
+                                               reinterpret_cast<const _Float16*>(lp + a.pj_off), reinterpret_cast<const float*>(lp + a.wis_off),
+                                               a.R, a.t, a.proj, M);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       {  // ---- to_out
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        b6tile::rowgemm128_tile<false, 128>(reinterpret_cast<__bf16*>(lds), tid, b, a.feat, AF, reinterpret_cast<const __bf16*>(lp + a.out_off),
-                                            small + 576, nullptr, 0, xout, 128, M, AF);
+        h3tile::rowgemm128_h3_tile<false, 128>(reinterpret_cast<_Float16*>(lds), tid, b, a.feat, AF,
+                                               reinterpret_cast<const _Float16*>(lp + a.out_off),
+                                               reinterpret_cast<const float*>(lp + a.wis_off) + ANP, small + 576, nullptr, 0, xout, 128, M, AF);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -106,7 +108,9 @@ void set_module_stagger(int ticks, int classes) {
 }
 void set_module_stamps(void* p) { g_module_stamps = static_cast<unsigned long long*>(p); }
 
-bool ipa_module_persistent_supported(const diffab_dims* d) { return fast_path_supported(d) && d->K == 128 && d->NL >= 1; }
+bool ipa_module_persistent_supported(const diffab_dims* d) {
+  return fast_path_supported(d) && d->K == 128 && d->NL >= 1 && dense_h3_enabled();  // (the kernel holds the fp16 tiles only)
+}
 
 // planes: d->NL x ipa_layer_planes_bytes() (ipa_layer_split_weights); pair_planes: launch_pair_split(); xa in, result in (NL odd ? xb : xa)
 int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, const float* R, const float* t, float* ws, const void* planes,
@@ -125,7 +129,9 @@ int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, con
   a.t = t;
   a.planes = static_cast<const char*>(planes);
   a.layer_stride = ipa_layer_planes_bytes();
-  a.out_off = ipa_layer_out_planes_offset();
+  a.pj_off = ipa_layer_h3_pj_offset();
+  a.out_off = ipa_layer_h3_out_offset();
+  a.wis_off = ipa_layer_h3_wis_offset();
   a.small_off = ipa_layer_small_offset();
   a.stamps = g_module_stamps;
   a.B = d->B;

@@ -179,7 +179,9 @@ int diffab_debug_set_attn_stamps(void* device_buffer);
  * and a stamp buffer of (B NL 8 tiles x 8 waves x 8) + (B NL 4) uint64 filled with 100 MHz s_memrealtime stamps (NULL: off). */
 int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; process-global): bit 0 = four-wave work-groups in the plane
                                                  attention kernel (two per CU; measured slower), bit 2 (4) = the PairEmbedding forward / backward
-                                                 as their unfused launches where the fused kernel would apply.  0 = defaults. */
+                                                 as their unfused launches where the fused kernel would apply, 8 (alone) = the six
+                                                 projections and to_out as six-term bf16 split products (rounds 3-4) instead of the
+                                                 three-term fp16 ones - per-layer launches only.  0 = defaults. */
 int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes);
 int diffab_debug_set_module_stamps(void* device_buffer);
 /* The cross-stream ordering guard described under "Streams" above: on (default) / off, process-wide. */

@@ -1,0 +1,37 @@
+"""The built library must not contain the packed-fp32 form that gfx950 miscomputes next to f16/bf16 MFMAs (tools/isa_hazard_lint.py,
+profiles/r05_pk_opsel_hazard.md).  Needs the built .so and the ROCm binary utilities, no GPU."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import isa_hazard_lint  # noqa: E402
+
+LIB = os.path.join(REPO, "diffab-pytorch_amd", "lib", "libdiffab_hip.so")
+
+
+def test_lint_recognises_the_hazard_form():
+    text = """
+0000000000001000 <kernel_a>:
+\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], v[0:3] // 0
+\tv_pk_mul_f32 v[92:93], v[110:111], v[92:93] op_sel:[0,1]   // 1
+\tv_pk_mul_f32 v[92:93], v[110:111], v[92:93] op_sel_hi:[1,0] // 2
+\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[0,1,0]  // 3
+0000000000002000 <kernel_b>:
+\tv_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]  // fp32 MFMAs do not trigger it
+\tv_pk_mul_f32 v[92:93], v[110:111], v[92:93] op_sel:[0,1]
+"""
+    found = isa_hazard_lint.lint_text(text)
+    assert [(k, d) for k, _, d in found] == [("kernel_a", 1), ("kernel_a", 3)]
+
+
+@pytest.mark.skipif(not os.path.exists(LIB) or not os.path.exists(os.path.join(isa_hazard_lint.LLVM, "llvm-objdump")),
+                    reason="needs the built library and the ROCm llvm binary utilities")
+def test_built_library_has_no_op_sel_01_packed_ops_in_mfma_kernels():
+    texts = list(isa_hazard_lint.code_objects(LIB))
+    assert texts, "no gfx950 code object found in the library"
+    assert sum(t.count("v_mfma") for t in texts) > 1000  # the disassembly is the real one
+    found = isa_hazard_lint.lint_paths([LIB])
+    assert not found, found
