@@ -152,6 +152,10 @@ def gpu_clocks():
     import shutil
     import subprocess
 
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ):
+        # under rocprofv3 the profiler's preloaded library has initialised the GPU in this process before main(): starting rocm-smi
+        # (a python script: fork + exec) from here is the exec the GPU boxes refuse
+        return {"skipped": "under rocprofv3"}
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     try:
         out = subprocess.run([exe, "-d", "0", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"], capture_output=True,
