@@ -99,7 +99,8 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
 }
 
 namespace {
-int g_stagger_ticks = 500, g_stagger_classes = 8;  // 8 classes x 5 us: one attention-tile period (profiles/r03_lockstep.md section 3)
+int g_stagger_ticks = 1000, g_stagger_classes = 8;  // 8 classes x 10 us = two attention-tile periods (swept in round 5: 0 | 8 x 2.5 | 8 x 5 |
+                                                     // 8 x 10 | 8 x 20 | 16 x 10 | 8 x 30 us -> 2.47 2.48 2.47 2.43 2.44 2.46 2.50 ms per step)
 unsigned long long* g_module_stamps = nullptr;
 }  // namespace
 void set_module_stagger(int ticks, int classes) {

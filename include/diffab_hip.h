@@ -175,7 +175,7 @@ int diffab_kernel_timer_enable(int on);
  * writes s_memtime stamps at its phase boundaries into it (tools/attn_phase_profile.py).  NULL (default) disables it. */
 int diffab_debug_set_attn_stamps(void* device_buffer);
 /* Diagnostics of the patch-resident module kernel (DIFFAB_FLAG_PERSISTENT_MODULE): its start-up stagger (work-groups of class
- * (index / 8) % classes start class x ticks late, ticks of 10 ns; default 8 x 500 = one attention-tile period spread over 8 classes),
+ * (index / 8) % classes start class x ticks late, ticks of 10 ns; default 8 x 1000: eight classes 10 us apart),
  * and a stamp buffer of (B NL 8 tiles x 8 waves x 8) + (B NL 4) uint64 filled with 100 MHz s_memrealtime stamps (NULL: off). */
 int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; process-global): bit 0 = four-wave work-groups in the plane
                                                  attention kernel (two per CU; measured slower), bit 2 (4) = the PairEmbedding forward / backward
