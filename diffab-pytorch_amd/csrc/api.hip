@@ -387,6 +387,15 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
   DIFFAB_REQUIRE(X && W && Y && M >= 1 && M < (1LL << 31) && Kd >= 32 && Kd % 32 == 0, DIFFAB_ERR_ARG, "debug_linear128: bad operands");
   hipStream_t st = as_stream(stream);
   if (mode == 0) return launch_linear(X, Kd, W, bias, Y, 128, static_cast<int>(M), 128, Kd, false, st);  // rowgemm128 / tiled f32 MFMA
+  if (mode == 2) {  // fp16 x 3 (gemm_f16x3.hip): planes | 1 / scale of the 128 weight rows
+    const size_t pb = (rowgemm128_h3_planes_bytes(Kd) + 255) & ~static_cast<size_t>(255);
+    DIFFAB_REQUIRE(scratch && scratch_bytes >= pb + 512 && rowgemm128_b6_ok(X, Kd, Y, 128, static_cast<int>(M), Kd) &&
+                       (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
+                   DIFFAB_ERR_ARG, "debug_linear128: mode 2 needs 16-byte aligned operands and %zu bytes of scratch", pb + 512);
+    float* wis = reinterpret_cast<float*>(static_cast<char*>(scratch) + pb);
+    if (int rc = launch_wsplit128_h3(W, Kd, Kd, scratch, wis, st)) return rc;
+    return launch_rowgemm128_h3p(X, Kd, scratch, wis, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, st, nullptr);
+  }
   DIFFAB_REQUIRE(mode == 1 && scratch && scratch_bytes >= rowgemm128_b6_scratch_bytes(Kd) && rowgemm128_b6_ok(X, Kd, Y, 128, static_cast<int>(M), Kd),
                  DIFFAB_ERR_ARG, "debug_linear128: mode 1 needs 16-byte aligned operands and %zu bytes of scratch", rowgemm128_b6_scratch_bytes(Kd));
   return launch_rowgemm128_b6(X, Kd, W, Kd, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, scratch, st);

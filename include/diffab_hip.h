@@ -69,7 +69,8 @@ extern "C" {
 #define DIFFAB_FLAG_PAIR_F32 64u /* diffab_sample_loop: keep the fp32 pair stream (do not build the fp16 planes); for single calls simply
                                     do not pass DIFFAB_FLAG_PAIR_PLANES.  The plain-fp32 reference form of the attention kernel. */
 #define DIFFAB_FLAG_FP32_GEMM 128u /* forward paths: the dense products (projections, to_out, MLPs) on the f32-input MFMA kernels instead
-                                      of the six-term bf16 split; same results to fp32 rounding (the plain-fp32 reference form) */
+                                      of the split-precision products (projections, to_out: three-term fp16 under power-of-two
+                                      scales; MLPs: six-term bf16); same results to fp32 rounding (the plain-fp32 reference form) */
 
 #define DIFFAB_FLAG_GRAPH_SAMPLER 16u /* diffab_sample_loop: capture one reverse step into a hipGraph (timestep read from device memory)
                                          and replay it for the remaining steps - one host call per step instead of ~45.  Bitwise the
@@ -188,7 +189,8 @@ int diffab_debug_set_module_stamps(void* device_buffer);
 int diffab_set_stream_guard(int on);
 /* Diagnostics / accuracy tests: Y[M x 128] = X[M x Kd] W[128 x Kd]^T + bias through ONE of the two dense kernels of the MFMA path -
  * mode 0: f32-input MFMA (rowgemm128_kernel), mode 1: bf16 matrix cores, six-term split (rowgemm128_b6_kernel; scratch >=
- * 3 * 128 * Kd * 2 bytes, 16-byte aligned operands).  Kd a multiple of 32.  Lets a test measure both against float64. */
+ * 3 * 128 * Kd * 2 bytes, 16-byte aligned operands), mode 2: f16 matrix cores, three-term split under power-of-two scales
+ * (rowgemm128_h3_kernel; scratch >= 2 * 128 * Kd * 2 + 768 bytes).  Kd a multiple of 32.  Lets a test measure them against float64. */
 int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
                            size_t scratch_bytes, void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);

@@ -145,6 +145,25 @@ def test_patch_resident_module_is_bitwise_the_per_layer_launches(hip):
     torch.cuda.empty_cache()
 
 
+def test_ipa_layer_bits_do_not_depend_on_the_launch_form(hip):
+    """One IPA layer on the first patches of batches of 1, 8, 40, 128 and 256 patches: the dense products pick a launch form by batch
+    size - (row tile, 64-k part) work-groups, 64-row groups, 128-row groups, projections split over column blocks - and all of them
+    have to produce the same bits for the same patch (the sampler's shard invariance rests on it)."""
+    from diffab_pytorch.diffab_pytorch import InvariantPointAttentionLayer
+
+    d, K = syn.BENCH_DIMS, 128
+    torch.manual_seed(0)
+    layer = InvariantPointAttentionLayer(d["D"], d["C"], d["DS"], d["PQ"], d["PV"], d["H"]).cuda().requires_grad_(False)
+    inp = device_patches(256, K, d, seed=77)
+    outs = {}
+    for B in (1, 8, 40, 128, 256):
+        args = [inp[k][:B].contiguous() for k in ("res_context_emb", "pair_context_emb", "orientations", "translations")]
+        outs[B] = layer(*args, flags=_hip.FLAG_PAIR_PLANES)[: min(B, 8)].clone()
+    for B, o in outs.items():
+        assert torch.isfinite(o).all()
+        assert torch.equal(o, outs[256][: o.shape[0]]), (B, int((o != outs[256][: o.shape[0]]).sum()))
+
+
 def test_config2_b256_k128_100_steps(hip):
     dims, model = bench_model(100)
     inp = device_patches(256, 128, dims, seed=2)

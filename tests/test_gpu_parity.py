@@ -1151,8 +1151,9 @@ def test_encode_context_benchmark_dims_and_end_to_end(hip):
 
 @pytest.mark.parametrize("Kd", [128, 1024, 1344])
 def test_split_precision_gemm_is_fp32_accurate(hip, Kd):
-    """The bf16x6 dense kernel (three exact bf16 pieces per operand, six exact partial products, fp32 accumulation) against float64,
-    side by side with the f32-input MFMA kernel it replaces: its error must be of the same size, on operands whose
+    """The bf16x6 dense kernel (three exact bf16 pieces per operand, six exact partial products, fp32 accumulation) and the fp16x3 one
+    (two fp16 pieces under power-of-two scales - one per weight row, one per (row, 64 k) of X - three partial products) against float64,
+    side by side with the f32-input MFMA kernel they replace: its error must be of the same size, on operands whose
     magnitudes span six decades (the split must not care) and at the three contraction lengths of the model."""
     g = torch.Generator(device="cuda").manual_seed(Kd)
     M = 4096 + 37  # ragged last work-group
@@ -1163,15 +1164,16 @@ def test_split_precision_gemm_is_fp32_accurate(hip, Kd):
     scale = (X.double().abs() @ W.double().abs().T) + b.double().abs()  # the natural error scale of a dot product: sum |x w|
     scratch = torch.empty(3 * 128 * Kd * 2 + 256, dtype=torch.uint8, device="cuda")
     errs = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         Y = torch.empty(M, 128, device="cuda")
         rc = hip.diffab_debug_linear128(_hip.ptr(X), _hip.ptr(W), _hip.ptr(b), _hip.ptr(Y), M, Kd, mode, _hip.ptr(scratch), scratch.numel(),
                                         _hip.stream_ptr())
         assert rc == 0, hip.diffab_last_error()
         errs[mode] = float(((Y.double() - want).abs() / scale).max())
-    print(f"Kd={Kd}: max |err| / sum|x w|: f32 MFMA {errs[0]:.2e}, bf16x6 {errs[1]:.2e}")
-    assert errs[0] < 2e-6 and errs[1] < 2e-6, errs      # both at fp32 accumulation noise (a plain bf16 product would be ~4e-3)
-    assert errs[1] < 4 * errs[0] + 1e-7, errs           # and the split form is not worse than the fp32 kernel by more than noise
+    print(f"Kd={Kd}: max |err| / sum|x w|: f32 MFMA {errs[0]:.2e}, bf16x6 {errs[1]:.2e}, fp16x3 {errs[2]:.2e}")
+    assert errs[0] < 2e-6 and errs[1] < 2e-6 and errs[2] < 2e-6, errs  # all at fp32 accumulation noise (a plain bf16 product would be ~4e-3)
+    assert errs[1] < 4 * errs[0] + 1e-7, errs           # and the split forms are not worse than the fp32 kernel by more than noise
+    assert errs[2] < 4 * errs[0] + 4e-7, errs           # (fp16 x 3 carries 22 bits per operand: 2^-22 = 2.4e-7 on top)
 
 
 @pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4])
