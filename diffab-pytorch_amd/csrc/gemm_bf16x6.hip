@@ -259,7 +259,9 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
         for (int term = 0; term < 6; ++term)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt)
-            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[term]], b[tt][TB[term]], acc[tt], 0, 0, 0);
+            // (weights as the A operand: D is the TRANSPOSED tile - a lane ends with 16 columns of ONE row, four consecutive ones per
+            // r >> 2, and the epilogue writes the next layer's input as 8-byte pieces instead of 2-byte ones)
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tt][TB[term]], a[TA[term]], acc[tt], 0, 0, 0);
       }
       if (c < 3) {  // next chunk of this layer into the other buffer, then request the one after it (or the next layer's first chunk)
         store_w(buf ^ 1);
@@ -269,37 +271,52 @@ __global__ __launch_bounds__(512) void mlp_chain_b6_kernel(const float* __restri
       }
       __syncthreads();
     }
-    // ---- epilogue.  D 32x32: column = lane & 31 (+ 32 tt + 64 cw), row = (r & 3) + 8 (r >> 2) + 4 hk (+ 32 rw)
+    // ---- epilogue.  D^T 32x32: row = lane & 31 (+ 32 rw), column = (r & 3) + 8 (r >> 2) + 4 hk (+ 32 tt + 64 cw)
     const bool table = L == 0 && (ch.bias_idx0 != nullptr || ch.bias_div0 > 0);
+    const int lrow = 32 * rw + l31, row = m0 + lrow;
+    const float* bl = bias_of(L);
+    if (table) {
+      const int rc = row < M ? row : M - 1;
+      const int64_t bi = ch.bias_idx0 ? ch.bias_idx0[rc] : rc / ch.bias_div0;
+      bl = bs0 + bi * 128;
+    }
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int col = 64 * cw + 32 * tt + l31;
-      const float* bl = bias_of(L);
-      float bv = (bl && !table && (!last || col < ch.n_out)) ? bl[col] : 0.0f;
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = 32 * rw + (r & 3) + 8 * (r >> 2) + 4 * hk, row = m0 + lrow;
-        if (table) {
-          const int rc = row < M ? row : M - 1;
-          const int64_t bi = ch.bias_idx0 ? ch.bias_idx0[rc] : rc / ch.bias_div0;
-          bv = bs0[bi * 128 + col];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int col = 64 * cw + 32 * tt + 8 * g4 + 4 * hk;  // four consecutive columns col .. col + 3
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bl && (table || !last || col + 3 < ch.n_out)) bv = *reinterpret_cast<const f32x4*>(bl + col);
+        else if (bl && col < ch.n_out) {  // the narrow last layer: the columns that exist
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < ch.n_out) bv[e] = bl[col + e];
         }
-        float o = acc[tt][r] + bv;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[tt][4 * g4 + e] + bv[e];
         if (last) {
-          if (row < M && col < ch.n_out) Y[static_cast<int64_t>(row) * ldy + col] = o;
+          if (row < M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < ch.n_out) Y[static_cast<int64_t>(row) * ldy + col + e] = o[e];
+          }
         } else {
-          o = fmaxf(o, 0.f);  // every layer but the last is followed by a ReLU
-          __bf16 hh, mm, ll;
-          split3(o, hh, mm, ll);
-          // element (row lrow, k = col) of the next layer's input: chunk col / 32, slot (col % 32) / 8, element col % 8.  All reads of
-          // the image by this layer are behind the last barrier of the chunk loop.
+          bf16x4 h, m, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            __bf16 hh, mm, ll;
+            split3(fmaxf(o[e], 0.f), hh, mm, ll);  // every layer but the last is followed by a ReLU
+            h[e] = hh; m[e] = mm; l[e] = ll;
+          }
+          // elements (row lrow, k = col .. col + 3) of the next layer's input: chunk col / 32, slot (col % 32) / 8, elements col % 8 ..
+          // All reads of the image by this layer are behind the last barrier of the chunk loop.
           __bf16* dst = img + (col >> 5) * (3 * 128 * BK) + b6_off(lrow, (col & 31) >> 3) + (col & 7);
-          dst[0] = hh;
-          dst[128 * BK] = mm;
-          dst[2 * 128 * BK] = ll;
+          *reinterpret_cast<bf16x4*>(dst) = h;
+          *reinterpret_cast<bf16x4*>(dst + 128 * BK) = m;
+          *reinterpret_cast<bf16x4*>(dst + 2 * 128 * BK) = l;
         }
       }
-    }
   }
 }
 
