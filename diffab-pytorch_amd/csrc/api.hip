@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "denoiser_internal.h"
+#include "mlp_chain_tile.h"
 
 namespace diffab {
 
@@ -227,10 +228,22 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     if (b6) return launch_rowgemm128_b6p(X, D, mlp + slot * mlp_planes_bytes(), bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
     return launch_rowgemm128(X, D, W, ldw, bias, bias_idx, bias_div, Y, D, rows, D, relu, st);
   };
+  // DIFFAB_FLAG_PERSISTENT_MODULE: the NL layers as one patch-resident launch (ipa_persistent.hip) - the same tile bodies, bitwise the
+  // same result; needs the prepared planes of all layers, the pair planes, and K = 128.  Where the MLP chains apply too, the embedding
+  // MLP and the three heads run as phases of that launch (fused_mlps): one launch per step in front of the state update.
+  const bool persistent = (flags & DIFFAB_FLAG_PERSISTENT_MODULE) && fold && use_b6_gemm(flags) && pair_planes != nullptr &&
+                          ipa_module_persistent_supported(d) && last_layer_tiles == nullptr;
+  const bool fused_mlps = persistent && chain && D == 128 && out_res_emb == nullptr;
+  float* logits = out_logits ? out_logits : b.logits;
+  MlpChainSet emb_set{}, head_set{};
   if (fold && chain) {
-    const void* pl[2] = {mlp, mlp + mlp_planes_bytes()};
-    const float* bs[2] = {b.emb_tab, w->res_b2};
-    if (int rc = launch_mlp_chain_b6(res_ctx, D, pl, bs, seq_t, 0, 2, D, b.hA, D, rows, st)) return rc;
+    const void* pl[3] = {mlp, mlp + mlp_planes_bytes(), nullptr};
+    const float* bs[3] = {b.emb_tab, w->res_b2, nullptr};
+    float* ys[1] = {b.hA};
+    const int nout1[1] = {D};
+    if (int rc = make_mlp_chain_set(&emb_set, 1, pl, bs, seq_t, 0, 2, nout1, ys, nout1)) return rc;
+    if (!fused_mlps)
+      if (int rc = launch_mlp_chain_b6(res_ctx, D, pl, bs, seq_t, 0, 2, D, b.hA, D, rows, st)) return rc;
   } else if (fold) {
     if (int rc = dense128(0, res_ctx, w->res_w0, 2 * D, b.emb_tab, seq_t, 0, b.h1, true)) return rc;
     if (int rc = dense128(1, b.h1, w->res_w2, D, w->res_b2, nullptr, 0, b.hA, false)) return rc;
@@ -240,12 +253,28 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     if (int rc = launch_linear(b.h1, D, w->res_w2, w->res_b2, b.hA, D, rows, D, D, false, st)) return rc;
   }
   float *cur = b.hA, *nxt = b.hB;
-  // DIFFAB_FLAG_PERSISTENT_MODULE: the NL layers as one patch-resident launch (ipa_persistent.hip) - the same tile bodies, bitwise the
-  // same result; needs the prepared planes of all layers, the pair planes, and K = 128
-  const bool persistent = (flags & DIFFAB_FLAG_PERSISTENT_MODULE) && fold && use_b6_gemm(flags) && pair_planes != nullptr &&
-                          ipa_module_persistent_supported(d) && last_layer_tiles == nullptr;
+  const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
+  float* outs[3] = {out_eps, b.vbuf, logits};
+  const int nout[3] = {3, 3, d->V};
+  const void* hpl[9];
+  const float* hbs[9];
+  if (fold && chain) {  // the three heads read the same rows: one launch (blockIdx.y = head), or three phases of the module launch
+    for (int hd = 0; hd < 3; ++hd) {
+      DIFFAB_REQUIRE(hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
+      hpl[3 * hd] = mlp + (2 + 2 * hd) * mlp_planes_bytes();
+      hpl[3 * hd + 1] = mlp + (3 + 2 * hd) * mlp_planes_bytes();
+      hpl[3 * hd + 2] = mlp + (8 + hd) * mlp_planes_bytes();
+      hbs[3 * hd] = beta_traj ? beta_traj + (static_cast<size_t>(hd) * traj_rows + t_step) * D : b.beta_tab + static_cast<size_t>(hd) * d->B * D;
+      hbs[3 * hd + 1] = hw[hd]->b2;
+      hbs[3 * hd + 2] = hw[hd]->b4;
+    }
+    // (beta_traj: one table row for every patch - "row / rows" is 0 for all of them)
+    if (int rc = make_mlp_chain_set(&head_set, 3, hpl, hbs, nullptr, beta_traj ? rows : d->K, 3, nout, outs, nout)) return rc;
+  }
   if (persistent) {
-    if (int rc = launch_ipa_module_persistent(d, b.hA, b.hB, O_t, x_t, b.ipa, b.planes, pair_planes, st)) return rc;
+    if (int rc = launch_ipa_module_persistent(d, b.hA, b.hB, O_t, x_t, b.ipa, b.planes, pair_planes, st, fused_mlps ? res_ctx : nullptr,
+                                              &emb_set, &head_set))
+      return rc;
     cur = (d->NL & 1) ? b.hB : b.hA;
   }
   for (int l = 0; l < d->NL && !persistent; ++l) {
@@ -256,27 +285,11 @@ static int denoise_step(const diffab_dims* d, const diffab_denoiser_weights* w, 
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   if (out_res_emb) DIFFAB_HIP_CHECK(hipMemcpyAsync(out_res_emb, cur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
-  float* logits = out_logits ? out_logits : b.logits;
   if (fold) {
-    const diffab_mlp3_weights* hw[3] = {&w->coord, &w->orient, &w->seq};
-    float* outs[3] = {out_eps, b.vbuf, logits};
-    const int nout[3] = {3, 3, d->V};
     for (int hd = 0; hd < 3; ++hd)
       DIFFAB_REQUIRE(hw[hd]->w2 && hw[hd]->b2 && hw[hd]->w4 && hw[hd]->b4, DIFFAB_ERR_ARG, "denoiser head: null weight pointer");
-    if (chain) {  // the three heads read the same rows: one launch, blockIdx.y = head
-      const void* pl[9];
-      const float* bs[9];
-      for (int hd = 0; hd < 3; ++hd) {
-        pl[3 * hd] = mlp + (2 + 2 * hd) * mlp_planes_bytes();
-        pl[3 * hd + 1] = mlp + (3 + 2 * hd) * mlp_planes_bytes();
-        pl[3 * hd + 2] = mlp + (8 + hd) * mlp_planes_bytes();
-        bs[3 * hd] = beta_traj ? beta_traj + (static_cast<size_t>(hd) * traj_rows + t_step) * D : b.beta_tab + static_cast<size_t>(hd) * d->B * D;
-        bs[3 * hd + 1] = hw[hd]->b2;
-        bs[3 * hd + 2] = hw[hd]->b4;
-      }
-      // (beta_traj: one table row for every patch - "row / rows" is 0 for all of them)
-      if (int rc = launch_mlp_chains_b6(cur, D, 3, pl, bs, nullptr, beta_traj ? rows : d->K, 3, nout, outs, nout, rows, st)) return rc;
-    }
+    if (chain && !fused_mlps)
+      if (int rc = launch_mlp_chains_b6(cur, D, 3, hpl, hbs, nullptr, beta_traj ? rows : d->K, 3, nout, outs, nout, rows, st)) return rc;
     for (int hd = 0; hd < 3 && !chain; ++hd) {
       if (int rc = dense128(2 + 2 * hd, cur, hw[hd]->w0, D + 3, b.beta_tab + static_cast<size_t>(hd) * d->B * D, nullptr, d->K, b.t1, true))
         return rc;

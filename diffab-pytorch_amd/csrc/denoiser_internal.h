@@ -49,6 +49,10 @@ int launch_wsplit128(const float* W, int ldw, int Kd, void* planes, hipStream_t 
 // activations stay in LDS); layer 0's bias may be a table indexed per row like launch_rowgemm128's
 int launch_mlp_chains_b6(const float* X, int ldx, int nchains, const void* const* planes, const float* const* bias, const int64_t* bias_idx0,
                          int bias_div0, int nlayers, const int* n_out, float* const* Y, const int* ldy, int M, hipStream_t st);
+struct MlpChainSet;  // mlp_chain_tile.h
+// the descriptors of up to three chains (the by-value kernel argument of mlp_chain_b6_kernel; also handed to the module kernel)
+int make_mlp_chain_set(MlpChainSet* out, int nchains, const void* const* planes, const float* const* bias, const int64_t* bias_idx0,
+                       int bias_div0, int nlayers, const int* n_out, float* const* Y, const int* ldy);
 int launch_mlp_chain_b6(const float* X, int ldx, const void* const* planes, const float* const* bias, const int64_t* bias_idx0, int bias_div0,
                         int nlayers, int n_out, float* Y, int ldy, int M, hipStream_t st);
 int launch_wsplit128_strided(const float* W, int64_t sn, int64_t sk, int kseg, int k0, void* planes, hipStream_t st);  // (n, k) = W[n sn + k sk]
@@ -95,7 +99,8 @@ int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hip
 // (NL odd ? xb : xa).  planes: NL x ipa_layer_planes_bytes(); pair_planes: launch_pair_split(); ws: proj | feat (ipa_fast_workspace_floats)
 bool ipa_module_persistent_supported(const diffab_dims* d);
 int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, const float* R, const float* t, float* ws, const void* planes,
-                                 const float* pair_planes, hipStream_t st);
+                                 const float* pair_planes, hipStream_t st, const float* emb_X = nullptr, const MlpChainSet* emb = nullptr,
+                                 const MlpChainSet* heads = nullptr);
 void set_module_stagger(int ticks, int classes);  // diagnostics: start-up stagger of the persistent module kernel (10 ns ticks)
 void set_module_stamps(void* device_buffer);      // diagnostics: phase stamps of the persistent module kernel
 // bias tables of the folded concatenations: emb_tab[25][D] and beta_tab[3 heads][B][D] (see denoiser_fast.hip)

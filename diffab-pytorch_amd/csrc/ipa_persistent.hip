@@ -17,13 +17,14 @@
 #include "ipa_attn_tile.h"
 #include "proj_frames_h3_tile.h"
 #include "rowgemm_h3_tile.h"
+#include "mlp_chain_tile.h"
 
 namespace diffab {
 
 namespace {
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
-constexpr size_t kModuleLdsBytes =
-    cmax(ipa_attn_lds_bytes(8), cmax(static_cast<size_t>(pjh3::PJ_LDS_BYTES), static_cast<size_t>(h3tile::lds_bytes<128>())));
+constexpr size_t kModuleLdsBytes = cmax(cmax(ipa_attn_lds_bytes(8), static_cast<size_t>(kChainLdsBytes)),
+                                        cmax(static_cast<size_t>(pjh3::PJ_LDS_BYTES), static_cast<size_t>(h3tile::lds_bytes<128>())));
 
 struct ModuleArgs {
   float* xa;                 // [B K][128]: the module's input (layer 0 reads it), then every odd layer's output
@@ -37,6 +38,10 @@ struct ModuleArgs {
   const char* planes;        // per layer: ipa_layer_planes_bytes() (projection planes | to_out planes | w_bias, gamma, b_out)
   size_t layer_stride, pj_off, out_off, wis_off, small_off;  // offsets of the fp16 planes, 1 / scale vectors and small vectors in a layer's block
   unsigned long long* stamps;  // diagnostics (null in production): [item][wave][8] of the attention tiles + [B][NL][4] phase stamps behind them
+  // the denoiser's MLPs as phases of the same launch (null emb_X: not fused): the embedding MLP of the patch's rows in front of layer 0
+  // (emb_X -> xa), the three heads behind the last layer (module output -> heads.Y[]); mlp_chain_tile.h, bitwise mlp_chain_b6_kernel
+  const float* emb_X;
+  MlpChainSet emb, heads;
   int B, NL;
   int stagger_ticks, stagger_classes;  // the work-groups of class c = (blockIdx / 8) % classes start c * ticks (10 ns each) late
 };
@@ -58,6 +63,14 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
   };
 #pragma unroll 1
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    if (a.emb_X != nullptr) {  // ---- to_res_emb of the patch's rows (diffab_pytorch.py:519-523, folded concatenation)
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      chaintile::mlp_chain_tile(reinterpret_cast<__bf16*>(lds), tid, b, a.emb_X, 128, a.emb.c[0].planes[0], a.emb.c[0].planes[1], nullptr,
+                                a.emb.c[0].bias[0], a.emb.c[0].bias[1], nullptr, a.emb.c[0].bias_idx0, a.emb.c[0].bias_div0, 2, 128, a.xa, 128, M);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
 #pragma unroll 1
     for (int l = 0; l < a.NL; ++l) {
       const char* lp = a.planes + static_cast<size_t>(l) * a.layer_stride;
@@ -95,6 +108,22 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       __syncthreads();
       pstamp(b, l, 3);
     }
+    if (a.emb_X != nullptr) {  // ---- the three heads on the module's output rows (:525-533, beta columns folded into bias tables)
+      const float* xfin = (a.NL & 1) ? a.xb : a.xa;
+#pragma unroll 1
+      for (int hd = 0; hd < 3; ++hd) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+#define HSEL(f) (hd == 0 ? a.heads.c[0].f : hd == 1 ? a.heads.c[1].f : a.heads.c[2].f)
+        chaintile::mlp_chain_tile(reinterpret_cast<__bf16*>(lds), tid, b, xfin, 128, HSEL(planes[0]), HSEL(planes[1]), HSEL(planes[2]),
+                                  HSEL(bias[0]), HSEL(bias[1]), HSEL(bias[2]), HSEL(bias_idx0), HSEL(bias_div0), 3, HSEL(n_out),
+                                  hd == 0 ? a.heads.Y[0] : hd == 1 ? a.heads.Y[1] : a.heads.Y[2],
+                                  hd == 0 ? a.heads.ldy[0] : hd == 1 ? a.heads.ldy[1] : a.heads.ldy[2], M);
+#undef HSEL
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the next chain (or the next patch's first phase) overwrites the image
+      }
+    }
   }
 }
 
@@ -114,8 +143,11 @@ bool ipa_module_persistent_supported(const diffab_dims* d) {
 }
 
 // planes: d->NL x ipa_layer_planes_bytes() (ipa_layer_split_weights); pair_planes: launch_pair_split(); xa in, result in (NL odd ? xb : xa)
+// emb_X (optional, with emb and heads): the embedding MLP's input rows - the launch then also runs the embedding MLP (-> xa) and the three
+// heads (module output -> heads->Y[]) of every patch
 int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, const float* R, const float* t, float* ws, const void* planes,
-                                 const float* pair_planes, hipStream_t st) {
+                                 const float* pair_planes, hipStream_t st, const float* emb_X, const MlpChainSet* emb,
+                                 const MlpChainSet* heads) {
   DIFFAB_REQUIRE(ipa_module_persistent_supported(d) && xa && xb && R && t && ws && planes && pair_planes, DIFFAB_ERR_ARG,
                  "ipa_module_persistent: unsupported operands");
   const size_t rows = static_cast<size_t>(d->B) * d->K;
@@ -135,6 +167,13 @@ int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, con
   a.wis_off = ipa_layer_h3_wis_offset();
   a.small_off = ipa_layer_small_offset();
   a.stamps = g_module_stamps;
+  if (emb_X != nullptr) {
+    DIFFAB_REQUIRE(emb && heads && d->D == 128 && (reinterpret_cast<uintptr_t>(emb_X) & 15) == 0, DIFFAB_ERR_ARG,
+                   "ipa_module_persistent: the fused MLP phases need both chain sets");
+    a.emb_X = emb_X;
+    a.emb = *emb;
+    a.heads = *heads;
+  }
   a.B = d->B;
   a.NL = d->NL;
   a.stagger_ticks = g_stagger_ticks;
