@@ -612,9 +612,9 @@ def main():
             "whole_path_hbm_frac": value / world * algorithmic_bytes_per_residue_step(K, dims["D"], dims["C"], dims["NL"]) / 1e9
                                    / HBM_PEAK_GBPS,
             "roofline": {
-                "kernel": ("ipa_module_persistent_kernel: the NL = %d layers of the IPA module as one patch-resident launch (per layer: six "
-                           "projections, eight attention row tiles, to_out); algorithmic bytes = NL x the pair-embedding stream"
-                           % dims["NL"]) if module_form else
+                "kernel": ("ipa_module_persistent_kernel: one patch-resident launch per denoiser forward - the embedding MLP, the NL = %d "
+                           "layers of the IPA module (per layer: six projections, eight attention row tiles, to_out) and the three heads "
+                           "of each patch; algorithmic bytes = NL x the pair-embedding stream" % dims["NL"]) if module_form else
                           "ipa_attention (pair-embedding stream: bias + softmax + attn-weighted pair/scalar/point sums)",
                 "bound": "hbm",
                 "achieved": achieved,

@@ -82,7 +82,10 @@ extern "C" {
                                          run as ONE patch-resident launch - a 512-thread work-group owns a patch through projections,
                                          eight attention row tiles and to_out, layer after layer, with no inter-CU synchronisation
                                          (patches never exchange data) - instead of 3 NL chip-wide launches.  Same tile bodies:
-                                         bitwise the multi-launch result.  Ignored where it does not apply.  diffab_sample_loop
+                                         bitwise the multi-launch result.  Where the MLP chains apply (D == 128, V <= 128, no
+                                         out_res_emb) the launch also runs the embedding MLP of the patch's rows in front of layer 0
+                                         and the three heads behind the last layer: one launch per denoiser forward.  Ignored where
+                                         it does not apply.  diffab_sample_loop
                                          chooses it by itself when the batch fills the chip (B >= number of CUs), see
                                          DIFFAB_FLAG_MULTI_LAUNCH; with DIFFAB_FLAG_SKIP_UNUSED_ROWS the per-layer launches stay. */
 #define DIFFAB_FLAG_MULTI_LAUNCH 1024u /* diffab_sample_loop: keep one launch per kernel of an IPA layer even where the patch-resident module

@@ -95,6 +95,12 @@ if os.environ.get("STAMPS", "0") != "0":
     print(f"  module span {(ph[:, -1, 3].max() - t00) * tick:.1f} us; per patch-layer: proj {((ph[..., 1] - ph[..., 0]).mean()) * tick:.1f} us, "
           f"attention {((ph[..., 2] - ph[..., 1]).mean()) * tick:.1f} us, to_out {((ph[..., 3] - ph[..., 2]).mean()) * tick:.1f} us; "
           f"last work-group done at {(ph[:, -1, 3].max() - t00) * tick:.1f}, first at {(ph[:, -1, 3].min() - t00) * tick:.1f}")
+    dur = (ph[:, -1, 3] - ph[:, 0, 0]) * tick  # a work-group's own module time (first projection stamp -> last to_out stamp)
+    start = (ph[:, 0, 0] - t00) * tick
+    print(f"  per work-group: own time min {dur.min():.0f} mean {dur.mean():.0f} max {dur.max():.0f} us; start min {start.min():.0f} max {start.max():.0f} us")
+    print("  own time by XCD (work-group % 8): " + " ".join(f"{float(dur[x::8].mean()):.0f}" for x in range(8)))
+    print("  own time by stagger class ((work-group / 8) % 8): " + " ".join(f"{float(dur[[i for i in range(B) if (i // 8) % 8 == c]].mean()):.0f}" for c in range(8)))
+    print("  finish time by stagger class: " + " ".join(f"{float(((ph[:, -1, 3] - t00) * tick)[[i for i in range(B) if (i // 8) % 8 == c]].mean()):.0f}" for c in range(8)))
     w0 = s[:, :, :, 0, :]  # wave 0
     tile_life = (w0[..., 5] - w0[..., 0]) * tick
     p1, p2, p3 = (w0[..., 2] - w0[..., 0]) * tick, (w0[..., 3] - w0[..., 2]) * tick, (w0[..., 5] - w0[..., 3]) * tick
