@@ -1,8 +1,9 @@
 """ISA lint for a gfx950 hazard hipcc (ROCm 7.2) does not guard (found in round 5, measured by tools/hwtests/pkmul_mfma.hip):
 a packed-fp32 VALU op (v_pk_mul/add/fma_f32) with op_sel:[0,1] - the LOW result reads source 0's low register and source 1's HIGH
 register - returns a wrong low result in lanes 48-63 when f16/bf16 matrix instructions (v_mfma_*_f16 / _bf16) are in flight around it:
-41 % of the time with an MFMA issued right behind it, ~1e-6 with MFMAs merely nearby.  op_sel:[1,0], [1,1] and op_sel_hi forms measured
-clean, fp32 MFMAs (16x16x4) do not trigger it.
+41 % of the time with an MFMA issued right behind it, ~1e-6 with MFMAs merely nearby.  op_sel:[1,0], [1,1], op_sel_hi:[1,0], the fma forms
+[0,0,1] [1,0,0] [0,1,1] [1,1,0] [1,0,1] and v_pk_mov_b32 measured clean, fp32 MFMAs (16x16x4) do not trigger it.  (The lint also flags
+fma [0,1,1], which measured clean: it matches on the first two selectors.)
 
 The lint disassembles every code object of the built library and lists the op_sel:[0,1] packed ops inside kernels that also contain
 f16/bf16 MFMAs.  Exit status 1 when there is one.  usage: isa_hazard_lint.py [build dir or .so/.o files]
