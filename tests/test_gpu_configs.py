@@ -141,6 +141,11 @@ def test_patch_resident_module_is_bitwise_the_per_layer_launches(hip):
             g = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=fl_a, graph=True, **kw)
             for k in a:
                 assert torch.equal(a[k], g[k]), ("graph", k)
+        if B == 256:  # and equal to itself, run after run (how the packed-fp32 hazard of profiles/r05_pk_opsel_hazard.md showed: a
+            for rep in range(4):  # handful of patches per step differed between two runs of the SAME launch)
+                a2 = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=fl_a, **kw)
+                for k in a:
+                    assert torch.equal(a[k], a2[k]), ("run-to-run", rep, k)
     del inp
     torch.cuda.empty_cache()
 
