@@ -1,5 +1,6 @@
 // api.hip - C-ABI entry points for the denoise step, the IPA layer and the reverse sampling loop,
 // plus library plumbing (version, last error, device probe).
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -19,14 +20,14 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- cross-stream ordering guard (common.h StreamOrder) --------------------------------------------------------------------------
-// Why it exists (profiles/r04_two_queue.md): with two library pipelines on two streams of one process, heads_finish_kernel - a small
-// elementwise kernel (sqrt, sincos, IEEE divisions) - computed wrong values in lanes 48-63 of a wave in 1-17 % of the steps, from inputs
-// that it had loaded correctly (in-kernel dump: loaded registers right early and late, a derived product wrong), only while kernels of
-// the bf16x6 GEMM family of the OTHER stream were running beside it, never alone, never beside the f32-MFMA kernels, and not
-// reproducible with stand-alone MFMA / transcendental / copy aggressors (tools/two_queue_*_probe.hip).  Nothing in the library's own
-// state is shared between two calls; the cause sits below this library.  Until it is understood the library does not let its own
-// kernels from two streams overlap: one state per device = {last stream, event}.
+// ---- cross-stream ordering guard (common.h StreamOrder), OFF by default since round 6 ---------------------------------------------
+// History (profiles/r04_two_queue.md, r05_two_queue.md): with two library pipelines on two streams of one process, heads_finish_kernel and
+// reverse_update_philox_kernel - small VALU-only kernels - computed wrong values in lanes 48-63 while bf16 x 6 GEMM work-groups of the OTHER
+// stream were resident.  Round 6 found the cause (profiles/r06_lanes_48_63.md, tools/hwtests/pkmul_two_streams.hip): hipcc's SLP vectoriser
+// had packed their scalar code into v_pk_{mul,fma}_f32 ... op_sel:[0,1], a form gfx950 miscomputes in lanes 48-63 while f16 / bf16 MFMAs of
+// ANY wave - another kernel's included - are in flight on the SIMD.  The form is gone from every kernel of the library (Makefile NOSLP,
+// tools/isa_hazard_lint.py), two pipelines on two streams measure bitwise the sequential runs with the guard off, so the guard is now an
+// opt-in (diffab_set_stream_guard(1)): one state per device = {last stream, event}.
 namespace {
 struct OrderState {
   std::recursive_mutex mu;
@@ -36,14 +37,15 @@ struct OrderState {
   int depth = 0;
 };
 OrderState g_order[32];
-bool g_order_on = true;
+std::atomic<bool> g_order_on{false};
 }  // namespace
 
-StreamOrder::StreamOrder(void* stream) : dev_(0) {
+StreamOrder::StreamOrder(void* stream) : dev_(-1) {
+  if (!g_order_on.load(std::memory_order_relaxed)) return;  // guard off (default): nothing is held, calls of host threads do not serialise
   if (hipGetDevice(&dev_) != hipSuccess) dev_ = 0;
   OrderState& o = g_order[dev_ & 31];
   o.mu.lock();
-  if (o.depth++ > 0 || !g_order_on) return;  // an entry point called from another entry point: already ordered
+  if (o.depth++ > 0) return;  // an entry point called from another entry point: already ordered
   hipStream_t st = as_stream(stream);
   if (o.have && o.last != st) {
     // everything enqueued on the previous stream so far (the library's last call, and whatever the caller put behind it) comes first
@@ -55,11 +57,12 @@ StreamOrder::StreamOrder(void* stream) : dev_(0) {
   o.have = true;
 }
 StreamOrder::~StreamOrder() {
+  if (dev_ < 0) return;
   OrderState& o = g_order[dev_ & 31];
   --o.depth;
   o.mu.unlock();
 }
-void set_stream_order(bool on) { g_order_on = on; }
+void set_stream_order(bool on) { g_order_on.store(on); }
 
 // ---- opt-in launch timer for the dominant kernel (bench.py's roofline leg) ---------------------------------
 // When enabled, the attention-kernel launchers bracket each launch with a hipEvent pair recorded on the launch

@@ -438,131 +438,6 @@ __global__ void count_mask_kernel(const uint8_t* __restrict__ gm, const uint8_t*
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
-// d L / d v from G0 = d L / d O0 for O0 = O_t E, E = exp(hat(v)) = I + a S + b S^2 (diffab_pytorch.py:594-596, so3.py:219-237)
-__device__ __forceinline__ void rotvec_head_bwd(const float (&G0)[9], const float* __restrict__ Ot, const float* __restrict__ v3,
-                                                float* __restrict__ dv3, float* __restrict__ dOt = nullptr) {
-  if (dOt != nullptr) {  // d L / d O_t = G0 E^T (the caller asked for frame gradients)
-    float E[9];
-    so3_rotvec_to_matrix(v3[0], v3[1], v3[2], E);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dOt[r * 3 + c] = (G0[r * 3 + 0] * E[c * 3 + 0] + G0[r * 3 + 1] * E[c * 3 + 1]) + G0[r * 3 + 2] * E[c * 3 + 2];
-  }
-  // G = dL/dE = O_t^T G0
-  float G[9];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float s = 0.f;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) s += Ot[r * 3 + a] * G0[r * 3 + b];
-      G[a * 3 + b] = s;
-    }
-  // S = hat(v), n = |v|, a = sin n / n, b = (1 - cos n) / n^2
-  const float vx = v3[0], vy = v3[1], vz = v3[2];
-  const float n = sqrtf(vx * vx + vy * vy + vz * vz);
-  float sn, cn;
-  sincosf(n, &sn, &cn);
-  const float a = sn / n, b = (1.0f - cn) / (n * n);
-  const float da = (cn - a) / n, db = (a - 2.0f * b) / n;  // derivatives with respect to n
-  float S[9], S2[9];
-  so3_hat(vx, vy, vz, S);
-  mat3_mul(S, S, S2);
-  float gS = 0.f, gS2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { gS += G[k] * S[k]; gS2 += G[k] * S2[k]; }
-  // <G, dS S + S dS> = <G S^T + S^T G, dS>;   dS = hat(dv)
-  float H[9], ST[9], T1[9], T2[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) ST[r * 3 + c] = S[c * 3 + r];
-  mat3_mul(G, ST, T1);
-  mat3_mul(ST, G, T2);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) H[k] = a * G[k] + b * (T1[k] + T2[k]);
-  const float vv[3] = {vx, vy, vz};
-  // <H, hat(e_x)> = H21 - H12, <H, hat(e_y)> = H02 - H20, <H, hat(e_z)> = H10 - H01
-  const float hk[3] = {H[7] - H[5], H[2] - H[6], H[3] - H[1]};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) dv3[k] = hk[k] + (da * gS + db * gS2) * vv[k] / n;
-}
-
-__global__ void losses_bwd_kernel(const float* __restrict__ post, const float* __restrict__ tpost, const float* __restrict__ eps,
-                                  const float* __restrict__ teps, const float* __restrict__ O0, const float* __restrict__ tO,
-                                  const float* __restrict__ O_t, const float* __restrict__ v, const uint8_t* __restrict__ gm,
-                                  const uint8_t* __restrict__ rm, const float* __restrict__ count, const float* __restrict__ up, int V,
-                                  int64_t rows, float* __restrict__ d_logits, float* __restrict__ d_eps, float* __restrict__ d_v) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i >= rows) return;
-  const float g_seq = up[0], g_x = up[1], g_o = up[2];  // upstream gradients of the three losses
-  const bool m = gm[i] && rm[i];
-  const float invN = 1.0f / count[0];
-  // KL(q || p) with p = softmax(logits): dL/dlogit_v = (p_v sum_u q_u - q_v) / N      (kl_div(log p, q), :857-859)
-  float qs = 0.f;
-  for (int c = 0; c < V; ++c) qs += tpost[i * V + c] > 0.0f ? tpost[i * V + c] : 0.0f;
-  for (int c = 0; c < V; ++c) {
-    const float q = tpost[i * V + c] > 0.0f ? tpost[i * V + c] : 0.0f;
-    d_logits[i * V + c] = m ? g_seq * invN * (post[i * V + c] * qs - q) : 0.0f;
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) d_eps[i * 3 + c] = m ? g_x * invN * 2.0f * (eps[i * 3 + c] - teps[i * 3 + c]) : 0.0f;  // MSE (:860-862)
-  if (!m) {
-    d_v[i * 3] = d_v[i * 3 + 1] = d_v[i * 3 + 2] = 0.0f;
-    return;
-  }
-  // orientation loss sum_jk (sum_r O0[r][j] tO[r][k] - delta_jk)^2   (:620-625)  -> G0 = dL/dO0
-  float D[9], G0[9];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float d = 0.f;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) d += O0[i * 9 + r * 3 + j] * tO[i * 9 + r * 3 + k];
-      D[j * 3 + k] = d - (j == k ? 1.0f : 0.0f);
-    }
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) s += 2.0f * D[j * 3 + k] * tO[i * 9 + r * 3 + k];
-      G0[r * 3 + j] = g_o * invN * s;
-    }
-  rotvec_head_bwd(G0, O_t + i * 9, v + i * 3, d_v + i * 3);
-}
-
-// Denoiser outputs -> head pre-activations for ARBITRARY upstream cotangents (diffab_denoise_step_bwd): d eps-hat passes through,
-// d posterior goes through the softmax of sequence_denoising (:555, :599), d O0-hat through O0 = O_t exp(hat(v)) (:594-596).
-// Null cotangent pointers stand for zeros.
-__global__ void heads_cotangent_kernel(const float* __restrict__ post, const float* __restrict__ c_post, const float* __restrict__ c_eps,
-                                       const float* __restrict__ c_O0, const float* __restrict__ O_t, const float* __restrict__ v, int V,
-                                       int64_t rows, float* __restrict__ d_logits, float* __restrict__ d_eps, float* __restrict__ d_v,
-                                       float* __restrict__ d_Ot) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i >= rows) return;
-  float dot = 0.f;
-  if (c_post)
-    for (int c = 0; c < V; ++c) dot += post[i * V + c] * c_post[i * V + c];
-  for (int c = 0; c < V; ++c) d_logits[i * V + c] = c_post ? post[i * V + c] * (c_post[i * V + c] - dot) : 0.0f;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) d_eps[i * 3 + c] = c_eps ? c_eps[i * 3 + c] : 0.0f;
-  if (c_O0 == nullptr) {
-    d_v[i * 3] = d_v[i * 3 + 1] = d_v[i * 3 + 2] = 0.0f;
-    if (d_Ot)
-      for (int k = 0; k < 9; ++k) d_Ot[i * 9 + k] = 0.0f;
-    return;
-  }
-  float G0[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) G0[k] = c_O0[i * 9 + k];
-  rotvec_head_bwd(G0, O_t + i * 9, v + i * 3, d_v + i * 3, d_Ot ? d_Ot + i * 9 : nullptr);  // d O_t is WRITTEN here, the layers add to it
-}
-
 // ------------------------------------------------------------------ attention backward in two atomic-free passes
 // Pass 1, one work-group per (patch, query residue i): recompute the row's softmax from the saved projections, form dA and
 // the logit gradient, write this row's own gradients (q_s, q points, de[i], and dog = d o_g) directly, and store the
@@ -1674,71 +1549,6 @@ __global__ void ipa_dog_kernel(const float* __restrict__ feat, const float* __re
   for (int k = 0; k < 3; ++k) dogbuf[row * n_og + hp * 3 + k] = dl[0] * Rr[0 * 3 + k] + dl[1] * Rr[1 * 3 + k] + dl[2] * Rr[2 * 3 + k];
 }
 
-// Gradients with respect to the FRAME (R_i, t_i) of residue i through one IPA layer (reference: euclidean_transform /
-// inverse_euclidean_transform are plain differentiable torch code, diffab_pytorch.py:315-336, used at :410-413 and :453).  One
-// work-group per residue row.  Two contributions, both accumulated (+=) into dR[row][9], dt[row][3]:
-//  (a) local -> global of the q / k / v points, g = p R + t (:324): with dg = d loss / d g (dproj, BEFORE points_bwd_kernel rewrites it),
-//      d t += sum_points dg,  d R[k][c] += sum_points p[k] dg[c],  p = (g - t) R^T recomputed from the stored global points;
-//  (b) global -> local of the attention-weighted value points, o_l = (o_g - t) R^T (:336) and o_n = |o_l| (:454): with
-//      dl = d o_l + d o_n o_l / o_n,  d t -= dl R,  d R[c][k] += dl[c] (o_g - t)[k],  (o_g - t) = o_l R.
-// p and (o_g - t) are recovered through R^T = R^-1: the frames on this path are rotations (to fp32 rounding), as in every caller.
-__global__ __launch_bounds__(256) void ipa_frames_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ dproj, int NP, int pt_col0,
-                                                             int n_pts, const float* __restrict__ feat, const float* __restrict__ dfeat, int F,
-                                                             int ol_col0, int on_col0, int n_vpts, const float* __restrict__ R,
-                                                             const float* __restrict__ t, float* __restrict__ dR, float* __restrict__ dt) {
-  const int64_t row = blockIdx.x;
-  const float* Rr = R + row * 9;
-  const float r0 = Rr[0], r1 = Rr[1], r2 = Rr[2], r3 = Rr[3], r4 = Rr[4], r5 = Rr[5], r6 = Rr[6], r7 = Rr[7], r8 = Rr[8];
-  const float tx = t[row * 3], ty = t[row * 3 + 1], tz = t[row * 3 + 2];
-  float acc[12];  // dR row-major, then dt
-#pragma unroll
-  for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-  for (int pt = threadIdx.x; pt < n_pts; pt += blockDim.x) {
-    const float* g = proj + row * NP + pt_col0 + pt * 3;
-    const float* dg = dproj + row * NP + pt_col0 + pt * 3;
-    const float gx = g[0] - tx, gy = g[1] - ty, gz = g[2] - tz;
-    const float p[3] = {gx * r0 + gy * r1 + gz * r2, gx * r3 + gy * r4 + gz * r5, gx * r6 + gy * r7 + gz * r8};  // (g - t) R^T
-    const float d[3] = {dg[0], dg[1], dg[2]};
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc[k * 3 + c] += p[k] * d[c];
-    acc[9] += d[0]; acc[10] += d[1]; acc[11] += d[2];
-  }
-  for (int vp = threadIdx.x; vp < n_vpts; vp += blockDim.x) {
-    const float* ol = feat + row * F + ol_col0 + vp * 3;
-    const float* dol = dfeat + row * F + ol_col0 + vp * 3;
-    const float on = feat[row * F + on_col0 + vp], don = dfeat[row * F + on_col0 + vp];
-    float dl[3], og[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dl[c] = dol[c] + (on > 0.0f ? don * ol[c] / on : 0.0f);
-    og[0] = ol[0] * r0 + ol[1] * r3 + ol[2] * r6;  // (o_g - t) = o_l R
-    og[1] = ol[0] * r1 + ol[1] * r4 + ol[2] * r7;
-    og[2] = ol[0] * r2 + ol[1] * r5 + ol[2] * r8;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc[c * 3 + k] += dl[c] * og[k];
-    acc[9] -= dl[0] * r0 + dl[1] * r3 + dl[2] * r6;  // d t -= dl R
-    acc[10] -= dl[0] * r1 + dl[1] * r4 + dl[2] * r7;
-    acc[11] -= dl[0] * r2 + dl[1] * r5 + dl[2] * r8;
-  }
-  __shared__ float red[4][12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    float v = acc[k];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 12) {
-    const int k = threadIdx.x;
-    const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-    if (k < 9) { if (dR) dR[row * 9 + k] += v; }
-    else if (dt) dt[row * 3 + (k - 9)] += v;
-  }
-}
-
 // gradient w.r.t. global points -> local points, in place: g = p R + t  =>  dp[k] = sum_c dg[c] R[k][c]
 __global__ void points_bwd_kernel(float* __restrict__ dproj, int ld, int col0, int n_pts, const float* __restrict__ R, int64_t rows) {
   const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -1877,13 +1687,13 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
   if (mode == BWD_LOSSES) {
     hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
     DIFFAB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(losses_bwd_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, true_post, eps_hat, true_eps, O0_hat,
-                       true_O0, O_t, tp.vbuf, gm, rm, cnt, upstream3, V, static_cast<int64_t>(rows), d_logits, d_eps, d_v);
-    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_losses_bwd(post_hat, true_post, eps_hat, true_eps, O0_hat, true_O0, O_t, tp.vbuf, gm, rm, cnt, upstream3, V,
+                                   static_cast<int64_t>(rows), d_logits, d_eps, d_v, st))
+      return rc;
   } else if (mode == BWD_COTANGENTS) {
-    hipLaunchKernelGGL(heads_cotangent_kernel, dim3((rows + 127) / 128), dim3(128), 0, st, post_hat, cot_post, cot_eps, cot_O0, O_t, tp.vbuf, V,
-                       static_cast<int64_t>(rows), d_logits, d_eps, d_v, d_O_t);
-    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_heads_cotangent(post_hat, cot_post, cot_eps, cot_O0, O_t, tp.vbuf, V, static_cast<int64_t>(rows), d_logits, d_eps, d_v,
+                                        d_O_t, st))
+      return rc;
   } else {
     DIFFAB_HIP_CHECK(hipMemcpyAsync(dcur, layer_dy, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));
   }
@@ -2008,9 +1818,9 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     }
     DIFFAB_LAUNCH_CHECK();
     if (d_x_t || d_O_t) {  // frame gradients of this layer, from the GLOBAL point gradients (before points_bwd_kernel rewrites dproj)
-      hipLaunchKernelGGL(ipa_frames_bwd_kernel, dim3(rows), dim3(256), 0, st, proj, dproj, NP, 3 * H * DS, 2 * H * PQ + H * PV, feat, dfeat, F,
-                         H * DS + H * C, H * DS + H * C + H * PV * 3, H * PV, O_t, x_t, d_O_t, d_x_t);
-      DIFFAB_LAUNCH_CHECK();
+      if (int rc = launch_ipa_frames_bwd(proj, dproj, NP, 3 * H * DS, 2 * H * PQ + H * PV, feat, dfeat, F, H * DS + H * C,
+                                         H * DS + H * C + H * PV * 3, H * PV, O_t, x_t, d_O_t, d_x_t, rows, st))
+        return rc;
     }
     // global-point gradients -> local-point gradients (three point blocks)
     {  // the three point blocks (q, k, v) are adjacent columns of dproj: one launch over all of a row's points

@@ -399,179 +399,6 @@ __global__ void points_to_global_fast_kernel(float* __restrict__ proj, const flo
   qv[2] = (x * Rr[2] + y * Rr[5] + z * Rr[8]) + t[r * 3 + 2];
 }
 
-// ================================================================== six projections + local->global frames in one kernel
-// proj[:, 0:1344] = x [Wq_s; Wk_s; Wv_s; Wq_p; Wk_p; Wv_p]^T with the three point blocks mapped to the global frame
-// (x R + t, row-vector convention of diffab_pytorch.py:324) before they are stored.
-//
-// x-stationary: a work-group owns 128 rows of x for the whole kernel and every wave keeps its 32 x 128 slab as MFMA A fragments
-// in 64 VGPRs, so x is read from HBM exactly once and the LDS only double-buffers 96-column blocks of the weights (14 blocks).
-// Inside a block the MFMA n index is permuted: tile tt (0..2), lane column j holds output column 3 j + tt of the wave's 48, so a
-// lane ends up with three CONSECUTIVE output columns per row - a whole (x, y, z) point in the point blocks, and a 12-byte
-// store (16 lanes = 192 contiguous bytes) everywhere.  The previous block's epilogue is issued between the MFMAs of the
-// current one (two accumulator sets), which keeps the matrix pipe fed across the one barrier per block.
-constexpr int PJB = 96, PJLD = 132, PJROWS = 128, PJNB = ANP / PJB;  // 14 blocks
-static_assert(ANP % PJB == 0 && OFF_GQ % PJB == 0, "projection blocks must tile the scalar and point column ranges");
-struct __attribute__((packed, aligned(4))) pj_f3 { float x, y, z; };
-
-struct PjW {  // the six weight matrices, by value (kept in SGPRs)
-  const float *w0, *w1, *w2, *w3, *w4, *w5;
-};
-struct PjCtx {  // per-thread constants of proj_frames_kernel
-  float* PW;
-  float* Rt;
-  float* ybase;
-  int tid, l15, g, rw, cw, m0, M;
-};
-
-// weight staging: thread -> (LDS row l = 16 r + tid / 32, float4 column tid % 32); LDS row l = 48 cw' + 16 tt + j holds output
-// column 48 cw' + 3 j + tt of the block.  The six weight pointers stay in SGPRs (selects, no indexed kernarg loads).
-__device__ __forceinline__ void pj_load_w(const PjCtx& c, const PjW w, int blk, f32x4 (&wreg)[6]) {
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const int l = 16 * r + (c.tid >> 5), c4 = c.tid & 31;
-    const int cwl = l / 48, rem = l % 48, tt = rem >> 4, j = rem & 15;
-    const int gc = PJB * blk + 48 * cwl + 3 * j + tt;
-    const float* Wp;
-    int row;
-    if (gc < OFF_GQ) {
-      Wp = gc < OFF_KS ? w.w0 : (gc < OFF_VS ? w.w1 : w.w2);
-      row = gc & 255;
-    } else {
-      Wp = gc < OFF_GK ? w.w3 : (gc < OFF_GV ? w.w4 : w.w5);
-      row = gc - (gc < OFF_GK ? OFF_GQ : (gc < OFF_GV ? OFF_GK : OFF_GV));
-    }
-    wreg[r] = *reinterpret_cast<const f32x4*>(Wp + row * 128 + 4 * c4);
-  }
-}
-__device__ __forceinline__ void pj_store_w(const PjCtx& c, int buf, const f32x4 (&wreg)[6]) {
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const int l = 16 * r + (c.tid >> 5), c4 = c.tid & 31;
-    *reinterpret_cast<f32x4*>(&c.PW[(buf * PJB + l) * PJLD + 4 * c4]) = wreg[r];
-  }
-}
-// one (mt, r) slice of a finished block: 3 consecutive columns of one row per lane
-template <bool FULL, bool FRAMES>
-__device__ __forceinline__ void pj_epilogue_piece(const PjCtx& c, const f32x4 (&acc)[2][3], int blk, int piece) {
-  const int mt = piece >> 2, r = piece & 3;
-  const int lrow = 32 * c.rw + 16 * mt + 4 * c.g + r;
-  float vx = acc[mt][0][r], vy = acc[mt][1][r], vz = acc[mt][2][r];
-  if (FRAMES) {
-    const f32x4* F = reinterpret_cast<const f32x4*>(c.Rt + lrow * 12);
-    const f32x4 f0 = F[0], f1 = F[1], f2 = F[2];  // R row-major 0..8, t 9..11
-    const float ox = (vx * f0[0] + vy * f0[3] + vz * f1[2]) + f2[1];
-    const float oy = (vx * f0[1] + vy * f1[0] + vz * f1[3]) + f2[2];
-    const float oz = (vx * f0[2] + vy * f1[1] + vz * f2[0]) + f2[3];
-    vx = ox; vy = oy; vz = oz;
-  }
-  if (FULL || c.m0 + lrow < c.M) {
-    pj_f3 o{vx, vy, vz};
-    *reinterpret_cast<pj_f3*>(c.ybase + (16 * mt + r) * ANP + PJB * blk) = o;
-  }
-}
-template <bool FULL, bool HAVE_PREV, bool PREV_FRAMES>
-__device__ __forceinline__ void pj_run_block(const PjCtx& c, const PjW w, const f32x4 (&a)[2][8], f32x4 (&wreg)[6], f32x4 (&cur)[2][3],
-                                             const f32x4 (&prev)[2][3], int blk) {
-  if (blk + 1 < PJNB) pj_load_w(c, w, blk + 1, wreg);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int tt = 0; tt < 3; ++tt) cur[mt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* Wl = c.PW + ((blk & 1) * PJB + 48 * c.cw + c.l15) * PJLD + 4 * c.g;
-  f32x4 b[2][3];
-#pragma unroll
-  for (int tt = 0; tt < 3; ++tt) b[0][tt] = *reinterpret_cast<const f32x4*>(Wl + 16 * tt * PJLD);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    if (q + 1 < 8) {
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) b[(q + 1) & 1][tt] = *reinterpret_cast<const f32x4*>(Wl + 16 * tt * PJLD + 16 * (q + 1));
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt)
-          cur[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q][s], b[q & 1][tt][s], cur[mt][tt], 0, 0, 0);
-    // The next block's weights go to LDS (q = 1) BEFORE this block issues any global store (q = 2..7): on gfx9 a wait for loads
-    // with stores in flight degenerates to vmcnt(0), i.e. to waiting for the L2 acknowledgement of the newest store (measured:
-    // 8 % of the kernel when the wait sat right behind the last store of the block).
-    if (q == 1 && blk + 1 < PJNB) pj_store_w(c, (blk + 1) & 1, wreg);
-    if (HAVE_PREV) {  // 8 epilogue slices of the previous block spread over q = 2..7
-      if (q == 2) { pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 0); pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 1); }
-      if (q == 3) { pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 2); pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, 3); }
-      if (q >= 4) pj_epilogue_piece<FULL, PREV_FRAMES>(c, prev, blk - 1, q);
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep each slice's stores where they are (the scheduler otherwise sinks all 8 to the barrier)
-  }
-  __syncthreads();
-}
-
-template <bool FULL>  // FULL: M is a multiple of 128, no row guards
-__global__ __launch_bounds__(512) void proj_frames_kernel(const float* __restrict__ X, const float* __restrict__ W0,
-                                                          const float* __restrict__ W1, const float* __restrict__ W2,
-                                                          const float* __restrict__ W3, const float* __restrict__ W4,
-                                                          const float* __restrict__ W5, const float* __restrict__ R,
-                                                          const float* __restrict__ t, float* __restrict__ Y, int M) {
-  extern __shared__ __attribute__((aligned(16))) float PW[];  // [2][PJB][PJLD] weights, then [PJROWS][12] frames
-  PjCtx c;
-  PjW w;
-  {  // pin the six weight pointers in SGPRs: without this the selects in pj_load_w become per-lane indexed loads of the
-     // pointer itself (a dependent memory round trip in front of every weight load)
-    const float *w0 = W0, *w1 = W1, *w2 = W2, *w3 = W3, *w4 = W4, *w5 = W5;
-    asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5));
-    w = PjW{w0, w1, w2, w3, w4, w5};
-  }
-  c.PW = PW;
-  c.Rt = PW + 2 * PJB * PJLD;
-  c.tid = threadIdx.x;
-  const int lane = c.tid & 63, wv = c.tid >> 6;
-  c.l15 = lane & 15; c.g = lane >> 4; c.rw = wv & 3; c.cw = wv >> 2;
-  c.m0 = blockIdx.x * PJROWS;
-  c.M = M;
-  c.ybase = Y + static_cast<int64_t>(c.m0 + 32 * c.rw + 4 * c.g) * ANP + 48 * c.cw + 3 * c.l15;
-
-  f32x4 wreg[6];
-  pj_load_w(c, w, 0, wreg);
-  // A fragments: a[mt][q][s] = x[m0 + 32 rw + 16 mt + l15][16 q + 4 g + s]
-  f32x4 a[2][8];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int row = c.m0 + 32 * c.rw + 16 * mt + c.l15;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (FULL || row < M) v = *reinterpret_cast<const f32x4*>(X + static_cast<int64_t>(row) * 128 + 16 * q + 4 * c.g);
-      a[mt][q] = v;
-    }
-  }
-  for (int idx = c.tid; idx < PJROWS * 12; idx += 512) {
-    const int row = idx / 12, cc = idx % 12, gr = c.m0 + row;
-    float v = 0.0f;
-    if (FULL || gr < M) v = cc < 9 ? R[static_cast<int64_t>(gr) * 9 + cc] : t[static_cast<int64_t>(gr) * 3 + (cc - 9)];
-    c.Rt[idx] = v;
-  }
-  pj_store_w(c, 0, wreg);
-  __syncthreads();
-
-  f32x4 accA[2][3], accB[2][3];
-  constexpr int FIRST_PT = OFF_GQ / PJB;  // 8: blocks 0..7 are the scalar q/k/v columns, 8..13 the point columns
-  static_assert(FIRST_PT % 2 == 0 && PJNB % 2 == 0, "block schedule below assumes even counts");
-  pj_run_block<FULL, false, false>(c, w, a, wreg, accA, accB, 0);
-  for (int blk = 1; blk < FIRST_PT; blk += 2) {  // previous block is a scalar block
-    pj_run_block<FULL, true, false>(c, w, a, wreg, accB, accA, blk);
-    pj_run_block<FULL, true, false>(c, w, a, wreg, accA, accB, blk + 1);
-  }
-  for (int blk = FIRST_PT + 1; blk + 1 < PJNB; blk += 2) {  // previous block is a point block
-    pj_run_block<FULL, true, true>(c, w, a, wreg, accB, accA, blk);
-    pj_run_block<FULL, true, true>(c, w, a, wreg, accA, accB, blk + 1);
-  }
-  pj_run_block<FULL, true, true>(c, w, a, wreg, accB, accA, PJNB - 1);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) pj_epilogue_piece<FULL, true>(c, accB, PJNB - 1, q);
-}
-
 // ================================================================== folded concatenations of the denoiser (D = 128)
 // cat[res_ctx, E[s]] W0^T + b0 = res_ctx W0[:, :D]^T + (E[s] W0[:, D:]^T + b0): the second term depends only on the residue type s
 // (25 rows), so it becomes a bias table indexed by seq_t and the 2D-wide concatenation is never materialised
@@ -800,18 +627,7 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   } else if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {
-    const size_t pj_lds = (2 * PJB * PJLD + PJROWS * 12) * sizeof(float);
-#define PROJ_LAUNCH(FULL_)                                                                                                        \
-  do {                                                                                                                            \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_kernel<FULL_>),                                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pj_lds)));                  \
-    hipLaunchKernelGGL((proj_frames_kernel<FULL_>), dim3((rows + PJROWS - 1) / PJROWS), dim3(512), pj_lds, st, x, segs.W[0],      \
-                       segs.W[1], segs.W[2], segs.W[3], segs.W[4], segs.W[5], R, t, proj, rows);                                  \
-  } while (0)
-    if (rows % PJROWS == 0) PROJ_LAUNCH(true);
-    else PROJ_LAUNCH(false);
-#undef PROJ_LAUNCH
-    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_proj_frames_f32(x, segs.W, R, t, proj, rows, st)) return rc;  // noslp_kernels.hip
   }
   // Training tape (sp_keep != nullptr, K = 64 / 128): the attention as three launches that leave the probabilities and the squared point
   // distances on the tape for the backward (attention_split.hip); ws has no tail there.  Everything else: the fused kernel.

@@ -244,27 +244,6 @@ int ipa_layer_generic(const diffab_dims* d, const diffab_ipa_layer_weights* w, c
   return launch_linear_generic(feat, F, w->w_out, w->b_out, y, D, rows, D, F, false, st);
 }
 
-// ------------------------------------------------------------------ heads epilogue
-// O0 = O_t @ exp(hat(v))  (diffab_pytorch.py:594-596);  posterior = softmax(logits)  (:555)
-__global__ void heads_finish_kernel(const float* __restrict__ v, const float* __restrict__ O_t, const float* __restrict__ logits, int V,
-                                    int64_t rows, float* __restrict__ O0, float* __restrict__ post) {
-  const int64_t r = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (r >= rows) return;
-  float ex[9], o[9], res[9];
-  so3_rotvec_to_matrix(v[r * 3], v[r * 3 + 1], v[r * 3 + 2], ex);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) o[k] = O_t[r * 9 + k];
-  mat3_mul(o, ex, res);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) O0[r * 9 + k] = res[k];
-  float m = -INFINITY;
-  for (int c = 0; c < V; ++c) m = fmaxf(m, logits[r * V + c]);
-  float s = 0.f;
-  for (int c = 0; c < V; ++c) s += expf(logits[r * V + c] - m);
-  const float inv = 1.0f / s;
-  for (int c = 0; c < V; ++c) post[r * V + c] = expf(logits[r * V + c] - m) * inv;
-}
-
 int launch_embed_concat(const float* res_ctx, const float* emb, const int64_t* seq, int D, int64_t rows, float* out, hipStream_t st) {
   hipLaunchKernelGGL(embed_concat_kernel, dim3(static_cast<unsigned>(rows)), dim3(128), 0, st, res_ctx, emb, seq, D, rows, out);
   DIFFAB_LAUNCH_CHECK();
@@ -272,11 +251,6 @@ int launch_embed_concat(const float* res_ctx, const float* emb, const int64_t* s
 }
 int launch_beta_concat(const float* h, const float* beta, int D, int K, int64_t rows, float* out, hipStream_t st) {
   hipLaunchKernelGGL(beta_concat_kernel, dim3(static_cast<unsigned>(rows)), dim3(128), 0, st, h, beta, D, K, rows, out);
-  DIFFAB_LAUNCH_CHECK();
-  return DIFFAB_OK;
-}
-int launch_heads_finish(const float* v, const float* O_t, const float* logits, int V, int64_t rows, float* O0, float* post, hipStream_t st) {
-  hipLaunchKernelGGL(heads_finish_kernel, dim3(static_cast<unsigned>((rows + 127) / 128)), dim3(128), 0, st, v, O_t, logits, V, rows, O0, post);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

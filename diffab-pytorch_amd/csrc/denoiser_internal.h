@@ -13,6 +13,16 @@ int ipa_layer_generic(const diffab_dims* d, const diffab_ipa_layer_weights* w, c
 int launch_embed_concat(const float* res_ctx, const float* emb, const int64_t* seq, int D, int64_t rows, float* out, hipStream_t st);
 int launch_beta_concat(const float* h, const float* beta, int D, int K, int64_t rows, float* out, hipStream_t st);
 int launch_heads_finish(const float* v, const float* O_t, const float* logits, int V, int64_t rows, float* O0, float* post, hipStream_t st);
+// noslp_kernels.hip (compiled without the SLP vectoriser: no packed fp32 arithmetic from scalar code)
+int launch_proj_frames_f32(const float* x, const float* const* W6, const float* R, const float* t, float* proj, int rows, hipStream_t st);
+int launch_losses_bwd(const float* post, const float* tpost, const float* eps, const float* teps, const float* O0, const float* tO,
+                      const float* O_t, const float* v, const uint8_t* gm, const uint8_t* rm, const float* count, const float* up, int V,
+                      int64_t rows, float* d_logits, float* d_eps, float* d_v, hipStream_t st);
+int launch_heads_cotangent(const float* post, const float* c_post, const float* c_eps, const float* c_O0, const float* O_t, const float* v,
+                           int V, int64_t rows, float* d_logits, float* d_eps, float* d_v, float* d_Ot, hipStream_t st);
+int launch_ipa_frames_bwd(const float* proj, const float* dproj, int NP, int pt_col0, int n_pts, const float* feat, const float* dfeat, int F,
+                          int ol_col0, int on_col0, int n_vpts, const float* R, const float* t, float* dR, float* dt, int rows,
+                          hipStream_t st);
 
 // MFMA path for the benchmark geometry (D=128, C=64, H=8, DS=32, PQ=PV=8, K % 16 == 0)
 bool fast_path_supported(const diffab_dims* d);

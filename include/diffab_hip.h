@@ -17,7 +17,7 @@
  *     (torch.bool);
  *   - the caller owns every buffer including the workspace (size from the
  *     matching *_workspace_bytes query); kernels are enqueued on `stream` and
- *     never synchronise on the host; no hidden global state beyond the stream guard below; the
+ *     never synchronise on the host; no hidden global state beyond the opt-in stream guard below; the
  *     library never reads the environment.  Two DIAGNOSTIC entry points keep
  *     process-global state and are off by default: diffab_kernel_timer_enable/read
  *     (an event list) and diffab_debug_set_attn_stamps / diffab_debug_set_module_stamps / _stagger (stamp-buffer pointers, two ints);
@@ -25,16 +25,20 @@
  *     DIFFAB_FLAG_GRAPH_SAMPLER makes diffab_sample_loop drain a private stream
  *     before it returns.  (Kernel variants that were measured and not adopted, the environment
  *     switches used to A/B them and the timing-ablation hooks are patches under experiments/.)
- *   - Streams: calls on ONE stream are ordered by the stream, as usual.  Calls on DIFFERENT streams are additionally serialised on
- *     the device by the library itself: before a call enqueues on stream B, everything enqueued so far on the stream of the library's
- *     previous call (same device) is ordered in front of it (hipEventRecord + hipStreamWaitEvent; no host synchronisation; one mutex
- *     per device, so concurrent host threads are safe).  Reason, measured on MI355X / ROCm 7.2 (profiles/r04_two_queue.md): while
- *     kernels of a second library pipeline ran on another hardware queue, a small elementwise kernel computed wrong values in lanes
- *     48-63 of some waves from correctly loaded inputs; no state of this library is shared between the two calls and stand-alone
- *     probes do not reproduce it, so the library guards instead of guessing.  A caller that keeps to one stream per device pays a
- *     pointer compare.  Consequences: a stream handed to the library must stay alive until the library's next call on that device
- *     has been made; the guard does not cover the caller's OWN kernels on other streams; diffab_set_stream_guard(0) switches it off
- *     (e.g. while the caller captures library calls into a hipGraph from a stream other than the last one used).
+ *   - Streams: calls on ONE stream are ordered by the stream, as usual; calls on DIFFERENT streams are independent and may overlap on
+ *     the device (no state of the library is shared between two calls).  History: rounds 3-5 saw a small elementwise kernel compute wrong
+ *     values in lanes 48-63 while kernels of a second library pipeline ran on another stream, and serialised the library's calls across
+ *     streams by default.  Round 6 found the cause (profiles/r06_lanes_48_63.md; reproducer tools/hwtests/pkmul_two_streams.hip): gfx950
+ *     returns a wrong low result in lanes 48-63 for v_pk_{mul,add,fma}_f32 ... op_sel:[0,1] while f16 / bf16 MFMAs of ANY wave on the
+ *     SIMD - another kernel's included - are in flight, and hipcc's SLP vectoriser had formed that instruction in 14 VALU-only kernels.
+ *     No kernel of the library contains the form any more (enforced at build time and by tests/test_isa_lint.py), two pipelines on two
+ *     streams are bitwise the sequential runs, and the ordering guard is OFF by default.  diffab_set_stream_guard(1) switches it on:
+ *     before a call enqueues on stream B, everything enqueued so far on the stream of the library's previous call (same device) is
+ *     ordered in front of it (hipEventRecord + hipStreamWaitEvent; no host synchronisation; one mutex per device).  With the guard on,
+ *     a stream handed to the library must stay alive until the library's next call on that device has been made, and library calls must
+ *     not be captured into a hipGraph from a stream other than the last one used.  NOTE for callers: the hardware behaviour applies to
+ *     YOUR kernels too - a caller's own VALU kernel holding that packed form can miscompute beside this library's f16 / bf16 MFMA
+ *     kernels on another stream (tools/isa_hazard_lint.py checks any gfx950 object file or shared library).
  *   - empty problems (a count or extent of 0) return 0 before any pointer is looked at: an empty tensor's data pointer is NULL;
  *   - return 0 on success, a negative DIFFAB_ERR_* otherwise (never throws);
  *     diffab_last_error() gives the thread's last message.
@@ -188,7 +192,7 @@ int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; pro
                                                  three-term fp16 ones - per-layer launches only.  0 = defaults. */
 int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes);
 int diffab_debug_set_module_stamps(void* device_buffer);
-/* The cross-stream ordering guard described under "Streams" above: on (default) / off, process-wide. */
+/* The cross-stream ordering guard described under "Streams" above: on / off (default since round 6), process-wide. */
 int diffab_set_stream_guard(int on);
 /* Diagnostics / accuracy tests: Y[M x 128] = X[M x Kd] W[128 x Kd]^T + bias through ONE of the two dense kernels of the MFMA path -
  * mode 0: f32-input MFMA (rowgemm128_kernel), mode 1: bf16 matrix cores, six-term split (rowgemm128_b6_kernel; scratch >=

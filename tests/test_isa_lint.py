@@ -1,5 +1,6 @@
-"""The built library must not contain the packed-fp32 form that gfx950 miscomputes next to f16/bf16 MFMAs (tools/isa_hazard_lint.py,
-profiles/r05_pk_opsel_hazard.md).  Needs the built .so and the ROCm binary utilities, no GPU."""
+"""The built library must not contain the packed-fp32 form that gfx950 miscomputes while f16/bf16 MFMAs are in flight on the SIMD - in ANY
+kernel, since the MFMA can belong to another kernel's wave (tools/isa_hazard_lint.py, profiles/r05_pk_opsel_hazard.md,
+profiles/r06_lanes_48_63.md).  Needs the built .so and the ROCm binary utilities, no GPU."""
 import os
 import sys
 
@@ -24,12 +25,13 @@ def test_lint_recognises_the_hazard_form():
 \tv_pk_mul_f32 v[92:93], v[110:111], v[92:93] op_sel:[0,1]
 """
     found = isa_hazard_lint.lint_text(text)
-    assert [(k, d) for k, _, d in found] == [("kernel_a", 1), ("kernel_a", 3)]
+    # kernel_b has no f16/bf16 MFMA of its own (dist -1): still a finding, another kernel's wave on the same SIMD can supply the MFMA
+    assert [(k, d) for k, _, d in found] == [("kernel_a", 1), ("kernel_a", 3), ("kernel_b", -1)]
 
 
 @pytest.mark.skipif(not os.path.exists(LIB) or not os.path.exists(os.path.join(isa_hazard_lint.LLVM, "llvm-objdump")),
                     reason="needs the built library and the ROCm llvm binary utilities")
-def test_built_library_has_no_op_sel_01_packed_ops_in_mfma_kernels():
+def test_built_library_has_no_op_sel_01_packed_ops_in_any_kernel():
     texts = list(isa_hazard_lint.code_objects(LIB))
     assert texts, "no gfx950 code object found in the library"
     assert sum(t.count("v_mfma") for t in texts) > 1000  # the disassembly is the real one
