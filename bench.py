@@ -136,7 +136,9 @@ def cpu_baseline(dims, sd, K, seed, budget_s=30.0):
     return {
         "value": best["residue_steps_per_s"],
         "unit": "residue-steps/s",
-        "cores": best["threads"],
+        "cores": best["threads"],  # (the contract's field name: the torch intra-op threads of the case that won, NOT the host's core count)
+        "threads": best["threads"],
+        "host_logical_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle/diffab_oracle.py (torch CPU fp32, reference formulation) on {os.cpu_count()} logical CPUs: B = 1 and 8 patches x "
                   f"K={K}; reverse-sampling steps and hot-path training steps (forward + backward); {thread_sets} threads and 1 thread; one "
@@ -232,7 +234,7 @@ def other_configs(model, dims, flags):
         _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(inp["generation_mask"]), 2024, 0, B, K, model.T,
                                           _hip.stream_ptr()), "sample_init")
         lean = {}
-        for name, fl in (("all_rows", flags), ("skip_unused_rows", flags | _hip.FLAG_SKIP_UNUSED_ROWS)):
+        for name, fl in (("all_rows", flags), ("skip_unused_rows", flags | _hip.FLAG_SKIP_UNUSED_ROWS), ("fp32_gemm", flags | _hip.FLAG_FP32_GEMM)):
             for n_ in (3, steps):  # warm-up, then timed
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -247,6 +249,10 @@ def other_configs(model, dims, flags):
         res["skip_unused_rows"] = {"patches": B, "K": K, "steps": steps, "ms_per_step_all_rows": lean["all_rows"],
                                    "ms_per_step": lean["skip_unused_rows"], "last_layer_row_tiles_run": tiles,
                                    "what": "DIFFAB_FLAG_SKIP_UNUSED_ROWS (opt-in): bitwise the same samples; not the headline"}
+        # the price of exact fp32 OPERANDS in the dense products (DIFFAB_FLAG_FP32_GEMM: f32-input MFMAs for the projections, to_out and the
+        # MLPs instead of the three-term fp16 / six-term bf16 split products; per-layer launches - the module launch holds the fp16 tiles only)
+        res["fp32_gemm_operands"] = {"patches": B, "K": K, "steps": steps, "ms_per_step": lean["fp32_gemm"], "ms_per_step_default": lean["all_rows"],
+                                     "what": "DIFFAB_FLAG_FP32_GEMM (opt-in): exact fp32 operands in every dense product; not the headline"}
         del inp, seq, x, O, ws
     except Exception as ex:  # noqa: BLE001
         res["skip_unused_rows"] = f"failed: {type(ex).__name__}: {ex}"
@@ -428,6 +434,8 @@ def main():
     ap.add_argument("--multi-launch", action="store_true",
                     help="DIFFAB_FLAG_MULTI_LAUNCH: one launch per kernel of an IPA layer instead of the patch-resident module launch the "
                          "sampler chooses at this batch size (bitwise the same samples; for profiles of the separate kernels)")
+    ap.add_argument("--attn-variant", type=int, default=0,
+                    help="developer A/B switch: diffab_debug_set_attn_variant(v) before anything runs (16 = value planes, 8 = bf16x6 dense tiles)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (tests/test_gpu_two_ranks.py); "
                          "exercises the launch contract, sharding, gather and max-over-ranks timing - NOT a scaling measurement")
@@ -491,6 +499,8 @@ def main():
     tab = model._reverse_so3().struct()
     ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
     flags = _hip.FLAG_FORCE_GENERIC if args.generic else (_hip.FLAG_MULTI_LAUNCH if args.multi_launch else 0)
+    if args.attn_variant:
+        lib.diffab_debug_set_attn_variant(args.attn_variant)
     seed = 2024
     _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gm), seed, first_patch, B, K, model.T,
                                       _hip.stream_ptr()), "sample_init")

@@ -405,6 +405,7 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
   if (mode == 0) return launch_linear(X, Kd, W, bias, Y, 128, static_cast<int>(M), 128, Kd, false, st);  // rowgemm128 / tiled f32 MFMA
   if (mode == 2) {  // fp16 x 3 (gemm_f16x3.hip): planes | 1 / scale of the 128 weight rows
     const size_t pb = (rowgemm128_h3_planes_bytes(Kd) + 255) & ~static_cast<size_t>(255);
+    DIFFAB_REQUIRE(Kd % 64 == 0, DIFFAB_ERR_ARG, "debug_linear128: mode 2 (fp16 x 3) needs Kd %% 64 == 0 (its chunks of 32 k are joined in pairs)");
     DIFFAB_REQUIRE(scratch && scratch_bytes >= pb + 512 && rowgemm128_b6_ok(X, Kd, Y, 128, static_cast<int>(M), Kd) &&
                        (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
                    DIFFAB_ERR_ARG, "debug_linear128: mode 2 needs 16-byte aligned operands and %zu bytes of scratch", pb + 512);

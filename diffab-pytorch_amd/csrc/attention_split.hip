@@ -27,11 +27,7 @@ namespace diffab {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MEM_FENCE() asm volatile("" ::: "memory")
-#ifdef DIFFAB_ACCURATE_EXP
-#define FAST_EXP(x) expf(x)
-#else
 #define FAST_EXP(x) __expf(x)
-#endif
 
 namespace {
 constexpr int AH = 8, ADS = 32, AP = 8, AC = 64;
@@ -638,10 +634,7 @@ int launch_attention_split(const diffab_dims* d, const float* proj, const float*
   if (D2) hipLaunchKernelGGL(ipa_logits_kernel<true>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, D2, K, RB);
   else hipLaunchKernelGGL(ipa_logits_kernel<false>, grid_ac, dim3(256), lds_a, st, proj, gamma, SP, nullptr, K, RB);
   DIFFAB_LAUNCH_CHECK();
-#ifndef SPB_RPW
-#define SPB_RPW 4
-#endif
-  constexpr int RPW = SPB_RPW;  // rows per wave: 8 RPW per work-group
+  constexpr int RPW = 4;  // rows per wave: 8 RPW per work-group
   const size_t lds_b = static_cast<size_t>(8) * 2 * 16 * ELD * sizeof(float);
   const dim3 grid_b((rows + 8 * RPW - 1) / (8 * RPW));
   timer_begin(st);

@@ -552,6 +552,25 @@ __global__ __launch_bounds__(1024) void pair_dist_bwd_group_kernel(const int64_t
     if (tab[i] != 0.0f) atomicAdd(grow + i, tab[i]);
 }
 
+// d softplus(coef) of a chunk of pair rows: the per-(b, i)-group kernel where its [21][A A] LDS table fits (A <= 27 within the 64 KiB a
+// launch gets by default; up to 160 KiB with the attribute raised: A <= 43) and the chunk is whole groups, the per-row atomic kernel otherwise
+static int launch_pair_dist_bwd(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din,
+                                const float* ddin, int K, int A, int64_t row0, int64_t nrows, int ld, float* g_coef_sp, hipStream_t st) {
+  const size_t lds = sizeof(float) * kAA * A * A;
+  if (lds <= 160 * 1024 && nrows % K == 0 && row0 % K == 0) {
+    if (lds > 64 * 1024)
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dist_bwd_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds)));
+    hipLaunchKernelGGL(pair_dist_bwd_group_kernel, dim3(static_cast<unsigned>(nrows / K)), dim3(1024), lds, st, seq, seq_m, distmat, xyz, din, ddin,
+                       K, A, row0, ld, g_coef_sp);
+  } else {
+    hipLaunchKernelGGL(pair_dist_bwd_kernel, dim3(static_cast<unsigned>((nrows + 7) / 8)), dim3(256), 0, st, seq, seq_m, distmat, xyz, din, ddin, K, A,
+                       row0, nrows, ld, g_coef_sp);
+  }
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 // g_coef[n] += g_coef_sp[n] * softplus'(coef[n])   (sigmoid; 1 beyond F.softplus's threshold of 20)
 __global__ void softplus_bwd_kernel(const float* __restrict__ coefw, const float* __restrict__ g_sp, int n, float* __restrict__ g_coef) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,9 +890,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
       DIFFAB_LAUNCH_CHECK();
     }
     if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
-    hipLaunchKernelGGL(pair_dist_bwd_group_kernel, dim3(static_cast<unsigned>(nrows / d->K)), dim3(1024), sizeof(float) * kAA * AA2, st, seq_idx,
-                       sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, AA2p, g_sp);
-    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_pair_dist_bwd(seq_idx, sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, nrows, AA2p, g_sp, st)) return rc;
   }
   // ---- the table segments: d aa_pair_emb += G1 W_a, d W_a += G1^T aa_pair_emb (W_a = mlp[0].weight[:, 0:C]); the same for relpos_emb / G2
   const int n1 = kAA * kAA, n2 = 2 * d->max_dist + 1;
@@ -987,9 +1004,7 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
     if (int rc = bwd_linear(ddf, C, h1, C, w->dw2, mut(g->dw2), mut(g->db2), dh1, C, rows, C, C, false, st)) return rc;
     if (int rc = bwd_relu_mask(dh1, h1, nrows * C, st)) return rc;
     if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
-    hipLaunchKernelGGL(pair_dist_bwd_group_kernel, dim3(static_cast<unsigned>(nrows / d->K)), dim3(1024), sizeof(float) * kAA * AA2, st, seq_idx,
-                       sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, AA2p, g_sp);
-    DIFFAB_LAUNCH_CHECK();
+    if (int rc = launch_pair_dist_bwd(seq_idx, sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, nrows, AA2p, g_sp, st)) return rc;
   }
   hipLaunchKernelGGL(unpad_add_kernel, dim3((C * AA2 + 255) / 256), dim3(256), 0, st, gdw0p, AA2p, AA2, C, mut(g->dw0));
   hipLaunchKernelGGL(unpad_add_kernel, dim3((C * W + 255) / 256), dim3(256), 0, st, gmw0p, Wp, W, C, mut(g->mw0));

@@ -1746,7 +1746,6 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     constexpr int RRm = 4;  // query rows per work-group of the multi-row kernel
     const size_t slot = ((3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) + 3) & ~static_cast<size_t>(3);
     const size_t lds_mr = RRm * slot * sizeof(float);
-#ifndef DIFFAB_BWD_ONE_ROW
     if (vec && H <= 8 && d->K % RRm == 0 && lds_mr <= 160 * 1024) {
       if (mfma_probs) {
         // MFMA path: probabilities and squared distances by the forward's kernels, the key/value part of dA as a batched GEMM; the
@@ -1790,7 +1789,6 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
                            nullptr, nullptr);
       }
     } else
-#endif
     {
       hipLaunchKernelGGL(ipa_attn_bwd_rows_kernel, dim3(rows), dim3(256), lds, st, proj, pair_ctx, O_t, lw->w_bias, lw->gamma, feat, dfeat,
                          dproj, d_pair_ctx, const_cast<float*>(lg->w_bias), const_cast<float*>(lg->gamma), At, Gt, dogbuf, wb_part, d->K, C, H,

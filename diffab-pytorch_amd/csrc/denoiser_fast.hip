@@ -171,13 +171,9 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // <-> output column 4 j + tt of the wave's 64) so a lane ends with 4 consecutive columns: float4 stores, 256 contiguous bytes per
 // 16 lanes.
 constexpr int RG_KC = 64, RG_LD = RG_KC + 4;
-#ifndef RG_MT
-#define RG_MT 2  // 16-row MFMA tiles per wave: 2 -> 128 rows per work-group (1 -> 64 rows, two work-groups per CU: measured slower)
-#endif
+constexpr int RG_MT = 2;  // 16-row MFMA tiles per wave: 2 -> 128 rows per work-group (1 -> 64 rows, two work-groups per CU: measured slower)
 constexpr int RG_ROWS = 64 * RG_MT;
-#ifndef RG_DEEP_A
-#define RG_DEEP_A 0  // 1: A register sets span two weight chunks (deeper prefetch) - measured SLOWER (101 vs 88 us at K = 1024)
-#endif
+constexpr bool RG_DEEP_A = false;  // true: A register sets span two weight chunks (deeper prefetch) - measured SLOWER (101 vs 88 us at K = 1024)
 
 // AW: weight chunks (64 k) per A register set.  The A fragments of set n+1 are requested while set n is consumed, so AW = 2
 // doubles the prefetch distance (2 x 3.5 us of MFMA work at K = 1024): with AW = 1 every CU asks for its next 64 KiB at the same
@@ -347,14 +343,15 @@ int launch_linear(const float* X, int ldx, const float* W, const float* bias, fl
 // ================================================================== fused IPA attention (benchmark geometry)
 // The body is ipa_attn_tile.h (a device function, shared with the patch-resident module kernel of ipa_persistent.hip); here one
 // work-group per (patch, 16 query residues), grid = B K / 16.
-template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8>
+template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8, bool VPL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ipa_attn_fast_kernel(const float* __restrict__ proj, const float* __restrict__ e,
                                                             const float* __restrict__ R, const float* __restrict__ t,
                                                             const float* __restrict__ Wb, const float* __restrict__ gamma,
                                                             float* __restrict__ feat, int B, int NC_arg,
                                                             unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr,
                                                             float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr,
-                                                            const unsigned char* __restrict__ tile_needed = nullptr) {
+                                                            const unsigned char* __restrict__ tile_needed = nullptr,
+                                                            const f32x4* __restrict__ vpl = nullptr, const float* __restrict__ vsc = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float S[];
   const int ntile = (MULTI ? NC_arg : 1) * NT;  // K / TI
   // XCD-aware map: blocks b and b+8 share an XCD (round-robin dispatch), so give all row tiles of one patch to one XCD.
@@ -371,15 +368,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ipa_attn_fast_kernel
   // tile_needed (reverse sampler, last layer, DIFFAB_FLAG_SKIP_UNUSED_ROWS): the outputs of this layer are read for generated residues
   // only - a row tile without one leaves at once (uniform; its feature rows keep the previous layer's values, which nothing reads)
   if (tile_needed != nullptr && !tile_needed[b * ntile + tile]) return;
-  ipa_attn_tile<NT, MULTI, PLANES, TAPE, NW>(S, b, tile, bid, proj, e, R, t, Wb, gamma, feat, NC_arg, stamps, esc, tape_p, tape_d2);
+  ipa_attn_tile<NT, MULTI, PLANES, TAPE, NW, VPL>(S, b, tile, bid, proj, e, R, t, Wb, gamma, feat, NC_arg, stamps, esc, tape_p, tape_d2, vpl, vsc);
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
 static int g_attn_variant = 0;                       // diagnostics only (diffab_debug_set_attn_variant): 1 = four-wave work-groups
+static bool g_value_planes = false;                  // diffab_debug_set_attn_variant bit 4 (16): the value side of P x V as fp16 planes (measured, not the default:
+                                                     // profiles/r06_attention.md)
+bool value_planes_enabled() { return g_value_planes; }
 void set_pair_embed_fused(bool on);  // pair_embed_fused.hip
 void set_attn_variant(int v) {       // A/B switches for tests and tools (include/diffab_hip.h)
   g_attn_variant = v & 9;  // 1: four-wave attention work-groups; 8: the two big dense products of a layer as six-term bf16 products
   set_pair_embed_fused(!(v & 4));
+  g_value_planes = (v & 16) != 0;  // 16: value planes - phase 3 of the attention tile on the f16 matrix cores (proj_frames_h3_tile.h "Value planes")
 }
 bool dense_h3_enabled() { return g_attn_variant != 8; }
 void set_attn_stamps(void* p) {
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256) void pair_rowscale_kernel(const float* __restr
   if (threadIdx.x == 0) {
     const unsigned b = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));  // NaN rows: fmaxf drops NaNs -> scale of the finite part
     const int ex = static_cast<int>((b >> 23) & 255u);
-    const bool ok = ex > 0 && ex < 231 && b < 0x7f800000u;  // zero / subnormal / huge / inf maximum: no scaling (inf / nan propagate as in fp32)
+    const bool ok = ex >= 8 && ex < 231 && b < 0x7f800000u;  // zero / below 2^-119 / huge / inf maximum: no scaling (inf / nan propagate as in fp32)
     rs[2 * row] = ok ? __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - ex) << 23) : 1.0f;
     rs[2 * row + 1] = ok ? __uint_as_float(static_cast<unsigned>(ex - 7) << 23) : 1.0f;
   }
@@ -544,7 +545,7 @@ size_t ipa_layer_small_offset() { return ipa_layer_out_planes_offset() + round25
 size_t ipa_layer_h3_pj_offset() { return ipa_layer_small_offset() + round256(kLayerSmallFloats * sizeof(float)); }
 size_t ipa_layer_h3_out_offset() { return ipa_layer_h3_pj_offset() + round256(proj_frames_h3_planes_bytes()); }
 size_t ipa_layer_h3_wis_offset() { return ipa_layer_h3_out_offset() + round256(rowgemm128_h3_planes_bytes(AF)); }  // [1344 projections | 128 to_out]
-size_t ipa_layer_planes_bytes() { return ipa_layer_h3_wis_offset() + round256((ANP + 128) * sizeof(float)); }
+size_t ipa_layer_planes_bytes() { return ipa_layer_h3_wis_offset() + round256((ANP + 128 + 64) * sizeof(float)); }  // + 28 group maxima (value planes)
 __global__ void layer_small_copy_kernel(const float* __restrict__ w_bias, const float* __restrict__ gamma, const float* __restrict__ b_out,
                                         float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -580,7 +581,18 @@ static size_t ipa_ws_operands_offset(const diffab_dims* d) {
   const size_t o = ipa_ws_parts_offset(d) + rowgemm128_h3_parts_floats(d->B * d->K, AF);
   return (o + 63) & ~static_cast<size_t>(63);
 }
-size_t ipa_fast_workspace_floats(const diffab_dims* d) { return ipa_ws_operands_offset(d); }
+// ... | value planes + their scales (the P x V operands of the plane attention kernels, written by the h3 projection tile)
+static size_t ipa_ws_vpl_offset(const diffab_dims* d) { return ipa_ws_operands_offset(d) + 64; }
+size_t ipa_fast_workspace_floats(const diffab_dims* d) {
+  const int64_t rows = static_cast<int64_t>(d->B) * d->K;
+  return ipa_ws_vpl_offset(d) + proj_value_planes_floats(rows) + proj_value_scales_floats(rows) + 64;
+}
+// the value planes of a layer workspace: 256-byte aligned planes, the scales behind them
+void ipa_ws_value_planes(const diffab_dims* d, float* ws, float** vpl, float** vsc) {
+  float* base = ws + ipa_ws_vpl_offset(d);
+  *vpl = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(base) + 255) & ~static_cast<uintptr_t>(255));
+  *vsc = *vpl + proj_value_planes_floats(static_cast<int64_t>(d->B) * d->K);
+}
 
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, float* sp_keep, float* d2_keep, const void* planes, const float* pair_planes,
@@ -622,8 +634,17 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   bool vec = aligned16(x);
   for (int s = 0; s < 6; ++s) vec = vec && aligned16(segs.W[s]);
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
+  // Value planes (round 6, opt-in: diffab_debug_set_attn_variant(16)): with the pair planes AND the fp16 x 3 projections (inference, not the
+  // training tape: its backward reads the fp32 value columns) the projection tile leaves the value side as fp16 planes for the attention
+  // tile's P x V product on the f16 matrix cores.  Parity-green and 5 % faster for the attention launch, but the plane stores cost the
+  // projection tile more than that (profiles/r06_attention.md): not the default.
+  const bool vpl_on = h3 && !taped && sp_keep == nullptr && pair_planes != nullptr && pair_planes_supported(d) && g_attn_variant != 1 &&
+                      d->K % 32 == 0 && g_value_planes;
+  float* vpl = nullptr;
+  float* vsc = nullptr;
+  if (vpl_on) ipa_ws_value_planes(d, ws, &vpl, &vsc);
   if (h3) {
-    if (int rc = launch_proj_frames_h3p(x, plc + ipa_layer_h3_pj_offset(), wis, R, t, proj, rows, st)) return rc;
+    if (int rc = launch_proj_frames_h3p(x, plc + ipa_layer_h3_pj_offset(), wis, R, t, proj, rows, st, vpl, vsc, d->K)) return rc;
   } else if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {
@@ -644,13 +665,14 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   const bool use_planes = pair_planes != nullptr && pair_planes_supported(d);
   const float* e_arg = use_planes ? pair_planes + 64 : e;
   const float* esc = use_planes ? pair_row_scales(d, pair_planes) : nullptr;
-#define ATTN_LAUNCH(NT_, MULTI_, PLANES_)                                                                                             \
+#define ATTN_LAUNCH(NT_, MULTI_, PLANES_, VPL_)                                                                                       \
   do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, PLANES_>),                   \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_fast_kernel<NT_, MULTI_, PLANES_, false, 8, VPL_>),   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                         \
     timer_begin(st);                                                                                                                  \
-    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, PLANES_>), grid, dim3(512), lds, st, proj, e_arg, R, t, w->w_bias,          \
-                       w->gamma, feat, d->B, nc, g_attn_stamps, esc, nullptr, nullptr, tile_needed);                                  \
+    hipLaunchKernelGGL((ipa_attn_fast_kernel<NT_, MULTI_, PLANES_, false, 8, VPL_>), grid, dim3(512), lds, st, proj, e_arg, R, t,     \
+                       w->w_bias, w->gamma, feat, d->B, nc, g_attn_stamps, esc, nullptr, nullptr, tile_needed,                        \
+                       reinterpret_cast<const f32x4*>(vpl), vsc);                                                                     \
     timer_end(st);                                                                                                                    \
   } while (0)
   if (tape) {
@@ -668,15 +690,20 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
     hipLaunchKernelGGL((ipa_attn_fast_kernel<4, true, true, false, 4>), grid, dim3(256), lds4, st, proj, e_arg, R, t, w->w_bias, w->gamma, feat,
                        d->B, nc4, g_attn_stamps, esc, nullptr, nullptr, tile_needed);
     timer_end(st);
+  } else if (vpl_on) {
+    if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, true, true);
+    else if (nt == 8) ATTN_LAUNCH(8, true, true, true);
+    else if (nc == 1) ATTN_LAUNCH(4, false, true, true);
+    else ATTN_LAUNCH(4, true, true, true);
   } else if (use_planes) {
-    if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, true);
-    else if (nt == 8) ATTN_LAUNCH(8, true, true);
-    else if (nc == 1) ATTN_LAUNCH(4, false, true);
-    else ATTN_LAUNCH(4, true, true);
-  } else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, false);
-  else if (nt == 8) ATTN_LAUNCH(8, true, false);
-  else if (nc == 1) ATTN_LAUNCH(4, false, false);
-  else ATTN_LAUNCH(4, true, false);
+    if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, true, false);
+    else if (nt == 8) ATTN_LAUNCH(8, true, true, false);
+    else if (nc == 1) ATTN_LAUNCH(4, false, true, false);
+    else ATTN_LAUNCH(4, true, true, false);
+  } else if (nt == 8 && nc == 1) ATTN_LAUNCH(8, false, false, false);
+  else if (nt == 8) ATTN_LAUNCH(8, true, false, false);
+  else if (nc == 1) ATTN_LAUNCH(4, false, false, false);
+  else ATTN_LAUNCH(4, true, false, false);
 #undef ATTN_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return to_out();

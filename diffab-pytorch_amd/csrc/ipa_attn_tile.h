@@ -29,12 +29,8 @@ constexpr int TI = 16;  // query residues per work-group
 // 8 (K + 8) + 8 keep both the (head, quarter)-lane and the (row, quarter)-lane ds_read_b128 patterns conflict-free.
 
 // softmax exponentials: v_exp_f32 path (2^(x log2 e)); arguments are <= 0 and the relative error (<~ |x| 1e-7) is far inside the
-// 1e-4 parity bar (measured ~2e-6 on the outputs).  -DDIFFAB_ACCURATE_EXP restores the libm expf expansion (~12 VALU ops each).
-#ifdef DIFFAB_ACCURATE_EXP
-#define FAST_EXP(x) expf(x)
-#else
+// 1e-4 parity bar (measured ~2e-6 on the outputs); libm's expf expansion is ~12 VALU ops each.
 #define FAST_EXP(x) __expf(x)
-#endif
 
 // NT: key tiles (16 keys each) per chunk: 8 when K % 128 == 0, else 4; compile-time so per-lane arrays stay in VGPRs.
 // MULTI: more than one chunk.  The single-chunk instantiation (K = 64, 128) has NC == 1 at compile time: the chunk loop and every
@@ -103,15 +99,23 @@ __device__ __forceinline__ void attn_p1_request(AttnP1Pre<SD>& pre, const int pi
 // 512 threads; S: the dynamic LDS (ipa_attn_lds_bytes(NT)); stamp_id: the slot of this item in the diagnostic stamp buffer.
 // NW: waves of the work-group (8: wave = head in phases 1 and 3, two rows in phase 2; 4: two heads / four rows per wave - the form that
 // fits two work-groups on a CU: with the 64-key chunk image its LDS is 79.5 KiB, and the two groups' phases interleave on the CU's pipes).
-template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8>
+// VPL (with PLANES, NW = 8; round 6): phase 3 (P x V) runs on the f16 matrix cores as well.  The value side arrives as two fp16 planes in
+// fragment order, written by the projection tile (proj_frames_h3_tile.h, "Value planes": per (patch, head, 32-key step) the four 16-column
+// tiles [v_s 0..15 | v_s 16..31 | x, y of the 8 points | z of the 8 points + a ones column], one power-of-two scale per (32-key step,
+// 48-column group) in vsc, point coordinates relative to the patch's first translation); the probabilities are split into two fp16 planes
+// on the fly (2^15 P = p1 + p2): three exact partial products per tile and 32 keys - 12 MFMAs of 16 cycles per (head, 32 keys) against 32
+// f32 MFMAs of 32 cycles (which also block the vector ALU), 8 linear 1 KiB loads per 32 keys straight into B fragments, no LDS staging.
+template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8, bool VPL = false>
 __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b, const int tile, const unsigned stamp_id,
                                               const float* __restrict__ proj, const float* __restrict__ e,
                                               const float* __restrict__ R, const float* __restrict__ t,
                                               const float* __restrict__ Wb, const float* __restrict__ gamma,
                                               float* __restrict__ feat, int NC_arg,
                                               unsigned long long* __restrict__ stamps, const float* __restrict__ esc = nullptr,
-                                              float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr) {
+                                              float* __restrict__ tape_p = nullptr, float* __restrict__ tape_d2 = nullptr,
+                                              const f32x4* __restrict__ vpl = nullptr, const float* __restrict__ vsc = nullptr) {
   static_assert(NW == 8 || (NW == 4 && PLANES && !TAPE), "the four-wave form exists for the plane kernels");
+  static_assert(!VPL || (PLANES && NW == 8 && NT % 2 == 0), "value planes: the eight-wave plane kernels");
   constexpr int HPW = AH / NW;  // heads per wave (phases 1 and 3)
   constexpr int RPW = TI / NW;  // query rows per wave (phase 2)
   static_assert(!PLANES || NT % 2 == 0, "the o_e product takes key tiles in pairs");
@@ -156,17 +160,8 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
   constexpr int P1_TILE = 16 * KLD + 16 * GLD;  // 1088 floats per staged key tile
   constexpr int ELD = 72;                       // pair-tile stride (floats)
   constexpr int SCR_FLOATS = 2 * 16 * ELD;      // 2304 floats per wave (>= 2 * P1_TILE = 2176)
-#ifndef DIFFAB_E_EARLY
-#define DIFFAB_E_EARLY 1
-#endif
-#ifndef DIFFAB_E_LAG
-#define DIFFAB_E_LAG 2
-#endif
-  constexpr int E_LAG = MULTI ? DIFFAB_E_LAG : 0;    // the next row's tile loads trail the retiring tiles by this many (VGPRs)
-#ifndef DIFFAB_E_EARLY_SINGLE
-#define DIFFAB_E_EARLY_SINGLE 2
-#endif
-  constexpr int E_EARLY = MULTI ? DIFFAB_E_EARLY : DIFFAB_E_EARLY_SINGLE;  // pair tiles of phase 2's first row started under the tail of phase 1
+  constexpr int E_LAG = MULTI ? 2 : 0;    // the next row's tile loads trail the retiring tiles by this many (VGPRs)
+  constexpr int E_EARLY = MULTI ? 1 : 2;  // pair tiles of phase 2's first row started under the tail of phase 1 (swept in rounds 2-3)
   float* scr = S + TI * IS + wv * SCR_FLOATS;
   float* st_fac = S + TI * IS + NW * SCR_FLOATS;  // [TI][AH] exp(M_old - M_new) of the current chunk
   float* st_inv = st_fac + TI * AH;              // [TI][AH] 1 / L after the last chunk (1 before)
@@ -346,15 +341,14 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
     // ---------------------------------------------------------------- phase 2: wave = 2 query rows, lanes = (head, key quarter)
     {
       const int h = l15 & 7;  // lanes with l15 >= 8 shadow head l15-8 (their MFMA columns are padding)
-#ifndef DIFFAB_E_DEPTH0
-#define DIFFAB_E_DEPTH0 3  // tiles of the first row in flight before its bias loop starts; the rest follow one per consumed tile (all 8 at once:
-                           // 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it builds delays every other CU's loads)
-#endif
+      constexpr int E_DEPTH_FP32 = 3;  // fp32 pair stream: tiles of the first row in flight before its bias loop starts; the rest follow one per
+                                       // consumed tile (all 8 at once: 256 KiB per CU requested in one burst, +3.5 % kernel time: the queue it
+                                       // builds delays every other CU's loads)
       // PLANES: RT = pair tiles of the wave's 2 NT-tile stream held in registers (requested RT tiles ahead of their use): half a row.
       // (A whole row spills in the chunked kernel, and in the single-chunk one its 24 loads per wave in front of the barrier take
       // 4.6 k cycles to issue on the waves that finish phase 1 last: 0.326 ms against 0.321 with half a row.)
       constexpr int RT = NT / 2;
-      constexpr int E_DEPTH0 = PLANES ? RT : (DIFFAB_E_DEPTH0 < NT ? (DIFFAB_E_DEPTH0 > E_EARLY ? DIFFAB_E_DEPTH0 : E_EARLY) : NT);
+      constexpr int E_DEPTH0 = PLANES ? RT : (E_DEPTH_FP32 < NT ? (E_DEPTH_FP32 > E_EARLY ? E_DEPTH_FP32 : E_EARLY) : NT);
       if constexpr (!PLANES) {
 #pragma unroll
         for (int jt = E_EARLY; jt < E_DEPTH0; ++jt) load_e_tile(0, c, jt);  // the first E_EARLY tiles were started under phase 1's tail
@@ -675,6 +669,114 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
     if (c == 0) stamp(3);
 
     // ---------------------------------------------------------------- phase 3: wave = head (NW = 4: two heads, one after the other)
+    if constexpr (VPL) {
+      const int h = wv;
+      constexpr int TPC = NT / 2;  // 32-key steps per chunk
+      const int Tsteps = K >> 5;   // per patch
+      // all value fragments of this chunk (TPC x 8 KiB per head), requested before the barrier: [step][tile 0..3][plane h1, h2]
+      int lane3 = lane0;
+      asm volatile("" : "+v"(lane3));
+      const f32x4* vsrc = vpl + ((static_cast<int64_t>(b) * AH + h) * Tsteps + c * TPC) * 512 + lane3;
+      f32x4 vf[TPC][8];
+#pragma unroll
+      for (int T = 0; T < TPC; ++T)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vf[T][u] = vsrc[(T * 8 + u) * 64];
+      // 1 / s of the three 48-column groups the head's tiles sit in, per step (wave-uniform: scalar loads); x 2^-15 for the scaled P
+      const float* scp = vsc + (static_cast<int64_t>(b) * Tsteps + c * TPC) * 28;
+      const int g_os0 = (512 + 32 * h) / 48, g_os1 = (528 + 32 * h) / 48, g_pt = (1152 + 24 * h) / 48;
+      float isc[TPC][3];
+#pragma unroll
+      for (int T = 0; T < TPC; ++T) {
+        isc[T][0] = scp[T * 28 + g_os0] * (1.0f / 32768.0f);
+        isc[T][1] = scp[T * 28 + g_os1] * (1.0f / 32768.0f);
+        isc[T][2] = scp[T * 28 + g_pt] * (1.0f / 32768.0f);
+      }
+      MEM_FENCE();
+      __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS (the value fragments arrive during the wait)
+      if (c == 0) stamp(4);
+      // tot: o_s dims 0..15 | o_s dims 16..31 | x, y of the points | z of the points.  Column 8 of the z tile is the planes' ones column:
+      // mass = sum_j (p1 + p2)_j, the probability mass AS THE SPLIT PLANES SEE IT - the local points are (sum_j P~_j (gv_j - c) -
+      // (t_i - c) mass) / L = sum_j P~_j (gv_j - t_i) / L, so the 2^-22 the planes cut off P multiplies the distance of key j from the
+      // QUERY (small where the mass is), not from the patch's reference point c.
+      f32x4 tot[4], mass = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tot[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* Prow = S + l15 * IS + h * HS + 4 * q;  // A operand: P[i = l15][j = 32 T + 16 tl + 4 q + r] <-> k slot (q, e = 4 tl + r)
+#pragma unroll
+      for (int T = 0; T < TPC; ++T) {
+        const f32x4 pa0 = *reinterpret_cast<const f32x4*>(Prow + (2 * T) * 16), pa1 = *reinterpret_cast<const f32x4*>(Prow + (2 * T + 1) * 16);
+        f16x8 p1, p2;  // 2^15 P = p1 + p2 (P <= 1: as high in the fp16 range as overflow allows, so small P keep their second plane)
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          const float x = 32768.0f * (e8 < 4 ? pa0[e8 & 3] : pa1[e8 & 3]);
+          const _Float16 hh = static_cast<_Float16>(x);
+          p1[e8] = hh;
+          p2[e8] = static_cast<_Float16>(x - static_cast<float>(hh));
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p2, __builtin_bit_cast(f16x8, vf[T][2 * u]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, __builtin_bit_cast(f16x8, vf[T][2 * u + 1]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, __builtin_bit_cast(f16x8, vf[T][2 * u]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          tot[0][r] = __builtin_fmaf(isc[T][0], acc[0][r], tot[0][r]);
+          tot[1][r] = __builtin_fmaf(isc[T][1], acc[1][r], tot[1][r]);
+          tot[2][r] = __builtin_fmaf(isc[T][2], acc[2][r], tot[2][r]);
+          tot[3][r] = __builtin_fmaf(isc[T][2], acc[3][r], tot[3][r]);
+          mass[r] += acc[3][r];  // (lanes l15 == 8: the ones column, unscaled)
+        }
+      }
+      // D rows i = 4 q + r, column n = l15; earlier chunks' sums are rescaled through the feature row
+      const float* tc = t + prow0 * 3;  // the reference point of the value planes' coordinates: the patch's first translation
+      const float c0 = tc[0], c1 = tc[1], c2 = tc[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = 4 * q + r;
+        const int64_t row = prow0 + i0 + il;
+        const float fac = st_fac[il * AH + h], inv = st_inv[il * AH + h];
+        float* fr = feat + row * AF;
+        float o0 = tot[0][r], o1 = tot[1][r];
+        float* po = fr + FOFF_OS + h * ADS + l15;
+        if (MULTI && c > 0) {
+          o0 += po[0] * fac;
+          o1 += po[16] * fac;
+        }
+        po[0] = o0 * inv;
+        po[16] = o1 * inv;
+        const float gy_lane = __shfl_xor(tot[2][r], 8);  // lanes 0..7 hold x of point l15, lanes 8..15 y of point l15 - 8
+        float m_ = __shfl(mass[r], (lane & 48) | 8) * (1.0f / 32768.0f);  // the mass of row 4 q + r, from the ones column's lane
+        if (l15 < 8) {
+          float* fo = fr + FOFF_OL + h * 24 + 3 * l15;
+          float* fm = fr + FOFF_ON + h * AP + l15;  // the norm's slot parks the running mass between chunks
+          float g0_ = tot[2][r], g1_ = gy_lane, g2_ = tot[3][r];
+          if (MULTI && c > 0) {  // running (unnormalised, centred) sums are parked in the o_l slot between chunks
+            g0_ += fo[0] * fac;
+            g1_ += fo[1] * fac;
+            g2_ += fo[2] * fac;
+            m_ += fm[0] * fac;
+          }
+          if (last) {
+            const float* Rr = R + row * 9;
+            const float* tr = t + row * 3;
+            const float dx = (g0_ - m_ * (tr[0] - c0)) * inv, dy = (g1_ - m_ * (tr[1] - c1)) * inv, dz = (g2_ - m_ * (tr[2] - c2)) * inv;
+            const float lx = dx * Rr[0] + dy * Rr[1] + dz * Rr[2];  // (p - t) R^T   (diffab_pytorch.py:336)
+            const float ly = dx * Rr[3] + dy * Rr[4] + dz * Rr[5];
+            const float lz = dx * Rr[6] + dy * Rr[7] + dz * Rr[8];
+            fo[0] = lx; fo[1] = ly; fo[2] = lz;
+            fm[0] = sqrtf(lx * lx + ly * ly + lz * lz);
+          } else {
+            fo[0] = g0_; fo[1] = g1_; fo[2] = g2_;
+            fm[0] = m_;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int hw = 0; hw < HPW; ++hw) {
       const int h = HPW * wv + hw;
@@ -795,6 +897,7 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         }
       }
     }
+    }  // !VPL
     if (!last) __syncthreads();  // the next chunk's phase 1 overwrites the image
   }
   stamp(5);

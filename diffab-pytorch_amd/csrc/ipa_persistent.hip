@@ -33,6 +33,8 @@ struct ModuleArgs {
   float* feat;               // [B K][1024] workspace
   const float* pair;         // fp16 planes of the pair embedding (launch_pair_split)
   const float* esc;          // {s, 1 / s} per pair row
+  float* vpl;                // value planes of the P x V product (proj_frames_h3_tile.h), null: phase 3 from the fp32 value columns
+  float* vsc;                // their scales
   const float* R;            // [B K][9]
   const float* t;            // [B K][3]
   const char* planes;        // per layer: ipa_layer_planes_bytes() (projection planes | to_out planes | w_bias, gamma, b_out)
@@ -47,6 +49,7 @@ struct ModuleArgs {
 };
 }  // namespace
 
+template <bool VPL>
 __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const ModuleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int K = 128, NTILE = K / TI;
@@ -81,18 +84,28 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       {  // ---- the six projections + frames of the patch's 128 rows
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (an opaque copy per phase: lane-constant addresses must not stay live across the phases)
-        pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b, 0, 1, xin,
-                                               reinterpret_cast<const _Float16*>(lp + a.pj_off), reinterpret_cast<const float*>(lp + a.wis_off),
-                                               a.R, a.t, a.proj, M);
+        if constexpr (VPL)
+          pjh3::proj_frames_h3_tile<true, false, true>(reinterpret_cast<_Float16*>(lds), tid, b, 0, 1, xin,
+                                                       reinterpret_cast<const _Float16*>(lp + a.pj_off),
+                                                       reinterpret_cast<const float*>(lp + a.wis_off), a.R, a.t, a.proj, M,
+                                                       reinterpret_cast<_Float16*>(a.vpl), a.vsc, K);
+        else
+          pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b, 0, 1, xin,
+                                                 reinterpret_cast<const _Float16*>(lp + a.pj_off), reinterpret_cast<const float*>(lp + a.wis_off),
+                                                 a.R, a.t, a.proj, M);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      // the value-plane scales of this layer were just written (vector stores) over the previous layer's at the same addresses and are read
+      // through the SCALAR cache by phase 3 of the attention tiles: drop its lines (the vector L1 needs nothing: same CU, written through)
+      if constexpr (VPL) __builtin_amdgcn_s_dcache_inv();
       pstamp(b, l, 1);
       // ---- attention: the eight row tiles of the patch
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
-        ipa_attn_tile<8, false, true, false>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R, a.t, small,
-                                             small + 512, a.feat, 1, a.stamps, a.esc);
+        ipa_attn_tile<8, false, true, false, 8, VPL>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R, a.t,
+                                                     small, small + 512, a.feat, 1, a.stamps, a.esc, nullptr, nullptr,
+                                                     reinterpret_cast<const f32x4*>(a.vpl), a.vsc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the next tile's phase 1 overwrites the image; the last tile's feature rows are complete
       }
@@ -158,6 +171,8 @@ int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, con
   a.feat = ws + rows * ANP;
   a.pair = pair_planes + 64;
   a.esc = pair_row_scales(d, pair_planes);
+  const bool vpl_on = value_planes_enabled();
+  if (vpl_on) ipa_ws_value_planes(d, ws, &a.vpl, &a.vsc);
   a.R = R;
   a.t = t;
   a.planes = static_cast<const char*>(planes);
@@ -181,10 +196,12 @@ int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, con
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   const int grid = d->B < ncu ? d->B : ncu;  // one work-group per CU (149 KiB of LDS each); more patches than CUs: a work-group walks its queue
-  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_module_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(kModuleLdsBytes)));
+  const void* kfn = vpl_on ? reinterpret_cast<const void*>(ipa_module_persistent_kernel<true>)
+                           : reinterpret_cast<const void*>(ipa_module_persistent_kernel<false>);
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kModuleLdsBytes)));
   timer_begin(st);
-  hipLaunchKernelGGL(ipa_module_persistent_kernel, dim3(grid), dim3(512), kModuleLdsBytes, st, a);
+  if (vpl_on) hipLaunchKernelGGL(ipa_module_persistent_kernel<true>, dim3(grid), dim3(512), kModuleLdsBytes, st, a);
+  else hipLaunchKernelGGL(ipa_module_persistent_kernel<false>, dim3(grid), dim3(512), kModuleLdsBytes, st, a);
   timer_end(st);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;

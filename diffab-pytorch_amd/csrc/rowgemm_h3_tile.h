@@ -23,11 +23,11 @@ constexpr int BK = 32;           // k per weight chunk
 constexpr int PART_CHUNKS = 2;   // chunks per part (64 k): the unit of the X scale and of the fixed summation order
 
 __device__ __forceinline__ int h3_off(int row, int slot) { return row * BK + 8 * (slot ^ ((row >> 2) & 3)); }  // fp16 elements
-// power-of-two scale for a vector whose largest magnitude is m: s puts it into [128, 256); is = 1 / s (both exact); m = 0, subnormal or
-// huge: no scaling
+// power-of-two scale for a vector whose largest magnitude is m: s puts it into [128, 256); is = 1 / s (both exact); m = 0, below 2^-119
+// (biased exponent < 8: 1 / s = 2^(e - 7 - 127) would not be a normal number, s = 2^(261 - e - 127) would overflow) or huge: no scaling
 __device__ __forceinline__ void h3_scale(float m, float& s, float& is) {
   const int e = static_cast<int>((__float_as_uint(m) >> 23) & 255u);
-  const bool ok = e > 0 && e < 231;
+  const bool ok = e >= 8 && e < 231;
   s = ok ? __uint_as_float(static_cast<unsigned>(127 + 7 + 127 - e) << 23) : 1.0f;
   is = ok ? __uint_as_float(static_cast<unsigned>(e - 7) << 23) : 1.0f;
 }

@@ -189,7 +189,10 @@ int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; pro
                                                  attention kernel (two per CU; measured slower), bit 2 (4) = the PairEmbedding forward / backward
                                                  as their unfused launches where the fused kernel would apply, 8 (alone) = the six
                                                  projections and to_out as six-term bf16 split products (rounds 3-4) instead of the
-                                                 three-term fp16 ones - per-layer launches only.  0 = defaults. */
+                                                 three-term fp16 ones - per-layer launches only, bit 4 (16) = value planes: the projection
+                                                 tile writes the value side (v_s, global value points) as two fp16 planes and phase 3 of
+                                                 the attention tile (P x V) runs on the f16 matrix cores (parity-green, measured slower
+                                                 overall: profiles/r06_attention.md).  0 = defaults. */
 int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes);
 int diffab_debug_set_module_stamps(void* device_buffer);
 /* The cross-stream ordering guard described under "Streams" above: on / off (default since round 6), process-wide. */
@@ -197,7 +200,7 @@ int diffab_set_stream_guard(int on);
 /* Diagnostics / accuracy tests: Y[M x 128] = X[M x Kd] W[128 x Kd]^T + bias through ONE of the two dense kernels of the MFMA path -
  * mode 0: f32-input MFMA (rowgemm128_kernel), mode 1: bf16 matrix cores, six-term split (rowgemm128_b6_kernel; scratch >=
  * 3 * 128 * Kd * 2 bytes, 16-byte aligned operands), mode 2: f16 matrix cores, three-term split under power-of-two scales
- * (rowgemm128_h3_kernel; scratch >= 2 * 128 * Kd * 2 + 768 bytes).  Kd a multiple of 32.  Lets a test measure them against float64. */
+ * (rowgemm128_h3_kernel; scratch >= 2 * 128 * Kd * 2 + 768 bytes; Kd a multiple of 64).  Modes 0 and 1: Kd a multiple of 32.  Lets a test measure them against float64. */
 int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
                            size_t scratch_bytes, void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);

@@ -360,6 +360,34 @@ def test_denoiser_vs_reference_goldens(hip, golden, name, flags):
     assert torch.equal(out2["translations_eps"], out["translations_eps"])
 
 
+@pytest.mark.parametrize("name", ["bench_wide", "bench_tight", "bench_k256"])
+def test_value_planes_variant_vs_reference_goldens(hip, golden, name):
+    """diffab_debug_set_attn_variant(16) (round 6, opt-in): the projection tile writes the value side (v_s, global value points relative
+    to the patch's first translation) as two fp16 planes under a bound-derived power-of-two scale, and phase 3 of the attention tile runs
+    P x V on the f16 matrix cores (three exact partial products, the probability mass through a ones column).  Same bar as every other
+    form: the reference goldens at the benchmark geometry (K = 128 wide / tight patches, K = 256 chunked), pair planes on (the variant
+    applies to the plane kernels), every output < 1e-4 on the tensor-global and the element-wise norm - and NOT bitwise the default form."""
+    g = golden("denoiser_" + name)
+    dims, den, inp = build_case(g)
+    args = (inp["seq_idx"], inp["translations"], inp["orientations"], inp["res_context_emb"], inp["pair_context_emb"], T(g["beta"]).cuda(),
+            inp["generation_mask"], inp["residue_mask"])
+    base = den(*args, return_logits=True, flags=_hip.FLAG_PAIR_PLANES)
+    try:
+        hip.diffab_debug_set_attn_variant(16)
+        out = den(*args, return_logits=True, flags=_hip.FLAG_PAIR_PLANES)
+        l0 = den.ipa.layers[0](inp["res_context_emb"], inp["pair_context_emb"], inp["orientations"], inp["translations"], flags=_hip.FLAG_PAIR_PLANES)
+    finally:
+        hip.diffab_debug_set_attn_variant(0)
+    for k in ("res_emb", "aa_logits", "translations_eps", "orientations_t0", "seq_posterior"):
+        assert torch.isfinite(out[k]).all(), k
+        assert maxrel(out[k], g[k]) < TOL, (name, k, maxrel(out[k], g[k]))
+    for k in ("aa_logits", "translations_eps"):
+        assert elemrel(out[k], g[k]) < TOL, (name, k, elemrel(out[k], g[k]))
+    assert maxrel(l0, g["ipa_layer0"]) < TOL
+    assert not torch.equal(out["res_emb"], base["res_emb"])  # the variant really ran (different arithmetic, same answer)
+    print(f"value planes {name}: res_emb vs golden {maxrel(out['res_emb'], g['res_emb']):.1e} (default form {maxrel(base['res_emb'], g['res_emb']):.1e})")
+
+
 def test_denoiser_reference_test_shapes(hip):
     """reference tests/test_modules.py:143-248: unseeded random inputs, non-rotation 'orientations', shapes only."""
     from diffab_pytorch.diffab_pytorch import Denoiser, InvariantPointAttentionLayer, InvariantPointAttentionModule
@@ -1174,6 +1202,33 @@ def test_split_precision_gemm_is_fp32_accurate(hip, Kd):
     assert errs[0] < 2e-6 and errs[1] < 2e-6 and errs[2] < 2e-6, errs  # all at fp32 accumulation noise (a plain bf16 product would be ~4e-3)
     assert errs[1] < 4 * errs[0] + 1e-7, errs           # and the split forms are not worse than the fp32 kernel by more than noise
     assert errs[2] < 4 * errs[0] + 4e-7, errs           # (fp16 x 3 carries 22 bits per operand: 2^-22 = 2.4e-7 on top)
+
+
+def test_fp16x3_gemm_shape_guard_and_tiny_rows(hip):
+    """Round-5 advisor findings on the fp16 x 3 row GEMM: (1) it joins its 32-k chunks in pairs, so a contraction length that is not a
+    multiple of 64 must be REFUSED (Kd = 96 used to drop the last chunk silently); (2) a row whose largest magnitude is a normal number
+    below 2^-119 used to get an infinite scale (NaN outputs): such rows are now left unscaled, like zero rows - the answer is the fp32
+    one (about 0 beside the bias)."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M = 256
+    scratch = torch.empty(3 * 128 * 128 * 2 + 1024, dtype=torch.uint8, device="cuda")
+    X96, W96, Y = torch.randn(M, 96, device="cuda", generator=g), torch.randn(128, 96, device="cuda", generator=g), torch.empty(M, 128, device="cuda")
+    b = torch.randn(128, device="cuda", generator=g)
+    rc = hip.diffab_debug_linear128(_hip.ptr(X96), _hip.ptr(W96), _hip.ptr(b), _hip.ptr(Y), M, 96, 2, _hip.ptr(scratch), scratch.numel(),
+                                    _hip.stream_ptr())
+    assert rc != 0 and b"64" in hip.diffab_last_error()
+    X = torch.randn(M, 128, device="cuda", generator=g)
+    X[3] *= 1e-37   # largest magnitude ~ 3e-37: biased exponent 5..6
+    X[4] *= 3e-38   # ... and at the edge of the subnormals
+    X[5] = 0.0
+    W = torch.randn(128, 128, device="cuda", generator=g)
+    rc = hip.diffab_debug_linear128(_hip.ptr(X), _hip.ptr(W), _hip.ptr(b), _hip.ptr(Y), M, 128, 2, _hip.ptr(scratch), scratch.numel(),
+                                    _hip.stream_ptr())
+    assert rc == 0, hip.diffab_last_error()
+    want = X.double() @ W.double().T + b.double()
+    assert torch.isfinite(Y).all()
+    assert float((Y.double() - want).abs().max()) < 1e-5, float((Y.double() - want).abs().max())
+    assert torch.equal(Y[5], b)
 
 
 @pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4])
