@@ -222,6 +222,40 @@ def other_configs(model, dims, flags):
         res["k256_sampling"] = f"failed: {type(ex).__name__}: {ex}"
     gc.collect()
     torch.cuda.empty_cache()
+    try:  # BASELINE config 5 at its own batch: 512 patches of K = 256 on one GPU (two patches per CU: the patch-resident module launch)
+        B, K, steps = 512, 256, 10
+        g = torch.Generator(device="cuda").manual_seed(5)
+        small = {k: v.cuda() for k, v in syn.patches(8, K, dims, seed=5).items()}  # states / masks / frames: host generator, tiled
+        rep = lambda v: v.repeat((B // 8,) + (1,) * (v.dim() - 1)).contiguous()
+        seq, x, O, gmask = rep(small["seq_idx"]), rep(small["translations"]), rep(small["orientations"]), rep(small["generation_mask"])
+        res_c = torch.randn(B, K, dims["D"], device="cuda", generator=g)
+        pair_c = torch.randn(B, K, K, dims["C"], device="cuda", generator=g)  # 8.6 GB: generated on the device
+        hd, w = model.denoiser.hip_dims(B, K), model.denoiser.hip_weights()
+        sd_dev, tab = model._sched_on_device(), model._reverse_so3().struct()
+        ws = _hip.workspace(lib.diffab_sample_workspace_bytes(C.byref(hd)))
+        _hip.check(lib.diffab_sample_init(_hip.ptr(seq), _hip.ptr(x), _hip.ptr(O), _hip.ptr(gmask), 7, 0, B, K, model.T, _hip.stream_ptr()),
+                   "sample_init")
+        forms = {}
+        for name, fl in (("module_launch", flags | _hip.FLAG_PERSISTENT_MODULE), ("per_layer_launches", flags | _hip.FLAG_MULTI_LAUNCH)):
+            for n_ in (2, steps):  # warm-up, then timed
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _hip.check(lib.diffab_sample_loop(C.byref(hd), C.byref(w.struct), C.byref(sd_dev.struct), C.byref(tab), _hip.ptr(seq), _hip.ptr(x),
+                                                  _hip.ptr(O), _hip.ptr(res_c), _hip.ptr(pair_c), _hip.ptr(gmask), 7, 0, model.T, model.T - n_,
+                                                  _hip.ptr(ws), ws.numel(), fl, _hip.stream_ptr()), "sample_loop")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            forms[name] = dt / steps * 1e3  # (includes the once-per-call plane split of the 8.6 GB pair context)
+        res["k256_sampling_b512"] = {"patches": B, "K": K, "steps": steps, "ms_per_step": forms["per_layer_launches"],
+                                     "ms_per_step_module_launch": forms["module_launch"],
+                                     "residue_steps_per_s": B * K / (forms["per_layer_launches"] * 1e-3), "finite": bool(torch.isfinite(x).all()),
+                                     "what": "BASELINE config 5's batch on one GPU; per-layer launches (the sampler's choice at K = 256) and the "
+                                             "patch-resident module launch (DIFFAB_FLAG_PERSISTENT_MODULE); both include the per-call pair-plane split"}
+        del small, seq, x, O, gmask, res_c, pair_c, ws
+    except Exception as ex:  # noqa: BLE001
+        res["k256_sampling_b512"] = f"failed: {type(ex).__name__}: {ex}"
+    gc.collect()
+    torch.cuda.empty_cache()
     try:  # the headline shape with DIFFAB_FLAG_SKIP_UNUSED_ROWS: same samples bit for bit, the last layer's attention only for the row
         # tiles that hold a generated residue.  NOT the headline: the work skipped depends on the mask (synthetic: one CDR-like segment
         # of 5..20 residues per patch), the headline runs every row of every layer as the reference does.

@@ -680,7 +680,9 @@ int diffab_sample_loop(const diffab_dims* d, const diffab_denoiser_weights* w, c
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int rounds = (d->B + ncu - 1) / ncu;
-    if (d->B >= ncu && static_cast<double>(d->B) >= 0.85 * rounds * ncu) flags |= DIFFAB_FLAG_PERSISTENT_MODULE;
+    // (K = 256 - two dense tiles and sixteen two-chunk attention items per patch in the same launch, round 6 - measures SLOWER than its
+    // per-layer launches at B = 512: 19.5 against 18.6 ms per step; it is bitwise the same and stays behind the explicit flag)
+    if (d->K == 128 && d->B >= ncu && static_cast<double>(d->B) >= 0.85 * rounds * ncu) flags |= DIFFAB_FLAG_PERSISTENT_MODULE;
   }
   // DIFFAB_FLAG_SKIP_UNUSED_ROWS: the step's outputs (eps, O0, posterior) are read for GENERATED residues only (reverse_update leaves
   // the others alone), so the last layer's attention is needed only for row tiles that contain one; every other layer feeds keys and

@@ -1,4 +1,4 @@
-// ipa_persistent.hip - the IPA module (all NL layers) of a batch of K = 128 patches as ONE patch-resident launch.
+// ipa_persistent.hip - the IPA module (all NL layers) of a batch of K = 128 or K = 256 patches as ONE patch-resident launch.
 //
 // BASELINE.json's execution model: one 512-thread work-group per CDR patch.  A work-group owns its patch from the first layer's
 // projections to the last layer's to_out - per layer: the six projections of its 128 rows (proj_frames_h3_tile.h), the eight 16-row
@@ -49,10 +49,13 @@ struct ModuleArgs {
 };
 }  // namespace
 
-template <bool VPL>
+// KRES: residues per patch - 128 (one 128-row dense tile per patch, single-chunk attention items) or 256 (BASELINE config 5: two dense
+// tiles, sixteen attention items of two 128-key chunks with the online softmax across them - ipa_attn_tile<8, true, ...>)
+template <bool VPL, int KRES>
 __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const ModuleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int K = 128, NTILE = K / TI;
+  constexpr int K = KRES, NTILE = K / TI, DT = K / 128;  // DT: dense 128-row tiles per patch
+  static_assert(KRES == 128 || KRES == 256, "patch-resident module: K = 128 or 256");
   const int M = a.B * K;
   if (a.stagger_ticks > 0 && a.stagger_classes > 1) {
     // (every wave waits for itself: no barrier needed, the first phase starts with loads only)
@@ -67,12 +70,16 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
 #pragma unroll 1
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     if (a.emb_X != nullptr) {  // ---- to_res_emb of the patch's rows (diffab_pytorch.py:519-523, folded concatenation)
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));
-      chaintile::mlp_chain_tile(reinterpret_cast<__bf16*>(lds), tid, b, a.emb_X, 128, a.emb.c[0].planes[0], a.emb.c[0].planes[1], nullptr,
-                                a.emb.c[0].bias[0], a.emb.c[0].bias[1], nullptr, a.emb.c[0].bias_idx0, a.emb.c[0].bias_div0, 2, 128, a.xa, 128, M);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+#pragma unroll 1
+      for (int dt = 0; dt < DT; ++dt) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        chaintile::mlp_chain_tile(reinterpret_cast<__bf16*>(lds), tid, b * DT + dt, a.emb_X, 128, a.emb.c[0].planes[0], a.emb.c[0].planes[1],
+                                  nullptr, a.emb.c[0].bias[0], a.emb.c[0].bias[1], nullptr, a.emb.c[0].bias_idx0, a.emb.c[0].bias_div0, 2, 128,
+                                  a.xa, 128, M);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
     }
 #pragma unroll 1
     for (int l = 0; l < a.NL; ++l) {
@@ -81,18 +88,23 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       const float* xin = (l & 1) ? a.xb : a.xa;
       float* xout = (l & 1) ? a.xa : a.xb;
       pstamp(b, l, 0);
-      {  // ---- the six projections + frames of the patch's 128 rows
+#pragma unroll 1
+      for (int dt = 0; dt < DT; ++dt) {  // ---- the six projections + frames of the patch's rows, 128 at a time
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (an opaque copy per phase: lane-constant addresses must not stay live across the phases)
         if constexpr (VPL)
-          pjh3::proj_frames_h3_tile<true, false, true>(reinterpret_cast<_Float16*>(lds), tid, b, 0, 1, xin,
+          pjh3::proj_frames_h3_tile<true, false, true>(reinterpret_cast<_Float16*>(lds), tid, b * DT + dt, 0, 1, xin,
                                                        reinterpret_cast<const _Float16*>(lp + a.pj_off),
                                                        reinterpret_cast<const float*>(lp + a.wis_off), a.R, a.t, a.proj, M,
                                                        reinterpret_cast<_Float16*>(a.vpl), a.vsc, K);
         else
-          pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b, 0, 1, xin,
+          pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b * DT + dt, 0, 1, xin,
                                                  reinterpret_cast<const _Float16*>(lp + a.pj_off), reinterpret_cast<const float*>(lp + a.wis_off),
                                                  a.R, a.t, a.proj, M);
+        if (dt + 1 < DT) {  // the next tile's weight stages overwrite this one's LDS
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -103,19 +115,24 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       // ---- attention: the eight row tiles of the patch
 #pragma unroll 1
       for (int tile = 0; tile < NTILE; ++tile) {
-        ipa_attn_tile<8, false, true, false, 8, VPL>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R, a.t,
-                                                     small, small + 512, a.feat, 1, a.stamps, a.esc, nullptr, nullptr,
-                                                     reinterpret_cast<const f32x4*>(a.vpl), a.vsc);
+        ipa_attn_tile<8, (KRES > 128), true, false, 8, VPL>(lds, b, tile, static_cast<unsigned>((b * a.NL + l) * NTILE + tile), a.proj, a.pair, a.R,
+                                                            a.t, small, small + 512, a.feat, K / 128, a.stamps, a.esc, nullptr, nullptr,
+                                                            reinterpret_cast<const f32x4*>(a.vpl), a.vsc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the next tile's phase 1 overwrites the image; the last tile's feature rows are complete
       }
       pstamp(b, l, 2);
-      {  // ---- to_out
+#pragma unroll 1
+      for (int dt = 0; dt < DT; ++dt) {  // ---- to_out
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        h3tile::rowgemm128_h3_tile<false, 128>(reinterpret_cast<_Float16*>(lds), tid, b, a.feat, AF,
+        h3tile::rowgemm128_h3_tile<false, 128>(reinterpret_cast<_Float16*>(lds), tid, b * DT + dt, a.feat, AF,
                                                reinterpret_cast<const _Float16*>(lp + a.out_off),
                                                reinterpret_cast<const float*>(lp + a.wis_off) + ANP, small + 576, nullptr, 0, xout, 128, M, AF);
+        if (dt + 1 < DT) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -124,11 +141,12 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
     if (a.emb_X != nullptr) {  // ---- the three heads on the module's output rows (:525-533, beta columns folded into bias tables)
       const float* xfin = (a.NL & 1) ? a.xb : a.xa;
 #pragma unroll 1
-      for (int hd = 0; hd < 3; ++hd) {
+      for (int hdt = 0; hdt < 3 * DT; ++hdt) {
+        const int hd = hdt / DT, dt = hdt % DT;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
 #define HSEL(f) (hd == 0 ? a.heads.c[0].f : hd == 1 ? a.heads.c[1].f : a.heads.c[2].f)
-        chaintile::mlp_chain_tile(reinterpret_cast<__bf16*>(lds), tid, b, xfin, 128, HSEL(planes[0]), HSEL(planes[1]), HSEL(planes[2]),
+        chaintile::mlp_chain_tile(reinterpret_cast<__bf16*>(lds), tid, b * DT + dt, xfin, 128, HSEL(planes[0]), HSEL(planes[1]), HSEL(planes[2]),
                                   HSEL(bias[0]), HSEL(bias[1]), HSEL(bias[2]), HSEL(bias_idx0), HSEL(bias_div0), 3, HSEL(n_out),
                                   hd == 0 ? a.heads.Y[0] : hd == 1 ? a.heads.Y[1] : a.heads.Y[2],
                                   hd == 0 ? a.heads.ldy[0] : hd == 1 ? a.heads.ldy[1] : a.heads.ldy[2], M);
@@ -152,7 +170,7 @@ void set_module_stagger(int ticks, int classes) {
 void set_module_stamps(void* p) { g_module_stamps = static_cast<unsigned long long*>(p); }
 
 bool ipa_module_persistent_supported(const diffab_dims* d) {
-  return fast_path_supported(d) && d->K == 128 && d->NL >= 1 && dense_h3_enabled();  // (the kernel holds the fp16 tiles only)
+  return fast_path_supported(d) && (d->K == 128 || d->K == 256) && d->NL >= 1 && dense_h3_enabled();  // (the kernel holds the fp16 tiles only)
 }
 
 // planes: d->NL x ipa_layer_planes_bytes() (ipa_layer_split_weights); pair_planes: launch_pair_split(); xa in, result in (NL odd ? xb : xa)
@@ -196,13 +214,22 @@ int launch_ipa_module_persistent(const diffab_dims* d, float* xa, float* xb, con
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   const int grid = d->B < ncu ? d->B : ncu;  // one work-group per CU (149 KiB of LDS each); more patches than CUs: a work-group walks its queue
-  const void* kfn = vpl_on ? reinterpret_cast<const void*>(ipa_module_persistent_kernel<true>)
-                           : reinterpret_cast<const void*>(ipa_module_persistent_kernel<false>);
-  DIFFAB_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kModuleLdsBytes)));
-  timer_begin(st);
-  if (vpl_on) hipLaunchKernelGGL(ipa_module_persistent_kernel<true>, dim3(grid), dim3(512), kModuleLdsBytes, st, a);
-  else hipLaunchKernelGGL(ipa_module_persistent_kernel<false>, dim3(grid), dim3(512), kModuleLdsBytes, st, a);
-  timer_end(st);
+#define MODULE_LAUNCH(VPL_, K_)                                                                                                     \
+  do {                                                                                                                            \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_module_persistent_kernel<VPL_, K_>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kModuleLdsBytes)));        \
+    timer_begin(st);                                                                                                              \
+    hipLaunchKernelGGL((ipa_module_persistent_kernel<VPL_, K_>), dim3(grid), dim3(512), kModuleLdsBytes, st, a);                  \
+    timer_end(st);                                                                                                                \
+  } while (0)
+  if (d->K == 128) {
+    if (vpl_on) MODULE_LAUNCH(true, 128);
+    else MODULE_LAUNCH(false, 128);
+  } else {
+    if (vpl_on) MODULE_LAUNCH(true, 256);
+    else MODULE_LAUNCH(false, 256);
+  }
+#undef MODULE_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

@@ -22,7 +22,7 @@ FLAG_PAIR_F32 = 64  # sample_loop: keep the fp32 pair stream (no fp16 planes)
 FLAG_FP32_GEMM = 128  # forward paths: dense products on the f32-input MFMA kernels instead of the bf16 split
 FLAG_PAIR_PLANES = 32  # K = 64 / 128: pair embedding as two fp16 planes, pair-tile products on the f16 matrix cores (always on in sample_loop)
 FLAG_GRAPH_SAMPLER = 16  # sample_loop: one captured step replayed as a hipGraph (launch-bound small batches)
-FLAG_PERSISTENT_MODULE = 512  # MFMA path, K = 128, pair planes: the IPA module as one patch-resident launch (bitwise the multi-launch result)
+FLAG_PERSISTENT_MODULE = 512  # MFMA path, K = 128 / 256, pair planes: the IPA module as one patch-resident launch (bitwise the multi-launch result)
 FLAG_MULTI_LAUNCH = 1024  # sample_loop: never choose the patch-resident module launch (bitwise the same samples either way)
 FLAG_SKIP_UNUSED_ROWS = 256  # sample_loop: the last layer's attention only for row tiles with a generated residue (same trajectory)
 

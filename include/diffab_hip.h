@@ -81,7 +81,7 @@ extern "C" {
                                          eager trajectory.  The call drains its private replay stream before it returns (the graph
                                          must outlive its launches).  Measured at B = 1, K = 128: no gain (the host already runs
                                          ahead of the device; a step is 45 dependent small-grid kernels), hence opt-in. */
-#define DIFFAB_FLAG_PERSISTENT_MODULE 512u /* MFMA path with pair planes, K = 128 (diffab_sample_loop, or a single call with
+#define DIFFAB_FLAG_PERSISTENT_MODULE 512u /* MFMA path with pair planes, K = 128 or 256 (diffab_sample_loop, or a single call with
                                          DIFFAB_FLAG_PAIR_PLANES): the NL layers of the IPA module (reference diffab_pytorch.py:494-498)
                                          run as ONE patch-resident launch - a 512-thread work-group owns a patch through projections,
                                          eight attention row tiles and to_out, layer after layer, with no inter-CU synchronisation
@@ -90,8 +90,10 @@ extern "C" {
                                          out_res_emb) the launch also runs the embedding MLP of the patch's rows in front of layer 0
                                          and the three heads behind the last layer: one launch per denoiser forward.  Ignored where
                                          it does not apply.  diffab_sample_loop
-                                         chooses it by itself when the batch fills the chip (B >= number of CUs), see
-                                         DIFFAB_FLAG_MULTI_LAUNCH; with DIFFAB_FLAG_SKIP_UNUSED_ROWS the per-layer launches stay. */
+                                         chooses it by itself at K = 128 when the batch fills the chip (B >= number of CUs), see
+                                         DIFFAB_FLAG_MULTI_LAUNCH; with DIFFAB_FLAG_SKIP_UNUSED_ROWS the per-layer launches stay.  K = 256
+                                         (two dense tiles, sixteen two-chunk attention items per patch; round 6) only on request:
+                                         it measures 4 % slower than its per-layer launches at B = 512. */
 #define DIFFAB_FLAG_MULTI_LAUNCH 1024u /* diffab_sample_loop: keep one launch per kernel of an IPA layer even where the patch-resident module
                                           launch would be chosen (B >= number of CUs, K = 128); the two forms are bitwise equal */
 #define DIFFAB_FLAG_SKIP_UNUSED_ROWS 256u /* diffab_sample_loop (MFMA path, K % 16 == 0): a step's outputs are read for GENERATED residues

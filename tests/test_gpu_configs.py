@@ -148,6 +148,15 @@ def test_patch_resident_module_is_bitwise_the_per_layer_launches(hip):
                 a2 = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=fl_a, **kw)
                 for k in a:
                     assert torch.equal(a[k], a2[k]), ("run-to-run", rep, k)
+    # K = 256 (round 6: two dense tiles and sixteen two-chunk attention items per patch inside the same launch; BASELINE config 5)
+    inp = device_patches(6, 256, dims, seed=46)
+    kw = dict(res_context_emb=inp["res_context_emb"], pair_context_emb=inp["pair_context_emb"], generation_mask=inp["generation_mask"],
+              seed=5, t_stop=97)
+    a = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=_hip.FLAG_PERSISTENT_MODULE, **kw)
+    b = model.sample(inp["seq_idx"], inp["translations"], inp["orientations"], flags=0, **kw)
+    for k in a:
+        assert torch.equal(a[k], b[k]), ("K = 256", k)
+    assert not torch.equal(a["translations"], inp["translations"])
     # the opt-in value-plane form (diffab_debug_set_attn_variant(16), profiles/r06_attention.md) shares its tile bodies between the two launch
     # forms as well: bitwise equal to each other (and different bits from the default form: other arithmetic in phase 3)
     inp = device_patches(8, 128, dims, seed=48)
