@@ -5,6 +5,8 @@
 // (nothing of size K x K is stored), per-row results are written directly and per-key / per-parameter sums are added
 // with float atomics (sized by bytes per Guideline 12: ~0.4 MB of adds per patch-layer).  Saved activations ("tape"):
 // per layer the layer input, the projection buffer and the feature rows - the same buffers the forward kernels write.
+#include <mutex>
+
 #include "common.h"
 #include "denoiser_internal.h"
 #include "so3_math.h"
@@ -156,6 +158,82 @@ __global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restri
 }
 
 static int relu_mask(float* dY, const float* act, int64_t n, hipStream_t st);
+// ---- weight-gradient products beside the backward chain (round 6) -----------------------------------------------------------------
+// Nothing on the backward chain reads a dW or a db, and each of the 23 weight-gradient products of a training step fills 64..700 of
+// the chip's work-group slots for 20-46 us when it runs alone (0.9 ms of a 7 ms step, profiles/r05_train_kernel_stats.csv).  They go to a
+// second stream of the library's own: begin() orders it behind everything the caller's stream holds so far, reads(buf) remembers that the
+// side work enqueued since then reads buf, before_write(buf) makes the caller's stream wait for exactly that work before a kernel
+// overwrites buf, join() before the entry point returns - so from outside the call is still ordered by ONE stream.  (Two streams of one
+// process are safe since the packed-fp32 form of profiles/r06_lanes_48_63.md is out of the library.)  No side stream (creation failed, or
+// the caller's stream is being captured into a graph): everything runs on the caller's stream as before.
+class SideRun {
+ public:
+  explicit SideRun(hipStream_t main) : main_(main) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    st_ = &pool()[dev & 31];
+    st_->mu.lock();
+    if (st_->side == nullptr) {
+      bool ok = hipStreamCreateWithFlags(&st_->side, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&st_->fork, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < kEv && ok; ++i) ok = hipEventCreateWithFlags(&st_->done[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); st_->side = nullptr; st_->broken = true; }
+    }
+    if (st_->broken) { st_->mu.unlock(); st_ = nullptr; }
+  }
+  ~SideRun() {
+    if (st_ == nullptr) return;
+    join();
+    st_->mu.unlock();
+  }
+  SideRun(const SideRun&) = delete;
+  SideRun& operator=(const SideRun&) = delete;
+  hipStream_t begin() {
+    if (st_ == nullptr) return main_;
+    if (hipEventRecord(st_->fork, main_) == hipSuccess) (void)hipStreamWaitEvent(st_->side, st_->fork, 0);
+    return st_->side;
+  }
+  void reads(const void* buf) {
+    if (st_ == nullptr) return;
+    int slot = -1;
+    for (int i = 0; i < kEv; ++i)
+      if (buf_[i] == nullptr) { slot = i; break; }
+    if (slot < 0) { before_write(buf_[0]); slot = 0; }  // table full: retire the oldest entry
+    if (hipEventRecord(st_->done[slot], st_->side) == hipSuccess) buf_[slot] = buf;
+  }
+  void before_write(const void* buf) {
+    if (st_ == nullptr || buf == nullptr) return;
+    for (int i = 0; i < kEv; ++i)
+      if (buf_[i] == buf) {
+        (void)hipStreamWaitEvent(main_, st_->done[i], 0);
+        buf_[i] = nullptr;
+      }
+  }
+  void join() {
+    if (st_ == nullptr) return;
+    for (int i = 0; i < kEv; ++i) buf_[i] = nullptr;
+    if (hipEventRecord(st_->fork, st_->side) == hipSuccess) (void)hipStreamWaitEvent(main_, st_->fork, 0);
+  }
+
+ private:
+  static constexpr int kEv = 16;
+  struct State {
+    std::mutex mu;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, done[kEv] = {};
+    bool broken = false;
+  };
+  static State* pool() {
+    static State s[32];
+    return s;
+  }
+  hipStream_t main_;
+  State* st_ = nullptr;
+  const void* buf_[kEv] = {};
+};
+
 static int gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, bool acc, hipStream_t st,
                    const GemmSegs* segs = nullptr, const float* relu_act = nullptr, int ld_act = 0) {
   GemmSegs sg{};
@@ -302,12 +380,16 @@ static int relu_mask(float* dY, const float* act, int64_t n, hipStream_t st) {
 }
 
 // Y = act(X W^T + b) backward: dW += dY^T X, db += colsum dY, dX (+)= dY W.   dY must already carry the activation mask.
+// side (nullable): the weight / bias gradients run on its stream, beside the chain; the caller must side->before_write(dY) ahead of the
+// next kernel that overwrites dY
 static int linear_bwd(const float* dY, int ldy, const float* X, int ldx, const float* W, float* dW, float* db, float* dX, int lddx, int M,
-                      int N, int Kd, bool acc_dx, hipStream_t st) {
+                      int N, int Kd, bool acc_dx, hipStream_t st, SideRun* side = nullptr) {
   bool db_done = false;
-  if (int rc = gemm_tn(dY, ldy, X, ldx, dW, Kd, M, N, Kd, st, nullptr, db, &db_done)) return rc;
+  hipStream_t sw = side ? side->begin() : st;
+  if (int rc = gemm_tn(dY, ldy, X, ldx, dW, Kd, M, N, Kd, sw, nullptr, db, &db_done)) return rc;
   if (db && !db_done)
-    if (int rc = colsum(dY, ldy, M, N, db, st)) return rc;
+    if (int rc = colsum(dY, ldy, M, N, db, sw)) return rc;
+  if (side) side->reads(dY);
   if (dX) return gemm_nn(dY, ldy, W, Kd, dX, lddx, M, Kd, N, acc_dx, st);
   return DIFFAB_OK;
 }
@@ -1632,7 +1714,7 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
   const size_t HKK = static_cast<size_t>(d->B) * d->H * d->K * d->K;
-  return rows * (d->V + 3 + 3) + rows * (D + 3) + 2 * rows * D + 2 * rows * D + rows * F + rows * NP + rows * 2 * D + 64 + 2 * HKK +
+  return rows * (d->V + 3 + 3) + rows * (D + 3) + 6 * rows * D + 2 * rows * D + rows * F + 2 * rows * NP + rows * 2 * D + 64 + 2 * HKK +
          rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64 +
          ((fast_path_supported(d) && attention_split_supported(d)) ? 3 * HKK : 0) +  // probabilities / g, squared distances, dA_kv
          bwd_planes_floats(d);
@@ -1662,12 +1744,15 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
   float* d_eps = take(static_cast<size_t>(rows) * 3);
   float* d_v = take(static_cast<size_t>(rows) * 3);
   float* dcat3 = take(static_cast<size_t>(rows) * (D + 3));
-  float* dt2 = take(static_cast<size_t>(rows) * D);
-  float* dt1 = take(static_cast<size_t>(rows) * D);
+  float *dt2s[3], *dt1s[3];  // per head: the weight-gradient products beside the chain read them while the next head runs
+  for (int hd = 0; hd < 3; ++hd) {
+    dt2s[hd] = take(static_cast<size_t>(rows) * D);
+    dt1s[hd] = take(static_cast<size_t>(rows) * D);
+  }
   float* dxa = take(static_cast<size_t>(rows) * D);
   float* dxb = take(static_cast<size_t>(rows) * D);
   float* dfeat = take(static_cast<size_t>(rows) * F);
-  float* dproj = take(static_cast<size_t>(rows) * NP);
+  float* dprojs[2] = {take(static_cast<size_t>(rows) * NP), take(static_cast<size_t>(rows) * NP)};  // by layer parity (same reason)
   float* dcat2 = take(static_cast<size_t>(rows) * 2 * D);
   const size_t HKK = static_cast<size_t>(d->B) * H * d->K * d->K;
   float* At = take(HKK);
@@ -1684,6 +1769,7 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
 
   float* dcur = dxa;
   float* dnxt = dxb;
+  SideRun side(st);  // weight / bias gradients beside the chain; joined when it goes out of scope (every return path)
   if (mode == BWD_LOSSES) {
     hipLaunchKernelGGL(count_mask_kernel, dim3(1), dim3(1024), 0, st, gm, rm, static_cast<int64_t>(rows), cnt);
     DIFFAB_LAUNCH_CHECK();
@@ -1705,14 +1791,15 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
   const float* dy[3] = {d_eps, d_v, d_logits};
   const int nout[3] = {3, 3, V};
   for (int hd = 0; hd < 3 && mode != BWD_LAYER; ++hd) {
+    float *dt2 = dt2s[hd], *dt1 = dt1s[hd];
     if (int rc = linear_bwd(dy[hd], nout[hd], tp.t2[hd], D, hw[hd]->w4, const_cast<float*>(hg[hd]->w4), const_cast<float*>(hg[hd]->b4), dt2,
-                            D, rows, nout[hd], D, false, st)) return rc;
+                            D, rows, nout[hd], D, false, st, &side)) return rc;
     if (int rc = relu_mask(dt2, tp.t2[hd], static_cast<int64_t>(rows) * D, st)) return rc;
     if (int rc = linear_bwd(dt2, D, tp.t1[hd], D, hw[hd]->w2, const_cast<float*>(hg[hd]->w2), const_cast<float*>(hg[hd]->b2), dt1, D, rows,
-                            D, D, false, st)) return rc;
+                            D, D, false, st, &side)) return rc;
     if (int rc = relu_mask(dt1, tp.t1[hd], static_cast<int64_t>(rows) * D, st)) return rc;
     if (int rc = linear_bwd(dt1, D, tp.cat3, D + 3, hw[hd]->w0, const_cast<float*>(hg[hd]->w0), const_cast<float*>(hg[hd]->b0), dcat3,
-                            D + 3, rows, D, D + 3, hd > 0, st)) return rc;
+                            D + 3, rows, D, D + 3, hd > 0, st, &side)) return rc;
   }
   // dh = dcat3[:, :D] (leading dimension D+3)
   if (mode != BWD_LAYER)
@@ -1725,13 +1812,15 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     const float* proj = tp.ipa_ws[l];
     const float* feat = tp.ipa_ws[l] + static_cast<size_t>(rows) * NP;
     const float* xin = tp.x[l];
+    float* dproj = dprojs[l & 1];
+    side.before_write(dproj);  // the projection weight gradient of layer l + 2 (beside the chain) read this buffer
     // to_out
     if (planes && (reinterpret_cast<uintptr_t>(dcur) & 15) == 0) {  // d feat = d y W_out on the bf16x6 x-stationary kernel
       if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), nullptr, F, rows, D,
-                              F, false, st)) return rc;
+                              F, false, st, &side)) return rc;
       if (int rc = launch_xstat_b6(dcur, lw->w_out, 1, F, dfeat, F, rows, F, planes, st)) return rc;
     } else if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows,
-                                   D, F, false, st)) {
+                                   D, F, false, st, &side)) {
       return rc;
     }
     const size_t lds = (3 * static_cast<size_t>(H) * d->K + H * DS + H * PQ * 3 + H * PV * 3 + H + F) * sizeof(float);
@@ -1845,8 +1934,10 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
       gw.n_end[q] = gd.n_end[q] = col;
       segs_ok = segs_ok && Ns[q] % 64 == 0 && (reinterpret_cast<uintptr_t>(Ws[q]) & 15) == 0;
     }
+    side.before_write(dnxt);  // (to_out's weight gradient of layer l + 1 read it as its d y)
     if (segs_ok) {  // the six projections as ONE weight-gradient product and ONE input-gradient product over the 1344-wide dproj
-      if (int rc = gemm_tn(dproj, NP, xin, D, nullptr, D, rows, NP, D, st, &gd)) return rc;
+      if (int rc = gemm_tn(dproj, NP, xin, D, nullptr, D, rows, NP, D, side.begin(), &gd)) return rc;
+      side.reads(dproj);
       if (planes && NP % 32 == 0 && rowgemm128_b6_ok(dproj, NP, dnxt, D, rows, NP)) {
         // dx = dproj [W_q_s; ...; W_v_p] as Y = X W'^T with W'[n][k] = W_seg[k - k0][n]: six strided splits into one set of planes
         if (int rc = launch_wsplit128_segs(Ws, gw.n_end, 6, planes, st)) return rc;
@@ -1857,7 +1948,7 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     } else {
       col = 0;
       for (int q = 0; q < 6; ++q) {
-        if (int rc = linear_bwd(dproj + col, NP, xin, D, Ws[q], dWs[q], nullptr, dnxt, D, rows, Ns[q], D, q > 0, st)) return rc;
+        if (int rc = linear_bwd(dproj + col, NP, xin, D, Ws[q], dWs[q], nullptr, dnxt, D, rows, Ns[q], D, q > 0, st)) return rc;  // (generic dims: on the chain)
         col += Ns[q];
       }
     }
@@ -1868,11 +1959,12 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     return DIFFAB_OK;
   }
   // ---- to_res_emb (Linear-ReLU-Linear) and the sequence embedding
+  side.before_write(dnxt);
   if (int rc = linear_bwd(dcur, D, tp.h1, D, w->res_w2, const_cast<float*>(g->res_w2), const_cast<float*>(g->res_b2), dnxt, D, rows, D, D,
-                          false, st)) return rc;
+                          false, st, &side)) return rc;
   if (int rc = relu_mask(dnxt, tp.h1, static_cast<int64_t>(rows) * D, st)) return rc;
   if (int rc = linear_bwd(dnxt, D, tp.cat2, 2 * D, w->res_w0, const_cast<float*>(g->res_w0), const_cast<float*>(g->res_b0), dcat2, 2 * D,
-                          rows, D, 2 * D, false, st)) return rc;
+                          rows, D, 2 * D, false, st, &side)) return rc;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, st, dcat2, seq_t, D, static_cast<int64_t>(rows), d_res_ctx,
                      const_cast<float*>(g->seq_emb));
   DIFFAB_LAUNCH_CHECK();
