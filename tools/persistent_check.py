@@ -99,6 +99,25 @@ if os.environ.get("STAMPS", "0") != "0":
     start = (ph[:, 0, 0] - t00) * tick
     print(f"  per work-group: own time min {dur.min():.0f} mean {dur.mean():.0f} max {dur.max():.0f} us; start min {start.min():.0f} max {start.max():.0f} us")
     print("  own time by XCD (work-group % 8): " + " ".join(f"{float(dur[x::8].mean()):.0f}" for x in range(8)))
+    if os.environ.get("STAMPS") == "2":  # is a work-group's lateness systematic (the same CUs every launch) or drawn anew per launch?
+        durs, fins = [dur], [(ph[:, -1, 3] - t00) * tick]
+        for rep in range(3):
+            stamps.zero_()
+            lib.diffab_debug_set_module_stamps(_hip.ptr(stamps))
+            loop(st, model.T - 40 - rep, 1, P)
+            torch.cuda.synchronize()
+            lib.diffab_debug_set_module_stamps(None)
+            ph2 = stamps[n_att:].view(B, NL, 4).cpu().double()
+            durs.append((ph2[:, -1, 3] - ph2[:, 0, 0]) * tick)
+            fins.append((ph2[:, -1, 3] - ph2[:, 0, 0].min()) * tick)
+        D = torch.stack(durs)
+        print("  four stamped launches: own time mean " + " ".join(f"{float(d.mean()):.0f}" for d in durs) + " | max " +
+              " ".join(f"{float(d.max()):.0f}" for d in durs) + " | launch end (last finish) " + " ".join(f"{float(f_.max()):.0f}" for f_ in fins))
+        cc = torch.corrcoef(D)
+        print("  correlation of the per-work-group own times between launches: " + " ".join(f"{float(cc[0, j]):.2f}" for j in range(1, 4)) +
+              f" | mean over launches per work-group: min {float(D.mean(0).min()):.0f} max {float(D.mean(0).max()):.0f} (systematic spread) vs "
+              f"sum of the four launch maxima {float(D.max(1).values.sum()):.0f} against max of the four-launch sums {float(D.sum(0).max()):.0f} "
+              f"(what a trajectory-resident work-group would pay)")
     print("  own time by stagger class ((work-group / 8) % 8): " + " ".join(f"{float(dur[[i for i in range(B) if (i // 8) % 8 == c]].mean()):.0f}" for c in range(8)))
     print("  finish time by stagger class: " + " ".join(f"{float(((ph[:, -1, 3] - t00) * tick)[[i for i in range(B) if (i // 8) % 8 == c]].mean()):.0f}" for c in range(8)))
     w0 = s[:, :, :, 0, :]  # wave 0
