@@ -23,6 +23,7 @@
 #include "denoiser_internal.h"
 #include "rowgemm_b6_tile.h"
 #include "ipa_attn_tile.h"
+#include "attn_planes_tile.h"
 
 namespace diffab {
 
@@ -594,6 +595,19 @@ void ipa_ws_value_planes(const diffab_dims* d, float* ws, float** vpl, float** v
   *vsc = *vpl + proj_value_planes_floats(static_cast<int64_t>(d->B) * d->K);
 }
 
+// the value side of every patch as fp16 planes (attn_planes_tile.h): one work-group per patch
+__global__ __launch_bounds__(512) void attn_value_planes_kernel(const float* __restrict__ proj, const float* __restrict__ t, int K,
+                                                                _Float16* __restrict__ vpl, float* __restrict__ osc) {
+  extern __shared__ __attribute__((aligned(16))) float ap_lds[];
+  aplanes::attn_value_planes_tile(ap_lds, threadIdx.x, blockIdx.x, proj, t, K, vpl, osc);
+}
+int launch_attn_value_planes(const diffab_dims* d, const float* proj, const float* t, float* vpl, float* vsc, hipStream_t st) {
+  DIFFAB_REQUIRE(proj && t && vpl && vsc && d->K % 32 == 0 && fast_path_supported(d), DIFFAB_ERR_ARG, "attn_value_planes: unsupported operands");
+  hipLaunchKernelGGL(attn_value_planes_kernel, dim3(d->B), dim3(512), aplanes::LDS_BYTES, st, proj, t, d->K, reinterpret_cast<_Float16*>(vpl), vsc);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, const float* x, const float* e, const float* R, const float* t,
                    float* y, float* ws, hipStream_t st, float* sp_keep, float* d2_keep, const void* planes, const float* pair_planes,
                    bool fp32_gemm, bool taped, const unsigned char* tile_needed) {
@@ -634,17 +648,17 @@ int ipa_layer_fast(const diffab_dims* d, const diffab_ipa_layer_weights* w, cons
   bool vec = aligned16(x);
   for (int s = 0; s < 6; ++s) vec = vec && aligned16(segs.W[s]);
   DIFFAB_REQUIRE(vec, DIFFAB_ERR_ARG, "ipa_layer_fast: x and the projection weights must be 16-byte aligned");
-  // Value planes (round 6, opt-in: diffab_debug_set_attn_variant(16)): with the pair planes AND the fp16 x 3 projections (inference, not the
-  // training tape: its backward reads the fp32 value columns) the projection tile leaves the value side as fp16 planes for the attention
-  // tile's P x V product on the f16 matrix cores.  Parity-green and 5 % faster for the attention launch, but the plane stores cost the
-  // projection tile more than that (profiles/r06_attention.md): not the default.
+  // Value planes (round 6, diffab_debug_set_attn_variant(16)): with the pair planes (inference) a small kernel cuts the value side of the
+  // fresh projection rows into fp16 planes (attn_planes_tile.h) and the attention tile's P x V product runs on the f16 matrix cores.
   const bool vpl_on = h3 && !taped && sp_keep == nullptr && pair_planes != nullptr && pair_planes_supported(d) && g_attn_variant != 1 &&
                       d->K % 32 == 0 && g_value_planes;
   float* vpl = nullptr;
   float* vsc = nullptr;
   if (vpl_on) ipa_ws_value_planes(d, ws, &vpl, &vsc);
   if (h3) {
-    if (int rc = launch_proj_frames_h3p(x, plc + ipa_layer_h3_pj_offset(), wis, R, t, proj, rows, st, vpl, vsc, d->K)) return rc;
+    if (int rc = launch_proj_frames_h3p(x, plc + ipa_layer_h3_pj_offset(), wis, R, t, proj, rows, st)) return rc;
+    if (vpl_on)
+      if (int rc = launch_attn_value_planes(d, proj, t, vpl, vsc, st)) return rc;
   } else if (b6) {
     if (int rc = launch_proj_frames_b6p(x, planes, R, t, proj, rows, st)) return rc;
   } else {

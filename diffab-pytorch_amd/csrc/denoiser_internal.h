@@ -104,8 +104,8 @@ int launch_pjsplit_h3(const float* const* W6, void* planes, float* wis, hipStrea
 int launch_rowgemm128_h3p(const float* X, int ldx, const void* planes, const float* wis, const float* bias, const int64_t* bias_idx, int bias_div,
                           float* Y, int ldy, int M, int Kd, bool relu, hipStream_t st, float* parts = nullptr);
 int launch_proj_frames_h3p(const float* x, const void* planes, const float* wis, const float* R, const float* t, float* proj, int rows,
-                           hipStream_t st, void* vpl = nullptr, float* vsc = nullptr, int Kres = 128);  // vpl / vsc: the value side as fp16 planes
-size_t proj_value_planes_floats(int64_t rows);   // (proj_frames_h3_tile.h "Value planes"; consumer: ipa_attn_tile.h phase 3, VPL)
+                           hipStream_t st);
+size_t proj_value_planes_floats(int64_t rows);   // (attn_planes_tile.h; consumer: ipa_attn_tile.h phase 3, VPL)
 size_t proj_value_scales_floats(int64_t rows);
 int ipa_layer_split_weights(const diffab_ipa_layer_weights* w, void* planes, hipStream_t st);
 // ipa_persistent.hip: all NL layers of the IPA module for K = 128 patches as ONE patch-resident launch (one work-group owns a patch

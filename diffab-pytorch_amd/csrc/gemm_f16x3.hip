@@ -83,9 +83,8 @@ __global__ __launch_bounds__(256) void rowgemm128_h3_parts_sum_kernel(const floa
 }
 
 size_t rowgemm128_h3_planes_bytes(int Kd) { return static_cast<size_t>(2) * 128 * Kd * sizeof(_Float16); }
-// (Kd a multiple of 64: the tile joins its chunks of 32 k in PAIRS - one X scale per (row, 64 k) - and has no path for a trailing odd chunk)
 bool rowgemm128_h3_ok(const float* X, int ldx, const float* Y, int ldy, int M, int Kd) {
-  return Kd % (BK * h3tile::PART_CHUNKS) == 0 && Kd >= BK * h3tile::PART_CHUNKS && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+  return Kd % BK == 0 && Kd >= BK && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && M >= 1;
 }
 // planes: rowgemm128_h3_planes_bytes(Kd) bytes, 16-byte aligned; wis: 128 floats
@@ -162,12 +161,7 @@ __global__ __launch_bounds__(64) void pjsplit_h3_kernel(const float* __restrict_
   for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
   float s, is;
   h3_scale(m, s, is);
-  if (lane == 0) {
-    wis[gc] = is;
-    // the largest 1 / scale of each 48-column group (powers of two: compared as integers), behind the 1344 + 128 per-column values:
-    // the bound behind the value planes' scales (proj_frames_h3_tile.h)
-    atomicMax(reinterpret_cast<unsigned*>(wis + PJ_NP + 128) + gc / 48, __float_as_uint(is));
-  }
+  if (lane == 0) wis[gc] = is;
   const int blk = gc / PJ_B, rem = gc % PJ_B, cwl = rem / 48, r48 = rem % 48, j = r48 / 3, tt = r48 % 3;
   const int lrow = 48 * cwl + 16 * tt + j;
 #pragma unroll
@@ -180,22 +174,20 @@ __global__ __launch_bounds__(64) void pjsplit_h3_kernel(const float* __restrict_
   }
 }
 
-template <bool FULL, bool SPLIT, bool VPL>
+template <bool FULL, bool SPLIT>
 __global__ __launch_bounds__(512) void proj_frames_h3_kernel(const float* __restrict__ X, const _Float16* __restrict__ Wc, const float* __restrict__ wis,
-                                                             const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ Y, int M,
-                                                             _Float16* __restrict__ vpl, float* __restrict__ vsc, int Kres) {
+                                                             const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ Y, int M) {
   extern __shared__ __attribute__((aligned(16))) _Float16 pj_lds[];
-  pjh3::proj_frames_h3_tile<FULL, SPLIT, VPL>(pj_lds, threadIdx.x, blockIdx.x, blockIdx.y, gridDim.y, X, Wc, wis, R, t, Y, M, vpl, vsc, Kres);
+  pjh3::proj_frames_h3_tile<FULL, SPLIT>(pj_lds, threadIdx.x, blockIdx.x, blockIdx.y, gridDim.y, X, Wc, wis, R, t, Y, M);
 }
-// value planes of the attention tile's P x V product (proj_frames_h3_tile.h): floats of workspace for `rows` projection rows, Kres per patch
-size_t proj_value_planes_floats(int64_t rows) { return static_cast<size_t>(rows) * 512; }  // 8 heads x 4 tiles x 16 columns x 2 planes x 2 bytes per row
-size_t proj_value_scales_floats(int64_t rows) { return (static_cast<size_t>(rows / 32 + 1) * pjh3::VPL_GROUPS + 63) & ~static_cast<size_t>(63); }
 
+// operand planes of the attention tile (attn_planes_tile.h): floats of workspace for `rows` projection rows
+size_t proj_value_planes_floats(int64_t rows) { return static_cast<size_t>(rows) * 512; }  // V: 8 heads x 4 tiles x 16 columns x 2 planes x 2 bytes per row
+size_t proj_value_scales_floats(int64_t rows) { return (static_cast<size_t>(rows / 32 + 1) * 64 + 63) & ~static_cast<size_t>(63); }
 size_t proj_frames_h3_planes_bytes() { return static_cast<size_t>(2 * pjh3::PJ_NB) * pjh3::PJ_STAGE_ELEMS * sizeof(_Float16); }
 // W6 = {wq_s, wk_s, wv_s, wq_p, wk_p, wv_p} -> stage-ordered planes (proj_frames_h3_planes_bytes(), 16-byte aligned) + wis[1344]
 int launch_pjsplit_h3(const float* const* W6, void* planes, float* wis, hipStream_t st) {
   DIFFAB_REQUIRE(planes && wis && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, DIFFAB_ERR_ARG, "pjsplit_h3: bad operands");
-  DIFFAB_HIP_CHECK(hipMemsetAsync(wis + pjh3::PJ_NP + 128, 0, pjh3::VPL_GROUPS * sizeof(float), st));  // the group maxima (atomicMax below)
   hipLaunchKernelGGL(pjsplit_h3_kernel, dim3(pjh3::PJ_NP), dim3(64), 0, st, W6[0], W6[1], W6[2], W6[3], W6[4], W6[5],
                      static_cast<_Float16*>(planes), wis);
   DIFFAB_LAUNCH_CHECK();
@@ -203,7 +195,7 @@ int launch_pjsplit_h3(const float* const* W6, void* planes, float* wis, hipStrea
 }
 // the six projections of one IPA layer (D = 128) into proj[rows x 1344]
 int launch_proj_frames_h3p(const float* x, const void* planes, const float* wis, const float* R, const float* t, float* proj, int rows,
-                           hipStream_t st, void* vpl, float* vsc, int Kres) {
+                           hipStream_t st) {
   using namespace pjh3;
   DIFFAB_REQUIRE(planes && wis && R && t && (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(proj) & 3) == 0 && rows >= 1,
@@ -213,22 +205,18 @@ int launch_proj_frames_h3p(const float* x, const void* planes, const float* wis,
   int nsplit = 256 / ntiles;  // half the chip or less: several groups per row tile, each with its share of the column blocks
   nsplit = nsplit < 1 ? 1 : (nsplit > PJ_NB ? PJ_NB : nsplit);
   const dim3 grid(ntiles, nsplit);
-#define PJH3_LAUNCH(FULL_, SPLIT_, VPL_)                                                                                                  \
+#define PJH3_LAUNCH(FULL_, SPLIT_)                                                                                                    \
   do {                                                                                                                                \
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_h3_kernel<FULL_, SPLIT_, VPL_>),                    \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_frames_h3_kernel<FULL_, SPLIT_>),                          \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, PJ_LDS_BYTES));                                   \
-    hipLaunchKernelGGL((proj_frames_h3_kernel<FULL_, SPLIT_, VPL_>), grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, wis, R, t, proj, rows,  \
-                       static_cast<_Float16*>(vpl), vsc, Kres);                                                                        \
+    hipLaunchKernelGGL((proj_frames_h3_kernel<FULL_, SPLIT_>), grid, dim3(512), PJ_LDS_BYTES, st, x, Wc, wis, R, t, proj, rows);        \
   } while (0)
-  const bool v = vpl != nullptr;
-  DIFFAB_REQUIRE(!v || (vsc != nullptr && Kres >= 32 && Kres % 32 == 0 && rows % Kres == 0 && (reinterpret_cast<uintptr_t>(vpl) & 15) == 0),
-                 DIFFAB_ERR_ARG, "proj_frames_h3: value planes need K %% 32 == 0 and a 16-byte aligned buffer");
   if (rows % PJ_ROWS == 0) {
-    if (nsplit > 1) { if (v) PJH3_LAUNCH(true, true, true); else PJH3_LAUNCH(true, true, false); }
-    else { if (v) PJH3_LAUNCH(true, false, true); else PJH3_LAUNCH(true, false, false); }
+    if (nsplit > 1) PJH3_LAUNCH(true, true);
+    else PJH3_LAUNCH(true, false);
   } else {
-    if (nsplit > 1) { if (v) PJH3_LAUNCH(false, true, true); else PJH3_LAUNCH(false, true, false); }
-    else { if (v) PJH3_LAUNCH(false, false, true); else PJH3_LAUNCH(false, false, false); }
+    if (nsplit > 1) PJH3_LAUNCH(false, true);
+    else PJH3_LAUNCH(false, false);
   }
 #undef PJH3_LAUNCH
   DIFFAB_LAUNCH_CHECK();

@@ -100,9 +100,9 @@ __device__ __forceinline__ void attn_p1_request(AttnP1Pre<SD>& pre, const int pi
 // NW: waves of the work-group (8: wave = head in phases 1 and 3, two rows in phase 2; 4: two heads / four rows per wave - the form that
 // fits two work-groups on a CU: with the 64-key chunk image its LDS is 79.5 KiB, and the two groups' phases interleave on the CU's pipes).
 // VPL (with PLANES, NW = 8; round 6): phase 3 (P x V) runs on the f16 matrix cores as well.  The value side arrives as two fp16 planes in
-// fragment order, written by the projection tile (proj_frames_h3_tile.h, "Value planes": per (patch, head, 32-key step) the four 16-column
-// tiles [v_s 0..15 | v_s 16..31 | x, y of the 8 points | z of the 8 points + a ones column], one power-of-two scale per (32-key step,
-// 48-column group) in vsc, point coordinates relative to the patch's first translation); the probabilities are split into two fp16 planes
+// fragment order, cut once per (patch, layer) by attn_planes_tile.h (per (patch, head, 32-key step) the four 16-column tiles [v_s 0..15 |
+// v_s 16..31 | x, y of the 8 points | z of the 8 points + a ones column], one power-of-two scale per (head, step) and kind in vsc, point
+// coordinates relative to the patch's first translation); the probabilities are split into two fp16 planes
 // on the fly (2^15 P = p1 + p2): three exact partial products per tile and 32 keys - 12 MFMAs of 16 cycles per (head, 32 keys) against 32
 // f32 MFMAs of 32 cycles (which also block the vector ALU), 8 linear 1 KiB loads per 32 keys straight into B fragments, no LDS staging.
 template <int NT, bool MULTI, bool PLANES = false, bool TAPE = false, int NW = 8, bool VPL = false>
@@ -682,15 +682,13 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
       for (int T = 0; T < TPC; ++T)
 #pragma unroll
         for (int u = 0; u < 8; ++u) vf[T][u] = vsrc[(T * 8 + u) * 64];
-      // 1 / s of the three 48-column groups the head's tiles sit in, per step (wave-uniform: scalar loads); x 2^-15 for the scaled P
-      const float* scp = vsc + (static_cast<int64_t>(b) * Tsteps + c * TPC) * 28;
-      const int g_os0 = (512 + 32 * h) / 48, g_os1 = (528 + 32 * h) / 48, g_pt = (1152 + 24 * h) / 48;
+      // 1 / s of the head's v_s and point planes, per step (wave-uniform: scalar loads); x 2^-15 for the scaled P
+      const float* scp = vsc + ((static_cast<int64_t>(b) * AH + h) * Tsteps + c * TPC) * 2;
       float isc[TPC][3];
 #pragma unroll
       for (int T = 0; T < TPC; ++T) {
-        isc[T][0] = scp[T * 28 + g_os0] * (1.0f / 32768.0f);
-        isc[T][1] = scp[T * 28 + g_os1] * (1.0f / 32768.0f);
-        isc[T][2] = scp[T * 28 + g_pt] * (1.0f / 32768.0f);
+        isc[T][0] = isc[T][1] = scp[2 * T] * (1.0f / 32768.0f);
+        isc[T][2] = scp[2 * T + 1] * (1.0f / 32768.0f);
       }
       MEM_FENCE();
       __syncthreads();  // exp(logit - M) of all rows and the rescale factors are in LDS (the value fragments arrive during the wait)

@@ -15,6 +15,7 @@
 #include "denoiser_internal.h"
 #define AT_STAMP_REALTIME 1  // the diagnostic stamps of this file's kernels use the chip-wide 100 MHz counter (comparable between CUs)
 #include "ipa_attn_tile.h"
+#include "attn_planes_tile.h"
 #include "proj_frames_h3_tile.h"
 #include "rowgemm_h3_tile.h"
 #include "mlp_chain_tile.h"
@@ -92,15 +93,9 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       for (int dt = 0; dt < DT; ++dt) {  // ---- the six projections + frames of the patch's rows, 128 at a time
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (an opaque copy per phase: lane-constant addresses must not stay live across the phases)
-        if constexpr (VPL)
-          pjh3::proj_frames_h3_tile<true, false, true>(reinterpret_cast<_Float16*>(lds), tid, b * DT + dt, 0, 1, xin,
-                                                       reinterpret_cast<const _Float16*>(lp + a.pj_off),
-                                                       reinterpret_cast<const float*>(lp + a.wis_off), a.R, a.t, a.proj, M,
-                                                       reinterpret_cast<_Float16*>(a.vpl), a.vsc, K);
-        else
-          pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b * DT + dt, 0, 1, xin,
-                                                 reinterpret_cast<const _Float16*>(lp + a.pj_off), reinterpret_cast<const float*>(lp + a.wis_off),
-                                                 a.R, a.t, a.proj, M);
+        pjh3::proj_frames_h3_tile<true, false>(reinterpret_cast<_Float16*>(lds), tid, b * DT + dt, 0, 1, xin,
+                                               reinterpret_cast<const _Float16*>(lp + a.pj_off), reinterpret_cast<const float*>(lp + a.wis_off),
+                                               a.R, a.t, a.proj, M);
         if (dt + 1 < DT) {  // the next tile's weight stages overwrite this one's LDS
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
@@ -108,9 +103,16 @@ __global__ __launch_bounds__(512) void ipa_module_persistent_kernel(const Module
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      // the value-plane scales of this layer were just written (vector stores) over the previous layer's at the same addresses and are read
-      // through the SCALAR cache by phase 3 of the attention tiles: drop its lines (the vector L1 needs nothing: same CU, written through)
-      if constexpr (VPL) __builtin_amdgcn_s_dcache_inv();
+      if constexpr (VPL) {  // ---- the value side of the patch as fp16 planes for phase 3 of its attention items (attn_planes_tile.h)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        aplanes::attn_value_planes_tile(lds, tid, b, a.proj, a.t, K, reinterpret_cast<_Float16*>(a.vpl), a.vsc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // the scales were written (vector stores) over the previous layer's at the same addresses and are read through the SCALAR cache
+        // by phase 3: drop its lines (the vector L1 needs nothing: same CU, written through)
+        __builtin_amdgcn_s_dcache_inv();
+      }
       pstamp(b, l, 1);
       // ---- attention: the eight row tiles of the patch
 #pragma unroll 1

@@ -13,7 +13,6 @@
 
 namespace diffab {
 namespace pjh3 {
-using h3tile::f16x4;
 using h3tile::f16x8;
 using h3tile::f32x4;
 using h3tile::h3_scale;
@@ -33,37 +32,14 @@ __device__ __forceinline__ float mul1(float a, float b) {
   return r;
 }
 
-// Value planes (VPL, round 6).  The attention tile's P x V product (ipa_attn_tile.h, phase 3) runs on the f16 matrix cores from the VALUE side
-// (v_s: columns 512..767, global value points: 1152..1343) as two fp16 planes in the fragment order of v_mfma_f32_16x16x32_f16's B operand:
-// per (patch, head, key step T of 32 keys) an 8 KiB block [tile u: v_s 0..15 | v_s 16..31 | x of the 8 points, y of the 8 points | z of the 8
-// points, a column of ones, 7 unused columns][plane h1, h2][lane n + 16 g][8 keys], k slot e = 4 mt + r of lane group g <-> key 32 T + 16 mt + 4 g + r
-// - exactly the eight values of a column that a lane of this tile's accumulators holds for its 32-row slab, so a finished value block
-// (blocks 5..7 and 12, 13) leaves the tile as twelve 8-byte stores per lane (an m tile's four k slots at a time).  Scale: one power of two
-// per (32-key slab, 48-column group of a wave) that puts a BOUND of the group's magnitudes into [2^13, 2^14) (see the tile body; v s =
-// h1 + h2 to 2^-22 of each value down to 2^-17 of that bound); 1 / s goes to vsc[(patch * K / 32 + T) * 28 + column / 48].  Point coordinates are taken relative to the patch's FIRST
-// translation (the consumer adds it back through the probability mass the ones column returns): the planes resolve 2^-22 of a patch's
-// spread, not of its distance from the origin.  The fp32 columns of the value blocks are not written any more (block 5, which also
-// holds the last k_s columns, still is).
-constexpr int VPL_GROUPS = PJ_NP / 48;                                    // 28 scale slots per (patch, key step)
-constexpr int VPL_STEP_HALVES = 4 * 2 * 64 * 8;                           // fp16 per (patch, head, key step): 8 KiB
-__host__ __device__ constexpr bool vpl_value_block(int blk) { return (blk >= 5 && blk <= 7) || blk >= 12; }
-// power-of-two scale that puts m into [2^13, 2^14); is = 1 / s (both exact); m = 0, tiny or huge: no scaling
-__device__ __forceinline__ void vpl_scale(float m, float& s, float& is) {
-  const int e = static_cast<int>((__float_as_uint(m) >> 23) & 255u);
-  const bool ok = e >= 16 && e < 240;
-  s = ok ? __uint_as_float(static_cast<unsigned>(127 + 13 + 127 - e) << 23) : 1.0f;
-  is = ok ? __uint_as_float(static_cast<unsigned>(e - 13) << 23) : 1.0f;
-}
-
 // One 128-row tile (rows tile_m * 128 ..).  512 threads; pj_lds: PJ_LDS_BYTES, 16-byte aligned; Wc: stage-ordered planes of pjsplit_h3
 // ([(block 2 + k half)][2 planes][96][64] fp16), wis[1344]: 1 / scale of every output column; split_i of split_n work-groups share the
-// column blocks of the tile (each re-reads the x rows).  VPL: vpl / vsc as above, Kres = residues per patch (a multiple of 32).
-template <bool FULL, bool SPLIT = false, bool VPL = false>  // FULL: M is a multiple of 128, no row guards
+// column blocks of the tile (each re-reads the x rows).
+template <bool FULL, bool SPLIT = false>  // FULL: M is a multiple of 128, no row guards
 __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_lds, const int tid, const int tile_m, const int split_i,
                                                     const int split_n, const float* __restrict__ X, const _Float16* __restrict__ Wc,
                                                     const float* __restrict__ wis, const float* __restrict__ R, const float* __restrict__ t,
-                                                    float* __restrict__ Y, int M, _Float16* __restrict__ vpl = nullptr,
-                                                    float* __restrict__ vsc = nullptr, int Kres = 128) {
+                                                    float* __restrict__ Y, int M) {
   constexpr int NB = PJ_NB, ldy = PJ_NP, frames_from = PJ_GQ / PJ_B;
   const int blk0 = SPLIT ? (NB * split_i) / split_n : 0;
   const int blk1 = SPLIT ? (NB * (split_i + 1)) / split_n : NB;
@@ -97,7 +73,6 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
   load_w(2 * blk0);
   // A fragments (v_mfma_f32_16x16x32_f16: lane = row l15, k group g): a[mt][q][piece] of x[m0 + 32 rw + 16 mt + l15][32 q + 8 g .. + 7] s_row
   f16x8 a[2][4][2];
-  float v_isx_acc = 0.0f;  // VPL: the largest 1 / s_x of the wave's 32 rows
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = m0 + 32 * rw + 16 * mt + l15;
@@ -119,7 +94,6 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
     float s, is;
     h3_scale(m, s, is);
     if (g == 0) Sx[32 * rw + 16 * mt + l15] = is;
-    if constexpr (VPL) v_isx_acc = fmaxf(v_isx_acc, is);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -143,37 +117,6 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
   __syncthreads();
 
   // one (mt, r) slice of a finished block: 3 consecutive columns of one row per lane; wsc: 1 / scale of the lane's three columns
-  // VPL: the plane cut of a value block happens inside its eight epilogue slices.  The power-of-two scale of a (32-row slab, 48-column
-  // group) is not found from the values (a maximum over the wave in the middle of the MFMA loop: cross-lane round trips, and every value
-  // would have to stay in registers until it is known) but from a BOUND known before the block's first MFMA: the accumulators of the
-  // split product are sums of 128 products of operands below 256 (h3_scale), so |acc| <= 2^23 and |value| <= 2^23 (1 / s_x)(1 / s_w) -
-  // with the largest 1 / s_x of the slab's rows (v_isx, prologue) and the largest 1 / s_w of the group's columns (gmx, written next to
-  // wis by pjsplit_h3); a global point adds the largest |t_j - c| of the slab's rows (v_tc).  The bound is loose by 2^6 .. 2^10, which
-  // the [2^13, 2^14) target absorbs: fp16 keeps both pieces of a value normal down to 2^-3, i.e. 2^-17 of the bound.
-  const int v_row0 = __builtin_amdgcn_readfirstlane(m0 + 32 * rw);  // first key of the wave's 32-row slab
-  const int v_cw = __builtin_amdgcn_readfirstlane(cw);
-  const int v_patch = VPL ? v_row0 / Kres : 0;
-  const int v_T = VPL ? (v_row0 - v_patch * Kres) >> 5 : 0, v_steps = Kres >> 5;
-  const bool v_on = VPL && (FULL || v_row0 < M);
-  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;  // the patch's first translation (wave-uniform: scalar loads)
-  float v_isx = v_isx_acc, v_tc = 0.f, v_s = 1.0f;
-  if constexpr (VPL) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v_isx = fmaxf(v_isx, __shfl_xor(v_isx, o));  // (the four k groups of a row hold the same value)
-    if (v_on) {
-      const float* tc = t + static_cast<int64_t>(v_patch) * Kres * 3;
-      vc0 = tc[0]; vc1 = tc[1]; vc2 = tc[2];
-      const float* tr = t + static_cast<int64_t>(v_row0 + (lane & 31)) * 3;
-      v_tc = fmaxf(fmaxf(fabsf(tr[0] - vc0), fabsf(tr[1] - vc1)), fabsf(tr[2] - vc2));
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) v_tc = fmaxf(v_tc, __shfl_xor(v_tc, o));
-    }
-  }
-  // the four k slots of one m tile, cut two at a time and packed: [plane][column tt][pair] of two fp16 each; xe: the even slot's values
-  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2v __attribute__((ext_vector_type(2)));
-  f16x2 vp[2][3][2];
-  float xe[3];
   auto epilogue_piece = [&](const f32x4 (&acc)[2][3], const pj_f3 wsc, int blk, int piece) {
     const int mt = piece >> 2, r = piece & 3;
     const int lrow = 32 * rw + 16 * mt + 4 * g + r;
@@ -192,64 +135,6 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
       ox = __builtin_fmaf(vz, f1[2], __builtin_fmaf(vy, f0[3], mul1(vx, f0[0]))) + f2[1];
       oy = __builtin_fmaf(vz, f1[3], __builtin_fmaf(vy, f1[0], mul1(vx, f0[1]))) + f2[2];
       oz = __builtin_fmaf(vz, f2[0], __builtin_fmaf(vy, f1[1], mul1(vx, f0[2]))) + f2[3];
-    }
-    if constexpr (VPL) {
-      if (vpl_value_block(blk)) {
-        const bool pt = blk >= frames_from;
-        if (piece == 0) {  // the block's scale from its bound (wave-uniform), published for phase 3 of the attention tiles
-          const float gmx = wis[PJ_NP + 128 + 2 * blk + v_cw];
-          const float vb = 8388608.0f * v_isx * gmx;
-          float is;
-          vpl_scale(pt ? 3.0f * vb + v_tc : vb, v_s, is);
-          if (v_on && lane == 0) vsc[(static_cast<int64_t>(v_patch) * v_steps + v_T) * VPL_GROUPS + 2 * blk + v_cw] = is;
-        }
-        const float x3[3] = {pt ? ox - vc0 : ox, pt ? oy - vc1 : oy, pt ? oz - vc2 : oz};
-#pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
-          const float xs = mul1(x3[tt], v_s);
-          if ((r & 1) == 0) {
-            xe[tt] = xs;
-          } else {
-            const f32x2v x2 = {xe[tt], xs};
-            const f16x2 h1 = __builtin_convertvector(x2, f16x2);
-            const f32x2v rem = {mul1(1.0f, x2[0] - static_cast<float>(h1[0])), mul1(1.0f, x2[1] - static_cast<float>(h1[1]))};
-            vp[0][tt][r >> 1] = h1;
-            vp[1][tt][r >> 1] = __builtin_convertvector(rem, f16x2);
-          }
-        }
-        if (r == 3 && v_on) {  // the m tile's four k slots e = 4 mt + r of the lane's three columns: six 8-byte stores
-#pragma unroll
-          for (int tt = 0; tt < 3; ++tt) {
-            int h, u, n;
-            bool val = true;
-            if (pt) {
-              const int pi = 32 * (blk - 12) + 16 * cw + l15;  // point index among the 64 value points of a row
-              h = pi >> 3;
-              u = tt == 2 ? 3 : 2;
-              n = (pi & 7) + (tt == 1 ? 8 : 0);
-            } else {
-              const int cc = PJ_B * blk + col0 + tt - 512;  // (block 5: columns 480..511 are k_s)
-              val = cc >= 0;
-              h = (cc >> 5) & 7;
-              u = (cc >> 4) & 1;
-              n = cc & 15;
-            }
-            if (val) {
-              _Float16* dst = vpl + (((static_cast<int64_t>(v_patch) * 8 + h) * v_steps + v_T) * 4 + u) * 1024 + (n + 16 * g) * 8 + 4 * mt;
-              *reinterpret_cast<f16x4*>(dst) = f16x4{vp[0][tt][0][0], vp[0][tt][0][1], vp[0][tt][1][0], vp[0][tt][1][1]};
-              *reinterpret_cast<f16x4*>(dst + 512) = f16x4{vp[1][tt][0][0], vp[1][tt][0][1], vp[1][tt][1][0], vp[1][tt][1][1]};
-            }
-          }
-          if (pt && mt == 1 && (l15 & 7) == 0) {  // column 8 of the z tile: ones in plane h1, zeros in h2 (-> the probability mass)
-            const int h = (32 * (blk - 12) + 16 * cw + l15) >> 3;
-            _Float16* dst = vpl + (((static_cast<int64_t>(v_patch) * 8 + h) * v_steps + v_T) * 4 + 3) * 1024 + (8 + 16 * g) * 8;
-            const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1}, zeros = {0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<f16x8*>(dst) = ones;
-            *reinterpret_cast<f16x8*>(dst + 512) = zeros;
-          }
-        }
-        if (blk != 5) return;  // (block 5 = the last 32 k_s columns + the first 64 v_s columns: its fp32 rows are still written)
-      }
     }
     if (FULL || m0 + lrow < M) {
       pj_f3 o{ox, oy, oz};

@@ -191,9 +191,9 @@ int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; pro
                                                  attention kernel (two per CU; measured slower), bit 2 (4) = the PairEmbedding forward / backward
                                                  as their unfused launches where the fused kernel would apply, 8 (alone) = the six
                                                  projections and to_out as six-term bf16 split products (rounds 3-4) instead of the
-                                                 three-term fp16 ones - per-layer launches only, bit 4 (16) = value planes: the projection
-                                                 tile writes the value side (v_s, global value points) as two fp16 planes and phase 3 of
-                                                 the attention tile (P x V) runs on the f16 matrix cores (parity-green, measured slower
+                                                 three-term fp16 ones - per-layer launches only, bit 4 (16) = value planes: a pass after the
+                                                 projections cuts the value side (v_s, global value points) into two fp16 planes and phase 3
+                                                 of the attention tile (P x V) runs on the f16 matrix cores (parity-green, measured slower
                                                  overall: profiles/r06_attention.md).  0 = defaults. */
 int diffab_debug_set_module_stagger(int32_t ticks_10ns, int32_t classes);
 int diffab_debug_set_module_stamps(void* device_buffer);
