@@ -412,9 +412,11 @@ __device__ __forceinline__ void ipa_attn_tile(float* __restrict__ S, const int b
         // the products had moved to the f16 matrix cores: phase 2 had become a wait for HBM latency, 38 k of its 20 k cycles.)
         // The probabilities go to LDS relative to the running maximum of their step and are rescaled to the row maximum after the row.
         char* trt = reinterpret_cast<char*>(scr);                                    // [2 tiles][2 planes][16 keys][128 bytes] = 8 KiB
-        const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)));      // ^ 64 ks: 8-byte unit 8 ks + 2 q of row l15
+        // (round 6: the row's low bit enters the swizzle too - without it rows 2 m and 2 m + 1 of an 8-lane store group shared their four
+        // banks: every ds_write_b128 of the pair tile was a 2-way conflict, half of the kernel's 26 % conflict cycles, SQ_LDS_BANK_CONFLICT)
+        const int wr_off = l15 * 128 + 8 * ((2 * q) ^ (4 * ((l15 >> 1) & 3)) ^ (2 * (l15 & 1)));  // ^ 64 ks: 8-byte unit 8 ks + 2 q of row l15
         const int rrow = 4 * q + (l15 >> 2);
-        const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)));  // ^ 32 ct: unit 4 ct + (l15 & 3) of row rrow
+        const int rd_off = rrow * 128 + 8 * ((l15 & 3) ^ (4 * ((rrow >> 1) & 3)) ^ (2 * (rrow & 1)));  // ^ 32 ct: unit 4 ct + (l15 & 3) of row rrow
 #pragma unroll
         for (int ii = 0; ii < RPW; ++ii) {
           const int il = RPW * wv + ii;  // local row
