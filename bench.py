@@ -377,9 +377,11 @@ def train_bench(args, model, dims, rank, world, dist):
     8(d)'s definition: the contexts are grad-requiring inputs, so the backward also produces d pair_ctx (107 MB of algorithmic
     traffic per patch-step).  The same step with constant contexts (no d pair_ctx: 56.6 MB per patch-step) is timed behind it and
     reported as `contexts_constant` with its own roofline fraction."""
-    from diffab_pytorch import distributed as D, synthetic as syn
+    from diffab_pytorch import _hip, distributed as D, synthetic as syn
 
     B, K = args.batch, args.k
+    if args.attn_variant:  # A/B switches (tools/ab_train.sh): 8 = the six-term bf16 form of the dense products
+        _hip.lib().diffab_debug_set_attn_variant(args.attn_variant)
     inp = syn.patches(B, K, dims, seed=2, first_patch=rank * B)
     batch = {"seq_idx": inp["seq_idx"].cuda(), "xyz": inp["translations"].cuda(), "orientations": inp["orientations"].cuda(),
              "generation_mask": inp["generation_mask"].cuda(), "residue_mask": inp["residue_mask"].cuda(),

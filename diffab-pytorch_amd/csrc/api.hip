@@ -418,6 +418,18 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
   return launch_rowgemm128_b6(X, Kd, W, Kd, bias, nullptr, 0, Y, 128, static_cast<int>(M), Kd, false, scratch, st);
 }
 
+int diffab_debug_xstat128(const float* X, const float* W, float* Y, int64_t M, int32_t N, int32_t mode, void* scratch, size_t scratch_bytes,
+                          void* stream) {
+  StreamOrder order_(stream);
+  DIFFAB_REQUIRE(X && W && Y && scratch && M >= 1 && M < (1LL << 31) && N >= 1 && (mode == 1 || mode == 2), DIFFAB_ERR_ARG,
+                 "debug_xstat128: bad operands");
+  const size_t need = mode == 1 ? xstat_b6_scratch_bytes(N) : xstat_h3_scratch_bytes(N);
+  DIFFAB_REQUIRE(scratch_bytes >= need && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
+                 DIFFAB_ERR_ARG, "debug_xstat128: needs 16-byte aligned X / scratch and %zu bytes of scratch", need);
+  hipStream_t st = as_stream(stream);
+  if (mode == 1) return launch_xstat_b6(X, W, 1, N, Y, N, static_cast<int>(M), N, scratch, st);
+  return launch_xstat_h3(X, W, 1, N, Y, N, static_cast<int>(M), N, scratch, st);
+}
 
 int diffab_set_stream_guard(int on) {
   set_stream_order(on != 0);

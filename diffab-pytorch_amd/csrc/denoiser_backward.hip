@@ -1706,8 +1706,9 @@ static size_t bwd_planes_floats(const diffab_dims* d) {
   const size_t NP = 3 * d->H * d->DS + 2 * d->H * d->PQ * 3 + d->H * d->PV * 3;
   const size_t F = d->H * d->DS + d->H * d->C + d->H * d->PV * 3 + d->H * d->PV;
   const size_t kmax = ((NP > F ? NP : F) + 31) / 32 * 32;
-  const size_t a = rowgemm128_b6_scratch_bytes(static_cast<int>(kmax)), b = xstat_b6_scratch_bytes(static_cast<int>(F));
-  return (a > b ? a : b) / sizeof(float) + 128;
+  const size_t a = rowgemm128_b6_scratch_bytes(static_cast<int>(kmax)), b = xstat_b6_scratch_bytes(static_cast<int>(F)),
+               c = xstat_h3_scratch_bytes(static_cast<int>(F));
+  return (a > b ? (a > c ? a : c) : (b > c ? b : c)) / sizeof(float) + 128;
 }
 size_t train_bwd_workspace_floats(const diffab_dims* d) {
   const size_t rows = static_cast<size_t>(d->B) * d->K, D = d->D;
@@ -1815,10 +1816,14 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     float* dproj = dprojs[l & 1];
     side.before_write(dproj);  // the projection weight gradient of layer l + 2 (beside the chain) read this buffer
     // to_out
-    if (planes && (reinterpret_cast<uintptr_t>(dcur) & 15) == 0) {  // d feat = d y W_out on the bf16x6 x-stationary kernel
+    if (planes && (reinterpret_cast<uintptr_t>(dcur) & 15) == 0) {  // d feat = d y W_out on the x-stationary kernel (fp16 x 3; bf16 x 6 under the A/B switch)
       if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), nullptr, F, rows, D,
                               F, false, st, &side)) return rc;
-      if (int rc = launch_xstat_b6(dcur, lw->w_out, 1, F, dfeat, F, rows, F, planes, st)) return rc;
+      if (dense_h3_enabled()) {
+        if (int rc = launch_xstat_h3(dcur, lw->w_out, 1, F, dfeat, F, rows, F, planes, st)) return rc;
+      } else if (int rc = launch_xstat_b6(dcur, lw->w_out, 1, F, dfeat, F, rows, F, planes, st)) {
+        return rc;
+      }
     } else if (int rc = linear_bwd(dcur, D, feat, F, lw->w_out, const_cast<float*>(lg->w_out), const_cast<float*>(lg->b_out), dfeat, F, rows,
                                    D, F, false, st, &side)) {
       return rc;

@@ -83,6 +83,8 @@ int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st);
 int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st);
 // the same x-stationary kernel as a plain product Y[rows x N] = X[rows x 128] W'^T, (n, k) of W' = W[n sn + k sk] (to_out input gradient)
 size_t xstat_b6_scratch_bytes(int N);
+size_t xstat_h3_scratch_bytes(int N);  // gemm_f16x3.hip: the same product as three fp16 terms
+int launch_xstat_h3(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st);
 int launch_xstat_b6(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st);
 // weight-gradient product C[N1 x N2] += A[M x N1]^T B[M x N2] (transposing LDS reads), any widths / row strides; rows of C optionally
 // spread over nseg matrices

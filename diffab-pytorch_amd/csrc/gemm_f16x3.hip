@@ -174,6 +174,42 @@ __global__ __launch_bounds__(64) void pjsplit_h3_kernel(const float* __restrict_
   }
 }
 
+// d feat = d y W (x-stationary, any N): the projection tile without frames (proj_frames_h3_tile.h, PROJ = false)
+template <bool FULL, bool SPLIT>
+__global__ __launch_bounds__(512) void xstat_h3_kernel(const float* __restrict__ X, const _Float16* __restrict__ Wc, const float* __restrict__ wis,
+                                                       float* __restrict__ Y, int M, int NB, int N, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 pj_lds[];
+  pjh3::proj_frames_h3_tile<FULL, SPLIT, false>(pj_lds, threadIdx.x, blockIdx.x, blockIdx.y, gridDim.y, X, Wc, wis, nullptr, nullptr, Y, M, NB, N, ldy);
+}
+// planes of a strided weight for xstat_h3_kernel: output column gc = W[gc sn + k sk], k < 128; columns N .. ncols - 1: zeros, wis 1.  The
+// layout of pjsplit_h3_kernel; one wave per column.
+__global__ __launch_bounds__(64) void xsplit_h3_kernel(const float* __restrict__ W, int64_t sn, int64_t sk, int N, _Float16* __restrict__ out,
+                                                       float* __restrict__ wis) {
+  using namespace pjh3;
+  const int gc = blockIdx.x, lane = threadIdx.x;
+  float v0 = 0.0f, v1 = 0.0f;
+  if (gc < N) {
+    v0 = W[gc * sn + lane * sk];
+    v1 = W[gc * sn + (64 + lane) * sk];
+  }
+  float m = fmaxf(fabsf(v0), fabsf(v1));
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s, is;
+  h3_scale(m, s, is);
+  if (lane == 0) wis[gc] = is;
+  const int blk = gc / PJ_B, rem = gc % PJ_B, cwl = rem / 48, r48 = rem % 48, j = r48 / 3, tt = r48 % 3;
+  const int lrow = 48 * cwl + 16 * tt + j;
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    _Float16 h1, h2;
+    split2((kh == 0 ? v0 : v1) * s, h1, h2);
+    const size_t base = (static_cast<size_t>(blk * 2 + kh) * 2 * PJ_B + lrow) * 64 + lane;
+    out[base] = h1;
+    out[base + PJ_B * 64] = h2;
+  }
+}
+
 template <bool FULL, bool SPLIT>
 __global__ __launch_bounds__(512) void proj_frames_h3_kernel(const float* __restrict__ X, const _Float16* __restrict__ Wc, const float* __restrict__ wis,
                                                              const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ Y, int M) {
@@ -219,6 +255,45 @@ int launch_proj_frames_h3p(const float* x, const void* planes, const float* wis,
     else PJH3_LAUNCH(false, false);
   }
 #undef PJH3_LAUNCH
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+// Y[rows x N] (leading dimension ldy) = X[rows x 128] W, W[k][n] = W[n sn + k sk] (the backward's d feat = d y W_out: sn = 1, sk = F).
+// scratch: xstat_h3_scratch_bytes(N), 16-byte aligned, overwritten (planes | 1 / column scale)
+static int xstat_h3_blocks(int N) { return (N + pjh3::PJ_B - 1) / pjh3::PJ_B; }
+size_t xstat_h3_scratch_bytes(int N) {
+  const size_t nb = xstat_h3_blocks(N);
+  return 2 * nb * pjh3::PJ_STAGE_ELEMS * sizeof(_Float16) + nb * pjh3::PJ_B * sizeof(float);
+}
+int launch_xstat_h3(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st) {
+  using namespace pjh3;
+  DIFFAB_REQUIRE(X && W && Y && scratch && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                     N >= 1 && rows >= 1 && ldy >= N,
+                 DIFFAB_ERR_ARG, "xstat_h3: unsupported operands");
+  const int NB = xstat_h3_blocks(N);
+  _Float16* Wc = static_cast<_Float16*>(scratch);
+  float* wis = reinterpret_cast<float*>(Wc + static_cast<size_t>(2 * NB) * PJ_STAGE_ELEMS);
+  hipLaunchKernelGGL(xsplit_h3_kernel, dim3(NB * PJ_B), dim3(64), 0, st, W, sn, sk, N, Wc, wis);
+  DIFFAB_LAUNCH_CHECK();
+  const int ntiles = (rows + PJ_ROWS - 1) / PJ_ROWS;
+  int nsplit = 256 / ntiles;
+  nsplit = nsplit < 1 ? 1 : (nsplit > NB ? NB : nsplit);
+  const dim3 grid(ntiles, nsplit);
+#define XSH3_LAUNCH(FULL_, SPLIT_)                                                                                              \
+  do {                                                                                                                          \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(xstat_h3_kernel<FULL_, SPLIT_>),                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, PJ_LDS_BYTES));                             \
+    hipLaunchKernelGGL((xstat_h3_kernel<FULL_, SPLIT_>), grid, dim3(512), PJ_LDS_BYTES, st, X, Wc, wis, Y, rows, NB, N, ldy);     \
+  } while (0)
+  if (rows % PJ_ROWS == 0) {
+    if (nsplit > 1) XSH3_LAUNCH(true, true);
+    else XSH3_LAUNCH(true, false);
+  } else {
+    if (nsplit > 1) XSH3_LAUNCH(false, true);
+    else XSH3_LAUNCH(false, false);
+  }
+#undef XSH3_LAUNCH
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

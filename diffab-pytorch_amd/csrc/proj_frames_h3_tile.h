@@ -25,22 +25,28 @@ constexpr int PJ_STAGE_ELEMS = 2 * PJ_B * 64;   // fp16 per stage in global memo
 constexpr int PJ_STAGE_LDS = 2 * PJ_B * PJ_LD;  // fp16 per stage in LDS (30 720 bytes)
 constexpr int PJ_LDS_BYTES = 2 * PJ_STAGE_LDS * 2 + PJ_ROWS * 12 * 4 + PJ_ROWS * 4;  // two stages | frames [128][12] | 1 / row scale [128]
 struct __attribute__((packed, aligned(4))) pj_f3 { float x, y, z; };
-// a * b as ONE v_mul_f32 the compiler cannot fuse into a packed op (see epilogue_piece)
+// a * b as ONE multiply that is never contracted into an fma (the epilogue's operation order is part of the shard invariance).  NOT inline
+// assembly (rounds 5-6 spelled it `asm("v_mul_f32 ...")` against the packed-op hazard of profiles/r05_pk_opsel_hazard.md): the compiler
+// does not guard an assembly statement's READ of a matrix-core result - the ragged x-stationary instantiation scheduled the first
+// epilogue slice three instructions behind the MFMA that writes its z accumulator and stored a stale register (round 6,
+// test_x_stationary_backward_product_is_fp32_accurate).  The packed forms cannot appear: the library is built without the SLP
+// vectoriser and tools/isa_hazard_lint.py checks every kernel.
 __device__ __forceinline__ float mul1(float a, float b) {
-  float r;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+#pragma clang fp contract(off)
+  return a * b;
 }
 
 // One 128-row tile (rows tile_m * 128 ..).  512 threads; pj_lds: PJ_LDS_BYTES, 16-byte aligned; Wc: stage-ordered planes of pjsplit_h3
 // ([(block 2 + k half)][2 planes][96][64] fp16), wis[1344]: 1 / scale of every output column; split_i of split_n work-groups share the
 // column blocks of the tile (each re-reads the x rows).
-template <bool FULL, bool SPLIT = false>  // FULL: M is a multiple of 128, no row guards
+// PROJ = false (the backward's d feat = d y W_out, gemm_f16x3.hip launch_xstat_h3): the same x-stationary product for ANY number of output
+// columns - nb_rt blocks of 96 (planes and wis padded with zeros / ones), the first n_rt columns stored into rows of ldy_rt floats, no frames.
+template <bool FULL, bool SPLIT = false, bool PROJ = true>  // FULL: M is a multiple of 128, no row guards
 __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_lds, const int tid, const int tile_m, const int split_i,
                                                     const int split_n, const float* __restrict__ X, const _Float16* __restrict__ Wc,
                                                     const float* __restrict__ wis, const float* __restrict__ R, const float* __restrict__ t,
-                                                    float* __restrict__ Y, int M) {
-  constexpr int NB = PJ_NB, ldy = PJ_NP, frames_from = PJ_GQ / PJ_B;
+                                                    float* __restrict__ Y, int M, const int nb_rt = 0, const int n_rt = 0, const int ldy_rt = 0) {
+  const int NB = PROJ ? PJ_NB : nb_rt, ldy = PROJ ? PJ_NP : ldy_rt, frames_from = PROJ ? PJ_GQ / PJ_B : NB;
   const int blk0 = SPLIT ? (NB * split_i) / split_n : 0;
   const int blk1 = SPLIT ? (NB * (split_i + 1)) / split_n : NB;
   float* Rt = reinterpret_cast<float*>(pj_lds + 2 * PJ_STAGE_LDS);  // [128][12]
@@ -104,7 +110,7 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
         a[mt][q][1][c] = h2;
       }
   }
-  for (int idx = tid; idx < PJ_ROWS * 12; idx += 512) {
+  for (int idx = tid; PROJ && idx < PJ_ROWS * 12; idx += 512) {
     const int row = idx / 12, cc = idx % 12, gr = m0 + row;
     float v = 0.0f;
     if (FULL || gr < M) v = cc < 9 ? R[static_cast<int64_t>(gr) * 9 + cc] : t[static_cast<int64_t>(gr) * 3 + (cc - 9)];
@@ -121,12 +127,11 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
     const int mt = piece >> 2, r = piece & 3;
     const int lrow = 32 * rw + 16 * mt + 4 * g + r;
     const float isx = Sx[lrow];
-    // (single-register multiplies on purpose: packed as v_pk_mul_f32 ... op_sel:[0,1] - what hipcc makes of `isx * wsc.xy` when isx sits in
-    // the odd register of a 64-bit LDS read - the low product came out 0 in lanes 48-63 with the MFMAs of the next block in flight around
-    // it: a gfx950 hazard the compiler does not guard, profiles/r05_pk_opsel_hazard.md, tools/isa_hazard_lint.py)
+    // (scalar multiplies; a `v_pk_mul_f32 ... op_sel:[0,1]` here - what the SLP vectoriser made of `isx * wsc.xy` - came out 0 in lanes 48-63
+    // with the MFMAs of the next block in flight: profiles/r05_pk_opsel_hazard.md; the library is built without that pass)
     const float vx = mul1(acc[mt][0][r], mul1(isx, wsc.x)), vy = mul1(acc[mt][1][r], mul1(isx, wsc.y)), vz0 = mul1(acc[mt][2][r], mul1(isx, wsc.z));
     float ox = vx, oy = vy, oz = vz0;
-    if (blk >= frames_from) {  // point columns: local -> global frame (diffab_pytorch.py:324)
+    if (PROJ && blk >= frames_from) {  // point columns: local -> global frame (diffab_pytorch.py:324)
       const f32x4* F = reinterpret_cast<const f32x4*>(Rt + lrow * 12);
       const f32x4 f0 = F[0], f1 = F[1], f2 = F[2];  // R row-major 0..8, t 9..11
       // (explicit operation order: left to the compiler's contraction the three products associate differently in the SPLIT and the
@@ -137,8 +142,16 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
       oz = __builtin_fmaf(vz, f2[0], __builtin_fmaf(vy, f1[1], mul1(vx, f0[2]))) + f2[3];
     }
     if (FULL || m0 + lrow < M) {
-      pj_f3 o{ox, oy, oz};
-      *reinterpret_cast<pj_f3*>(ybase + (16 * mt + r) * ldy + PJ_B * blk) = o;
+      float* yp = ybase + (16 * mt + r) * ldy + PJ_B * blk;
+      if constexpr (PROJ) {
+        pj_f3 o{ox, oy, oz};
+        *reinterpret_cast<pj_f3*>(yp) = o;
+      } else {  // (the last block may be partial)
+        const int c = PJ_B * blk + col0;
+        if (c < n_rt) yp[0] = ox;
+        if (c + 1 < n_rt) yp[1] = oy;
+        if (c + 2 < n_rt) yp[2] = oz;
+      }
     }
   };
   // block `blk` into `cur`; the previous block's epilogue (`prev`, `wprev`) is issued between the MFMA groups of the first k half
@@ -191,7 +204,7 @@ __device__ __forceinline__ void proj_frames_h3_tile(_Float16* __restrict__ pj_ld
     run_block(accB, accA, wA, blk + 1);
     if (blk + 2 < blk1) wA = wsc_of(blk + 2);
   }
-  if (SPLIT && blk < blk1) {  // odd share (the 14 projection blocks over two groups: 7 each)
+  if ((SPLIT || !PROJ) && blk < blk1) {  // odd share (the 14 projection blocks over two groups: 7 each)
     run_block(accA, accB, wB, blk);
 #pragma unroll
     for (int piece = 0; piece < 8; ++piece) epilogue_piece(accA, wA, blk, piece);

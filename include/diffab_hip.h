@@ -205,6 +205,12 @@ int diffab_set_stream_guard(int on);
  * (rowgemm128_h3_kernel; scratch >= 2 * 128 * Kd * 2 + 768 bytes; Kd a multiple of 64).  Modes 0 and 1: Kd a multiple of 32.  Lets a test measure them against float64. */
 int diffab_debug_linear128(const float* X, const float* W, const float* bias, float* Y, int64_t M, int32_t Kd, int32_t mode, void* scratch,
                            size_t scratch_bytes, void* stream);
+/* Diagnostics / accuracy tests: Y[M x N] = X[M x 128] W[128 x N] (row-major, 16-byte aligned X) through one of the two x-stationary kernels
+ * the training backward uses for d feat = d y W_out (reference: autograd of diffab_pytorch.py:459-464) - mode 1: bf16 matrix cores, six-term
+ * split (proj_frames_b6_kernel without frames), mode 2: f16 matrix cores, three-term split under power-of-two scales (xstat_h3_kernel).
+ * Any N >= 1, any M >= 1; scratch: 16-byte aligned, >= 3 * 2 * ceil(N / 96) * 96 * 128 * 2 + ceil(N / 96) * 96 * 4 bytes. */
+int diffab_debug_xstat128(const float* X, const float* W, float* Y, int64_t M, int32_t N, int32_t mode, void* scratch, size_t scratch_bytes,
+                          void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
 /* ---- SO(3) maps, n matrices/vectors each --------------------------------- */
 /* so3.py:146-162  log R = theta/(2 sin theta) (R - R^T); NaN at theta = 0 like the reference */

@@ -1204,6 +1204,32 @@ def test_split_precision_gemm_is_fp32_accurate(hip, Kd):
     assert errs[2] < 4 * errs[0] + 4e-7, errs           # (fp16 x 3 carries 22 bits per operand: 2^-22 = 2.4e-7 on top)
 
 
+@pytest.mark.parametrize("M,N", [(16384, 1024), (4096 + 37, 1024), (300, 100), (129, 1344)])
+def test_x_stationary_backward_product_is_fp32_accurate(hip, M, N):
+    """d feat = d y W_out of the training backward (autograd of diffab_pytorch.py:459-464; 128 -> N columns, x-stationary): the fp16 x 3
+    kernel (round 6: the projection tile without frames, any N) beside the bf16 x 6 one it replaces, against float64 on rows and weight
+    columns whose magnitudes span decades - gradients are small and uneven; per-row and per-column power-of-two scales must absorb it.
+    Shapes: the training step's own (16 384 x 1024), ragged rows, a partial last block (N = 100: one block of 96 + 4), one row tile + 1."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    X = torch.randn(M, 128, device="cuda", generator=g) * 1e-4 * torch.exp(3 * torch.randn(M, 1, device="cuda", generator=g))
+    X[7] = 0.0
+    W = torch.randn(128, N, device="cuda", generator=g) * 0.1 * torch.exp(2 * torch.randn(1, N, device="cuda", generator=g))
+    want = X.double() @ W.double()
+    scale = X.double().abs() @ W.double().abs() + 1e-300
+    nb = (N + 95) // 96
+    scratch = torch.empty(3 * 2 * nb * 96 * 128 * 2 + nb * 96 * 4 + 256, dtype=torch.uint8, device="cuda")
+    errs = {}
+    for mode in (1, 2):
+        Y = torch.full((M + 1, N), 7.0, device="cuda")  # (one guard row behind the product)
+        rc = hip.diffab_debug_xstat128(_hip.ptr(X), _hip.ptr(W), _hip.ptr(Y), M, N, mode, _hip.ptr(scratch), scratch.numel(), _hip.stream_ptr())
+        assert rc == 0, hip.diffab_last_error()
+        assert torch.isfinite(Y).all() and bool((Y[M] == 7.0).all()) and bool((Y[7] == 0.0).all())
+        errs[mode] = float(((Y[:M].double() - want).abs() / scale).max())
+    print(f"M={M} N={N}: max |err| / sum|x w|: bf16x6 {errs[1]:.2e}, fp16x3 {errs[2]:.2e}")
+    assert errs[1] < 2e-6 and errs[2] < 2e-6, errs
+    assert errs[2] < 4 * errs[1] + 4e-7, errs
+
+
 def test_fp16x3_gemm_shape_guard_and_tiny_rows(hip):
     """Round-5 advisor findings on the fp16 x 3 row GEMM: (1) it joins its 32-k chunks in pairs, so a contraction length that is not a
     multiple of 64 must be REFUSED (Kd = 96 used to drop the last chunk silently); (2) a row whose largest magnitude is a normal number
