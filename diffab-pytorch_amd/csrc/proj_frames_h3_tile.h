@@ -26,7 +26,7 @@ constexpr int PJ_STAGE_LDS = 2 * PJ_B * PJ_LD;  // fp16 per stage in LDS (30 720
 constexpr int PJ_LDS_BYTES = 2 * PJ_STAGE_LDS * 2 + PJ_ROWS * 12 * 4 + PJ_ROWS * 4;  // two stages | frames [128][12] | 1 / row scale [128]
 struct __attribute__((packed, aligned(4))) pj_f3 { float x, y, z; };
 // a * b as ONE multiply that is never contracted into an fma (the epilogue's operation order is part of the shard invariance).  NOT inline
-// assembly (rounds 5-6 spelled it `asm("v_mul_f32 ...")` against the packed-op hazard of profiles/r05_pk_opsel_hazard.md): the compiler
+// assembly (rounds 5-6 spelled it as a v_mul_f32 assembly statement against the packed-op hazard of profiles/r05_pk_opsel_hazard.md): the compiler
 // does not guard an assembly statement's READ of a matrix-core result - the ragged x-stationary instantiation scheduled the first
 // epilogue slice three instructions behind the MFMA that writes its z accumulator and stored a stale register (round 6,
 // test_x_stationary_backward_product_is_fp32_accurate).  The packed forms cannot appear: the library is built without the SLP

@@ -37,3 +37,25 @@ def test_built_library_has_no_op_sel_01_packed_ops_in_any_kernel():
     assert sum(t.count("v_mfma") for t in texts) > 1000  # the disassembly is the real one
     found = isa_hazard_lint.lint_paths([LIB])
     assert not found, found
+
+
+def test_no_inline_assembly_vector_op_outside_the_reviewed_list():
+    """The compiler guards neither waits nor matrix-core hazards it cannot see: it does not insert the MFMA -> VALU wait states for the
+    operands of an inline-assembly statement (round 6: the projection tile's `asm("v_mul_f32 ...")` read an accumulator three
+    instructions behind its MFMA in one instantiation and stored a stale register; proj_frames_h3_tile.h mul1).  Every assembly
+    statement that names a vector instruction is therefore listed here with the reason its operands can never be MFMA results."""
+    import glob
+    import re
+
+    reviewed = {
+        # packed subtract of point coordinates: both operands come from LDS / global loads (phase 1 of the attention tile)
+        ("ipa_attn_tile.h", "v_pk_add_f32"),
+        ("attention_split.hip", "v_pk_add_f32"),
+    }
+    seen = set()
+    for path in glob.glob(os.path.join(REPO, "diffab-pytorch_amd", "csrc", "*")):
+        if not path.endswith((".h", ".hip")):
+            continue
+        for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"\s*(v_\w+|ds_\w+|global_\w+|buffer_\w+)', open(path).read()):
+            seen.add((os.path.basename(path), m.group(1)))
+    assert seen <= reviewed, sorted(seen - reviewed)
