@@ -431,6 +431,15 @@ int diffab_debug_xstat128(const float* X, const float* W, float* Y, int64_t M, i
   return launch_xstat_h3(X, W, 1, N, Y, N, static_cast<int>(M), N, scratch, st);
 }
 
+int diffab_debug_gemm_tn(const float* A, const float* B, float* C, float* db, int64_t M, int32_t N1, int32_t N2, int32_t mode, void* stream) {
+  StreamOrder order_(stream);
+  DIFFAB_REQUIRE(A && B && C && M >= 1 && M < (1LL << 31) && N1 >= 1 && N2 >= 1 && (mode == 1 || mode == 2), DIFFAB_ERR_ARG,
+                 "debug_gemm_tn: bad operands");
+  hipStream_t st = as_stream(stream);
+  if (mode == 1) return launch_gemm_tn_b6(A, N1, B, N2, C, N2, static_cast<int>(M), N1, N2, db, nullptr, nullptr, 0, st);
+  return launch_gemm_tn_h3(A, N1, B, N2, C, N2, static_cast<int>(M), N1, N2, db, nullptr, nullptr, 0, st);
+}
+
 int diffab_set_stream_guard(int on) {
   set_stream_order(on != 0);
   return DIFFAB_OK;

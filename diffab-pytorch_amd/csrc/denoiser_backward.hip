@@ -176,7 +176,11 @@ class SideRun {
     st_ = &pool()[dev & 31];
     st_->mu.lock();
     if (st_->side == nullptr) {
-      bool ok = hipStreamCreateWithFlags(&st_->side, hipStreamNonBlocking) == hipSuccess;
+      // lowest priority: the weight-gradient products fill the chain's gaps and tails, they must not hold CUs (64 KiB of LDS per
+      // work-group) that the chain's next kernel is waiting for
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = 0; }
+      bool ok = hipStreamCreateWithPriority(&st_->side, hipStreamNonBlocking, lo) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&st_->fork, hipEventDisableTiming) == hipSuccess;
       for (int i = 0; i < kEv && ok; ++i) ok = hipEventCreateWithFlags(&st_->done[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); st_->side = nullptr; st_->broken = true; }
@@ -349,6 +353,7 @@ static int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, i
     for (int i = 0; i < sg.nseg; ++i) seg_ok = seg_ok && sg.n_end[i] % 64 == 0;
     if (seg_ok) {
       if (db_done) *db_done = db != nullptr;
+      if (tn_h3_enabled()) return launch_gemm_tn_h3(A, lda, B, ldb, C, ldc, M, N1, N2, db_done ? db : nullptr, sg.p, sg.n_end, sg.nseg, st);
       return launch_gemm_tn_b6(A, lda, B, ldb, C, ldc, M, N1, N2, db_done ? db : nullptr, sg.p, sg.n_end, sg.nseg, st);
     }
   }

@@ -73,6 +73,7 @@ size_t rowgemm128_b6_parts_floats(int M, int Kd);  // scratch of the k-parts for
 size_t rowgemm128_h3_parts_floats(int M, int Kd);
 bool value_planes_enabled();  // true: diffab_debug_set_attn_variant(16)
 void ipa_ws_value_planes(const diffab_dims* d, float* ws, float** vpl, float** vsc);  // the value planes / scales inside a layer workspace
+bool tn_h3_enabled();     // false: diffab_debug_set_attn_variant(8 | 32): weight-gradient products in the six-term bf16 form
 bool dense_h3_enabled();  // false: diffab_debug_set_attn_variant(8), the six-term bf16 form of the projections and to_out
 int launch_rowgemm128_b6(const float* X, int ldx, const float* W, int ldw, const float* bias, const int64_t* bias_idx, int bias_div, float* Y,
                          int ldy, int M, int Kd, bool relu, void* scratch, hipStream_t st);
@@ -83,6 +84,9 @@ int launch_pjsplit(const float* const* W6, void* planes, hipStream_t st);
 int launch_proj_frames_b6p(const float* x, const void* planes, const float* R, const float* t, float* proj, int rows, hipStream_t st);
 // the same x-stationary kernel as a plain product Y[rows x N] = X[rows x 128] W'^T, (n, k) of W' = W[n sn + k sk] (to_out input gradient)
 size_t xstat_b6_scratch_bytes(int N);
+// gemm_f16x3.hip: C[N1 x N2] += A^T B as three fp16 terms (launch_gemm_tn_b6's contract)
+int launch_gemm_tn_h3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db,
+                      float* const* seg_ptrs, const int* seg_ends, int nseg, hipStream_t st);
 size_t xstat_h3_scratch_bytes(int N);  // gemm_f16x3.hip: the same product as three fp16 terms
 int launch_xstat_h3(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st);
 int launch_xstat_b6(const float* X, const float* W, int64_t sn, int64_t sk, float* Y, int ldy, int rows, int N, void* scratch, hipStream_t st);

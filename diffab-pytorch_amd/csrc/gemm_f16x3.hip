@@ -259,6 +259,307 @@ int launch_proj_frames_h3p(const float* x, const void* planes, const float* wis,
   return DIFFAB_OK;
 }
 
+// ================================================================== weight-gradient products: C[N1 x N2] += A^T B  (fp16 x 3)
+// The three-term form of gemm_tn_b6_kernel (gemm_bf16x6.hip: same tiling - 128 x 128 output tile per work-group, 32-row slabs of both
+// operands staged in their natural [row][column] orientation, fragments through ds_read_b64_tr_b16, M split over work-groups, fp32
+// atomics): two fp16 planes per operand instead of three bf16 ones, 24 MFMAs per wave and slab instead of 48.  fp16 has no range to
+// spare, gradients are small and uneven: every (slab, operand) gets ONE power-of-two scale from the largest magnitude of the work-group's
+// 32 x 128 block (the contraction runs over the slab's rows, so the scale may not vary inside it).  The maxima travel ahead of the
+// data: a slab sits in the register ring for three steps before it is staged - each wave posts its maximum of slab s + 2 to LDS during
+// step s, the step's barrier publishes it, step s + 1 reads the eight wave maxima when it splits that slab.  A slab's products are
+// accumulated on their own and added to the running sums with 1 / (s_A s_B).
+namespace tnh3 {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+using h3tile::f16x8;
+using h3tile::f32x4;
+constexpr int TN_PLANE = 32 * 128;  // fp16 elements of one plane of one slab
+constexpr int TN_LDS_BYTES = 2 * 4 * TN_PLANE * 2 + 4 * 16 * 4;  // [2 buffers][A | B][2 planes] | wave maxima [4 ring slots][A | B][8 waves]
+__device__ __forceinline__ int tn_off(int row, int chunk) {  // element offset of 16-byte chunk `chunk` of row `row` (gemm_bf16x6.hip tn_off)
+  return row * 128 + 8 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+// maximum of a non-negative value over the wave (non-negative floats order like their bit patterns): the two row-swap instructions of
+// gfx950 for lanes 16 / 32 apart, rotations inside the rows of 16 - vector ALU only
+__device__ __forceinline__ float wave_max_nonneg(float m) {
+  unsigned u = __float_as_uint(m);
+  const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = s16[0] > s16[1] ? s16[0] : s16[1];
+  const auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = s32[0] > s32[1] ? s32[0] : s32[1];
+#define TNH3_ROR(N_)                                                                                      \
+  {                                                                                                       \
+    const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x120 + N_, 0xf, 0xf, false)); \
+    u = o > u ? o : u;                                                                                    \
+  }
+  TNH3_ROR(8) TNH3_ROR(4) TNH3_ROR(2) TNH3_ROR(1)
+#undef TNH3_ROR
+  return __uint_as_float(u);
+}
+}  // namespace tnh3
+
+struct TnSegsH3 {
+  float* p[6];
+  int n_end[6];
+  int nseg;  // 0: one plain matrix C
+};
+
+// A_VEC / B_VEC, db, segs: as gemm_tn_b6_kernel
+template <bool A_VEC, bool B_VEC>
+__global__ __launch_bounds__(512) void gemm_tn_h3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int m_chunk, int N1, int N2, TnSegsH3 segs,
+                                                         float* __restrict__ db) {
+  using namespace tnh3;
+  extern __shared__ __attribute__((aligned(16))) _Float16 tnh_lds[];
+  float* smax = reinterpret_cast<float*>(tnh_lds + 2 * 4 * TN_PLANE);  // [slot][op][wave]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int aw = wv & 3, bw = wv >> 2;  // wave tile: 32 rows of C (A columns) x 64 columns (B columns)
+  const int a0 = blockIdx.y * 128, b0 = blockIdx.x * 128;
+  const int m_lo = blockIdx.z * m_chunk, m_hi = min(M, m_lo + m_chunk);
+  const int nstep = (m_hi - m_lo + 31) / 32;
+  const int s_row = tid >> 5, s_f4 = tid & 31;  // staging: rows tid / 32 and 16 + tid / 32, float4 tid % 32 of a 32 x 128 slab
+  const int acol = a0 + 4 * s_f4, bcol = b0 + 4 * s_f4;
+  const bool a_ok = acol < N1, b_ok = bcol < N2;
+  const bool want_db = db != nullptr && blockIdx.x == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[4][2], rb[4][2];  // ring of four slabs in registers
+  auto load_slab = [&](int slot, int step) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m_lo + 32 * step + s_row + 16 * j;
+      const bool ok = m < m_hi;
+      const int mc = ok ? m : m_lo;  // clamped address, zeroed value
+      f32x4 va, vb;
+      if (A_VEC) {
+        va = *reinterpret_cast<const f32x4*>(A + static_cast<int64_t>(mc) * lda + (a_ok ? acol : 0));
+        if (!ok || !a_ok) va = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool in = acol + c < N1;
+          const float v = A[static_cast<int64_t>(mc) * lda + (in ? acol + c : 0)];
+          va[c] = (ok && in) ? v : 0.0f;
+        }
+      }
+      if (B_VEC) {
+        vb = *reinterpret_cast<const f32x4*>(Bm + static_cast<int64_t>(mc) * ldb + (b_ok ? bcol : 0));
+        if (!ok || !b_ok) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool in = bcol + c < N2;
+          const float v = Bm[static_cast<int64_t>(mc) * ldb + (in ? bcol + c : 0)];
+          vb[c] = (ok && in) ? v : 0.0f;
+        }
+      }
+      if (want_db) csum += va;
+      ra[slot][j] = va;
+      rb[slot][j] = vb;
+    }
+  };
+  auto post_max = [&](int slot) {  // this wave's largest magnitudes of the slab in ring slot `slot`
+    float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ma = fmaxf(ma, fabsf(ra[slot][j][c]));
+        mb = fmaxf(mb, fabsf(rb[slot][j][c]));
+      }
+    ma = wave_max_nonneg(ma);
+    mb = wave_max_nonneg(mb);
+    if (lane == 0) {
+      smax[slot * 16 + wv] = ma;
+      smax[slot * 16 + 8 + wv] = mb;
+    }
+  };
+  auto slab_scales = [&](int slot, float& sa, float& sb, float& inv) {  // (published by the barrier of the step before)
+    const f32x4* p = reinterpret_cast<const f32x4*>(smax + slot * 16);
+    const f32x4 a0v = p[0], a1v = p[1], b0v = p[2], b1v = p[3];
+    const float ma = fmaxf(fmaxf(fmaxf(a0v[0], a0v[1]), fmaxf(a0v[2], a0v[3])), fmaxf(fmaxf(a1v[0], a1v[1]), fmaxf(a1v[2], a1v[3])));
+    const float mb = fmaxf(fmaxf(fmaxf(b0v[0], b0v[1]), fmaxf(b0v[2], b0v[3])), fmaxf(fmaxf(b1v[0], b1v[1]), fmaxf(b1v[2], b1v[3])));
+    float isa, isb;
+    h3_scale(ma, sa, isa);
+    h3_scale(mb, sb, isb);
+    inv = isa * isb;
+  };
+  auto store_slab = [&](int slot, int buf, float sa, float sb) {
+    _Float16* base = tnh_lds + buf * (4 * TN_PLANE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int off = tn_off(s_row + 16 * j, s_f4 >> 1) + 4 * (s_f4 & 1);
+#pragma unroll
+      for (int op = 0; op < 2; ++op) {
+        const f32x4 v = op == 0 ? ra[slot][j] : rb[slot][j];
+        const float sc = op == 0 ? sa : sb;
+        f16x4 h1, h2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const _Float16 a = static_cast<_Float16>(v[c] * sc);  // (a power of two: exact)
+          h1[c] = a;
+          h2[c] = static_cast<_Float16>(__builtin_fmaf(v[c], sc, -static_cast<float>(a)));
+        }
+        _Float16* dst = base + op * (2 * TN_PLANE) + off;
+        *reinterpret_cast<f16x4*>(dst) = h1;
+        *reinterpret_cast<f16x4*>(dst + TN_PLANE) = h2;
+      }
+    }
+  };
+  const int q = l15 >> 2, pp = l15 & 3;
+  int offA[2][2], offB[4][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int row = 8 * g + 4 * rd + q;
+#pragma unroll
+    for (int at = 0; at < 2; ++at) offA[at][rd] = tn_off(row, 4 * aw + 2 * at + (pp >> 1)) + 4 * (pp & 1);
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) offB[bt][rd] = 2 * TN_PLANE + tn_off(row, 8 * bw + 2 * bt + (pp >> 1)) + 4 * (pp & 1);
+  }
+  auto frag = [&](const _Float16* base, int off0, int off1) -> f16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + off1));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, v);
+  };
+  f32x4 tot[2][4];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) tot[at][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_slab(i, i);
+  post_max(0);
+  post_max(1);
+  asm volatile("" ::: "memory");
+  __syncthreads();
+  float inv_cur;
+  {
+    float sa, sb;
+    slab_scales(0, sa, sb, inv_cur);
+    store_slab(0, 0, sa, sb);
+  }
+  load_slab(0, 4);  // slot k holds the slab with index == k (mod 4)
+  asm volatile("" ::: "memory");
+  __syncthreads();
+  for (int st0 = 0; st0 < nstep; st0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int step = st0 + u;
+      if (step >= nstep) break;
+      const _Float16* base = tnh_lds + (u & 1) * (4 * TN_PLANE);
+      // stage slab step + 1 (requested four steps ago) into the other buffer, request slab step + 5 into the freed slot, post the maxima
+      // of slab step + 2
+      float sa, sb, inv_next;
+      slab_scales((u + 1) & 3, sa, sb, inv_next);
+      store_slab((u + 1) & 3, (u & 1) ^ 1, sa, sb);
+      load_slab((u + 1) & 3, step + 5);
+      post_max((u + 2) & 3);
+      asm volatile("" ::: "memory");
+      f16x8 fa[2][2], fb[4][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int at = 0; at < 2; ++at) fa[at][p] = frag(base + p * TN_PLANE, offA[at][0], offA[at][1]);
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) fb[bt][p] = frag(base + p * TN_PLANE, offB[bt][0], offB[bt][1]);
+      }
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) acc[at][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {  // (a2 b1) (a1 b2) (a1 b1): smallest first
+        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int at = 0; at < 2; ++at)
+#pragma unroll
+          for (int bt = 0; bt < 4; ++bt)
+            acc[at][bt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[at][pa], fb[bt][pb], acc[at][bt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[at][bt][r] = __builtin_fmaf(acc[at][bt][r], inv_cur, tot[at][bt][r]);
+      inv_cur = inv_next;
+      __syncthreads();
+    }
+  }
+  // D: column l15 <-> C column b0 + 64 bw + 16 bt + l15; row 4 g + r <-> C row a0 + 32 aw + 16 at + 4 g + r
+#pragma unroll
+  for (int at = 0; at < 2; ++at) {
+    const int rbase = a0 + 32 * aw + 16 * at;  // 16-row group: inside one segment (segment ends are multiples of 64)
+    if (rbase >= N1) continue;
+    float* cbase = C;
+    int rloc = rbase;
+    if (segs.nseg > 0) {
+      int s_ = 0, beg = 0;
+      while (s_ + 1 < segs.nseg && rbase >= segs.n_end[s_]) { beg = segs.n_end[s_]; ++s_; }
+      cbase = segs.p[s_];
+      rloc = rbase - beg;
+    }
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+      const int col = b0 + 64 * bw + 16 * bt + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col < N2 && rbase + 4 * g + r < N1) atomicAdd(cbase + static_cast<int64_t>(rloc + 4 * g + r) * ldc + col, tot[at][bt][r]);
+    }
+  }
+  if (db != nullptr) {  // uniform per launch.  The slabs requested past the end loaded zeros, so csum holds exactly this chunk's rows.
+    __syncthreads();  // every wave is done with the staging buffers
+    float* red = reinterpret_cast<float*>(tnh_lds);  // [8 waves][32 column groups][4]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) csum[c] += __shfl_xor(csum[c], 32);  // lanes l and l + 32 hold the same columns (rows 2 wv, 2 wv + 1)
+    if (lane < 32) *reinterpret_cast<f32x4*>(red + (wv * 32 + lane) * 4) = csum;
+    __syncthreads();
+    if (want_db && tid < 128) {
+      const int col = a0 + tid;  // column group tid / 4, component tid % 4
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 32 + (tid >> 2)) * 4 + (tid & 3)];
+      if (col < N1) atomicAdd(db + col, v);
+    }
+  }
+}
+
+// C[N1 x N2] += A[M x N1]^T B[M x N2] (launch_gemm_tn_b6's contract: db, segmented C rows)
+int launch_gemm_tn_h3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N1, int N2, float* db,
+                      float* const* seg_ptrs, const int* seg_ends, int nseg, hipStream_t st) {
+  const bool a_vec = lda % 4 == 0 && N1 % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const bool b_vec = ldb % 4 == 0 && N2 % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  DIFFAB_REQUIRE(A && B && N1 >= 1 && N2 >= 1 && M >= 1 && (reinterpret_cast<uintptr_t>(A) & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 3) == 0 &&
+                     nseg >= 0 && nseg <= 6 && (nseg > 0 || C) && (nseg == 0 || (a_vec && N1 % 16 == 0)),
+                 DIFFAB_ERR_ARG, "gemm_tn_h3: unsupported operands");
+  TnSegsH3 sg{};
+  sg.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) { sg.p[i] = seg_ptrs[i]; sg.n_end[i] = seg_ends[i]; }
+  const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128, tiles = t1 * t2;
+  int splits = 256 / tiles;  // at most one (tile, M chunk) work-group per CU
+  if (splits < 1) splits = 1;
+  int m_chunk = (M + splits - 1) / splits;
+  m_chunk = ((m_chunk < 256 ? 256 : m_chunk) + 31) / 32 * 32;
+  const int nchunks = (M + m_chunk - 1) / m_chunk;
+  const dim3 grid(t2, t1, nchunks);
+#define TNH3_LAUNCH(AV_, BV_)                                                                                                         \
+  do {                                                                                                                                \
+    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_h3_kernel<AV_, BV_>),                                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, tnh3::TN_LDS_BYTES));                            \
+    hipLaunchKernelGGL((gemm_tn_h3_kernel<AV_, BV_>), grid, dim3(512), tnh3::TN_LDS_BYTES, st, A, lda, B, ldb, C, ldc, M, m_chunk, N1, N2, \
+                       sg, db);                                                                                                       \
+  } while (0)
+  if (a_vec && b_vec) TNH3_LAUNCH(true, true);
+  else if (a_vec) TNH3_LAUNCH(true, false);
+  else if (b_vec) TNH3_LAUNCH(false, true);
+  else TNH3_LAUNCH(false, false);
+#undef TNH3_LAUNCH
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 // Y[rows x N] (leading dimension ldy) = X[rows x 128] W, W[k][n] = W[n sn + k sk] (the backward's d feat = d y W_out: sn = 1, sk = F).
 // scratch: xstat_h3_scratch_bytes(N), 16-byte aligned, overwritten (planes | 1 / column scale)
 static int xstat_h3_blocks(int N) { return (N + pjh3::PJ_B - 1) / pjh3::PJ_B; }

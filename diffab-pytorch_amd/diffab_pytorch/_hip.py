@@ -94,6 +94,7 @@ SYMBOLS = {
     "diffab_debug_set_module_stamps": (C.c_int, [_fp]),
     "diffab_set_stream_guard": (C.c_int, [C.c_int]),
     "diffab_debug_linear128": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp]),
+    "diffab_debug_gemm_tn": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp]),
     "diffab_debug_xstat128": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp]),
     "diffab_kernel_timer_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "diffab_so3_log": (C.c_int, [_fp, _fp, _i64, _fp]),

@@ -191,7 +191,9 @@ int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; pro
                                                  attention kernel (two per CU; measured slower), bit 2 (4) = the PairEmbedding forward / backward
                                                  as their unfused launches where the fused kernel would apply, 8 (alone) = the six
                                                  projections and to_out as six-term bf16 split products (rounds 3-4) instead of the
-                                                 three-term fp16 ones - per-layer launches only, bit 4 (16) = value planes: a pass after the
+                                                 three-term fp16 ones (and with them the backward's d feat and weight-gradient products) -
+                                                 per-layer launches only, bit 5 (32) = only the weight-gradient products of the training
+                                                 backward in the six-term bf16 form, bit 4 (16) = value planes: a pass after the
                                                  projections cuts the value side (v_s, global value points) into two fp16 planes and phase 3
                                                  of the attention tile (P x V) runs on the f16 matrix cores (parity-green, measured slower
                                                  overall: profiles/r06_attention.md).  0 = defaults. */
@@ -211,6 +213,11 @@ int diffab_debug_linear128(const float* X, const float* W, const float* bias, fl
  * Any N >= 1, any M >= 1; scratch: 16-byte aligned, >= 3 * 2 * ceil(N / 96) * 96 * 128 * 2 + ceil(N / 96) * 96 * 4 bytes. */
 int diffab_debug_xstat128(const float* X, const float* W, float* Y, int64_t M, int32_t N, int32_t mode, void* scratch, size_t scratch_bytes,
                           void* stream);
+/* Diagnostics / accuracy tests: C[N1 x N2] += A[M x N1]^T B[M x N2] (row-major, contraction over the rows) through one of the two
+ * weight-gradient kernels of the training backward (reference: autograd of every nn.Linear, e.g. diffab_pytorch.py:375-379, :459-464) -
+ * mode 1: bf16 matrix cores, six-term split (gemm_tn_b6_kernel), mode 2: f16 matrix cores, three-term split with one power-of-two
+ * scale per (32-row slab, operand) (gemm_tn_h3_kernel).  db (nullable): db[N1] += column sums of A.  Any M, N1, N2 >= 1. */
+int diffab_debug_gemm_tn(const float* A, const float* B, float* C, float* db, int64_t M, int32_t N1, int32_t N2, int32_t mode, void* stream);
 int diffab_kernel_timer_read(int64_t* launches, double* total_ms);
 /* ---- SO(3) maps, n matrices/vectors each --------------------------------- */
 /* so3.py:146-162  log R = theta/(2 sin theta) (R - R^T); NaN at theta = 0 like the reference */

@@ -1230,6 +1230,35 @@ def test_x_stationary_backward_product_is_fp32_accurate(hip, M, N):
     assert errs[2] < 4 * errs[1] + 4e-7, errs
 
 
+@pytest.mark.parametrize("M,N1,N2", [(16384, 1344, 128), (16384, 128, 1024), (4096 + 37, 131, 128), (777, 20, 131), (128, 3, 128)])
+def test_weight_gradient_product_is_fp32_accurate(hip, M, N1, N2):
+    """d W += d y^T x of every nn.Linear's backward (contraction over the B K rows): the fp16 x 3 kernel (round 6: one power-of-two scale
+    per 32-row slab and operand, found from wave maxima that travel one barrier ahead of the data) beside the bf16 x 6 one, against
+    float64.  Rows whose magnitudes span decades in BOTH operands and change from slab to slab (masked rows are zero, gradients are
+    1e-6 .. 1e-2): the per-slab scales must follow.  Shapes: the projections' and to_out's of the training step, the 131-wide head
+    input (scalar loads), the 20- and 3-wide head outputs, a ragged last slab; C accumulates (+=); db = column sums of A."""
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N1 + N2)
+    rowmag = torch.exp(4 * torch.randn(M, 1, device="cuda", generator=g))
+    A = torch.randn(M, N1, device="cuda", generator=g) * 1e-4 * rowmag
+    Bm = torch.randn(M, N2, device="cuda", generator=g) * torch.exp(2 * torch.randn(M, 1, device="cuda", generator=g))
+    A[M // 3: M // 3 + 70] = 0.0  # masked rows: whole slabs of zeros
+    C0 = torch.randn(N1, N2, device="cuda", generator=g) * 1e-3
+    want = C0.double() + A.double().T @ Bm.double()
+    scale = A.double().abs().T @ Bm.double().abs() + C0.double().abs()
+    want_db = A.double().sum(0)
+    errs = {}
+    for mode in (1, 2):
+        Cm, db = C0.clone(), torch.zeros(N1, device="cuda")
+        rc = hip.diffab_debug_gemm_tn(_hip.ptr(A), _hip.ptr(Bm), _hip.ptr(Cm), _hip.ptr(db), M, N1, N2, mode, _hip.stream_ptr())
+        assert rc == 0, hip.diffab_last_error()
+        assert torch.isfinite(Cm).all()
+        errs[mode] = float(((Cm.double() - want).abs() / scale).max())
+        assert float((db.double() - want_db).abs().max()) <= 1e-5 * float(A.double().abs().sum(0).max()), mode
+    print(f"M={M} N1={N1} N2={N2}: max |err| / sum|a b|: bf16x6 {errs[1]:.2e}, fp16x3 {errs[2]:.2e}")
+    assert errs[1] < 2e-6 and errs[2] < 2e-6, errs
+    assert errs[2] < 4 * errs[1] + 4e-7, errs
+
+
 def test_fp16x3_gemm_shape_guard_and_tiny_rows(hip):
     """Round-5 advisor findings on the fp16 x 3 row GEMM: (1) it joins its 32-k chunks in pairs, so a contraction length that is not a
     multiple of 64 must be REFUSED (Kd = 96 used to drop the last chunk silently); (2) a row whose largest magnitude is a normal number
