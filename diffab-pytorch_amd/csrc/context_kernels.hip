@@ -800,7 +800,7 @@ static size_t fused_bwd_workspace_floats(const diffab_ctx_dims* d) {
   const size_t R = static_cast<size_t>(fused_bwd_chunk_patches(d)) * d->K * d->K;
   const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
   return R * (9 * d->C + 2 * AA2p + 20) + 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + static_cast<size_t>(kAA) * kAA * d->A * d->A +
-         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + 1024;
+         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + pair_chain_bwd_prep_floats() + 1024;
 }
 
 static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
@@ -832,6 +832,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
   float* G1 = cv.take<float>(static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C);  // G1 | G2 adjacent
   float* G2 = G1 + static_cast<size_t>(kAA) * kAA * C;
   float* prep = cv.take<float>(pair_embed_fused_prep_floats(d));
+  float* chain_prep = cv.take<float>(pair_chain_bwd_prep_floats());
   auto mut = [](const float* p) { return const_cast<float*>(p); };
   hipLaunchKernelGGL(pad_rows_kernel, dim3((C * AA2p + 255) / 256), dim3(256), 0, st, w->dw0, AA2, C, dw0p, AA2p);
   hipLaunchKernelGGL(pad_rows_kernel, dim3((C * Wp + 255) / 256), dim3(256), 0, st, w->mw0, W, C, mw0p, Wp);
@@ -850,24 +851,37 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
     if (int rc = launch_pair_embed_fused(d, w, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx,
                                          atom_mask, sequence_context_mask, nullptr, prep, h1, df, m1, m2, row0, nrows, st, &coef_sp))
       return rc;
-    // ---- mlp[4], mlp[2]
-    hipLaunchKernelGGL(pair_mask_bwd_kernel, dim3(static_cast<unsigned>((nrows * C + 255) / 256)), dim3(256), 0, st, d_out, atom_mask, d->K,
-                       d->A, C, row0, nrows, dA);
-    DIFFAB_LAUNCH_CHECK();
-    // ---- the dX chain: four 64 x 64 products, each masked by the ReLU below it in the product's epilogue
-    //      dA = d out (masked) -> dB = d mlp[2] pre-activation -> dC = d mlp[0] pre-activation -> ddf -> dh1
-    if (int rc = bwd_gemm_nn_masked(dA, C, w->mw4, C, dB, C, rows, C, C, m2, st)) return rc;
-    if (int rc = bwd_gemm_nn_masked(dB, C, w->mw2, C, dC, C, rows, C, C, m1, st)) return rc;
-    if (int rc = bwd_gemm_nn_masked(dC, C, mw0p + 2 * C, Wp, ddf, C, rows, C, C, df, st)) return rc;  // distance_embedding ends with a ReLU (:212-217)
-    if (int rc = bwd_gemm_nn_masked(ddf, C, w->dw2, C, dh1, C, rows, C, C, h1, st)) return rc;
-    // ---- the four 64 x 64 weight gradients (+ bias gradients) of mlp[4], mlp[2], mlp[0][:, 2C:3C], distance_embedding[2] in one launch
-    {
-      const float* As[4] = {dA, dB, dC, ddf};
-      const float* Bs[4] = {m2, m1, df, h1};
-      float* Cs[4] = {mut(g->mw4), mut(g->mw2), gmw0p + 2 * C, mut(g->dw2)};
-      const int ldcs[4] = {C, C, Wp, C};
-      float* dbs[4] = {mut(g->mb4), mut(g->mb2), mut(g->mb0), mut(g->db2)};
-      if (int rc = bwd_tn64_set(4, As, Bs, Cs, ldcs, dbs, nrows, st)) return rc;
+    if (pair_chain_bwd_enabled() && pair_chain_bwd_supported(C, d->K, nrows)) {
+      // ---- the atom-mask product, the four 64 x 64 layers' d x chain and their weight / bias gradients: ONE launch, a 128-row tile stays
+      //      on the CU from d out to d h1 (pair_chain_bwd.hip); d C and d h1 leave for the steps below
+      const float* Xs[4] = {m2, m1, df, h1};
+      const float* Wsrc[4] = {w->mw4, w->mw2, mw0p + 2 * C, w->dw2};
+      const int ldws[4] = {C, C, Wp, C};
+      float* Gs[4] = {mut(g->mw4), mut(g->mw2), gmw0p + 2 * C, mut(g->dw2)};
+      const int ldgs[4] = {C, C, Wp, C};
+      float* gbs[4] = {mut(g->mb4), mut(g->mb2), mut(g->mb0), mut(g->db2)};
+      if (int rc = launch_pair_chain_bwd(d_out, atom_mask, d->K, d->A, kCA, row0, nrows, Xs, Wsrc, ldws, dC, dh1, Gs, ldgs, gbs, chain_prep, st))
+        return rc;
+    } else {
+      // ---- mlp[4], mlp[2]
+      hipLaunchKernelGGL(pair_mask_bwd_kernel, dim3(static_cast<unsigned>((nrows * C + 255) / 256)), dim3(256), 0, st, d_out, atom_mask, d->K,
+                         d->A, C, row0, nrows, dA);
+      DIFFAB_LAUNCH_CHECK();
+      // ---- the dX chain: four 64 x 64 products, each masked by the ReLU below it in the product's epilogue
+      //      dA = d out (masked) -> dB = d mlp[2] pre-activation -> dC = d mlp[0] pre-activation -> ddf -> dh1
+      if (int rc = bwd_gemm_nn_masked(dA, C, w->mw4, C, dB, C, rows, C, C, m2, st)) return rc;
+      if (int rc = bwd_gemm_nn_masked(dB, C, w->mw2, C, dC, C, rows, C, C, m1, st)) return rc;
+      if (int rc = bwd_gemm_nn_masked(dC, C, mw0p + 2 * C, Wp, ddf, C, rows, C, C, df, st)) return rc;  // distance_embedding ends with a ReLU (:212-217)
+      if (int rc = bwd_gemm_nn_masked(ddf, C, w->dw2, C, dh1, C, rows, C, C, h1, st)) return rc;
+      // ---- the four 64 x 64 weight gradients (+ bias gradients) of mlp[4], mlp[2], mlp[0][:, 2C:3C], distance_embedding[2] in one launch
+      {
+        const float* As[4] = {dA, dB, dC, ddf};
+        const float* Bs[4] = {m2, m1, df, h1};
+        float* Cs[4] = {mut(g->mw4), mut(g->mw2), gmw0p + 2 * C, mut(g->dw2)};
+        const int ldcs[4] = {C, C, Wp, C};
+        float* dbs[4] = {mut(g->mb4), mut(g->mb2), mut(g->mb0), mut(g->db2)};
+        if (int rc = bwd_tn64_set(4, As, Bs, Cs, ldcs, dbs, nrows, st)) return rc;
+      }
     }
     // ---- the rest of mlp[0] without its concatenation: the dihedral-encoding columns [3C, 3C + 18) are a plain product; the table
     // segments go through G1 / G2 after the loop

@@ -373,6 +373,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ipa_attn_fast_kernel
 }
 
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics only (diffab_debug_set_attn_stamps)
+static bool g_pair_chain_off = false;                // diffab_debug_set_attn_variant bit 6 (64)
 static bool g_tn_b6 = false;                         // diffab_debug_set_attn_variant bit 5 (32)
 static int g_attn_variant = 0;                       // diagnostics only (diffab_debug_set_attn_variant): 1 = four-wave work-groups
 static bool g_value_planes = false;                  // diffab_debug_set_attn_variant bit 4 (16): the value side of P x V as fp16 planes (measured, not the default:
@@ -381,11 +382,13 @@ bool value_planes_enabled() { return g_value_planes; }
 void set_pair_embed_fused(bool on);  // pair_embed_fused.hip
 void set_attn_variant(int v) {       // A/B switches for tests and tools (include/diffab_hip.h)
   g_attn_variant = v & 9;  // 1: four-wave attention work-groups; 8: the two big dense products of a layer as six-term bf16 products
+  g_pair_chain_off = (v & 64) != 0;  // 64: the PairEmbedding backward's 64-wide tail as its separate launches (A/B of pair_chain_bwd_kernel)
   g_tn_b6 = (v & 32) != 0;  // 32: the weight-gradient products of the training backward in the six-term bf16 form (A/B of gemm_tn_h3_kernel)
   set_pair_embed_fused(!(v & 4));
   g_value_planes = (v & 16) != 0;  // 16: value planes - phase 3 of the attention tile on the f16 matrix cores (proj_frames_h3_tile.h "Value planes")
 }
 bool dense_h3_enabled() { return g_attn_variant != 8; }
+bool pair_chain_bwd_enabled() { return !g_pair_chain_off; }
 bool tn_h3_enabled() { return g_attn_variant != 8 && !g_tn_b6; }
 void set_attn_stamps(void* p) {
   g_attn_stamps = static_cast<unsigned long long*>(p);

@@ -1,0 +1,325 @@
+// pair_chain_bwd.hip - the 64-wide tail of the PairEmbedding backward as ONE launch per chunk of pair rows (round 6).
+//
+// Reference: autograd of PairEmbedding.forward, /root/reference/diffab_pytorch/diffab_pytorch.py:186-312 (distance_embedding[2] and its
+// ReLU :212-217, the three Linear layers of `mlp` :219-229, the atom-mask product at the end of forward).  With the hidden activations
+// of a chunk on the tape (pair_embed_fused_kernel<true>) the backward of those four 64 x 64 layers was a mask kernel, four masked d x
+// products, and a four-product weight-gradient launch: 11 passes over 126 MB row buffers per chunk of 30 patches (2.7 GB, 875 us).
+// Here a work-group walks 128-row tiles and keeps a tile on the CU through the whole chain:
+//
+//   d A   = d out * atom_mask_i[CA] * atom_mask_j[CA]                                   (pair_mask_bwd_kernel)
+//   layer 0: d mlp[4].W += d A^T  m2,   d B   = (d A   mlp[4].W)          * [m2 > 0]
+//   layer 1: d mlp[2].W += d B^T  m1,   d C   = (d B   mlp[2].W)          * [m1 > 0]     -> global (the table scatter and the dihedral
+//   layer 2: d mlp[0].W[:, 2C:3C] += d C^T df,  d df = (d C mlp[0].W[:, 2C:3C]) * [df > 0]                  columns read it)
+//   layer 3: d dist[2].W += d df^T h1,  d h1  = (d df  dist[2].W)         * [h1 > 0]     -> global (distance_embedding[0]'s backward)
+//   and the four bias gradients = column sums of d A, d B, d C, d df.
+//
+// It reads d out and the four taped activations once (5 x 32 KiB per tile) and writes d C and d h1 (2 x 32 KiB): 880 MB per chunk.
+// Arithmetic: bf16 x 6 split products (three exact bf16 pieces per operand, six partial products, fp32 accumulation - gemm_bf16x6.hip):
+// fp32 accuracy without any scale bookkeeping for gradients that span decades.  Per layer a tile's d y and x sit in LDS as split
+// planes [128 rows][64 columns] in ONE orientation that serves three reads: the d x product takes d y rows as the MFMA's B operand
+// (ds_read_b128; the weights are the A operand, so a lane ends with four consecutive columns of one row: the next layer's d y goes back
+// into the planes as 8-byte pieces, mlp_chain_tile.h's arrangement), the weight gradient contracts over the ROWS and takes both
+// operands through the transposing read ds_read_b64_tr_b16 (gemm_tn_b6_kernel's arrangement), the ReLU mask is the sign of x's high
+// plane.  Weight fragments come pre-split and fragment-ordered from a 96 KiB prep buffer (L2-resident), one layer at a time.  The
+// weight and bias gradients stay in registers over all tiles of the work-group and leave as one set of atomics at the end.
+#include "common.h"
+#include "denoiser_internal.h"
+#include "rowgemm_b6_tile.h"
+
+namespace diffab {
+namespace {
+using b6tile::split3;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define PC_FENCE() asm volatile("" ::: "memory")
+
+constexpr int PC_C = 64, PC_ROWS = 128;
+constexpr int PC_PLANE = PC_ROWS * PC_C;                 // bf16 elements of one plane of one operand (16 KiB)
+constexpr int PC_LDS_BYTES = 2 * 3 * PC_PLANE * 2 + 4 * 64 * 64 * 4;  // d y planes | x planes | the four weight-gradient accumulators: 160 KiB
+constexpr int PC_WFRAG = 4 * 2 * 3 * 4 * 64 * 8;         // bf16 elements of the prep buffer: [layer][k step][plane][column tile][lane][8]
+// bf16 element offset of the 16-byte chunk `chunk` (8 columns) of row `row`: rows are 128 bytes = all 32 banks, so the chunk index is
+// swizzled with the row - four consecutive rows (a transposing read's 16-lane group) land on four different chunk PAIRS, eight
+// consecutive rows (a ds_read_b128's eight lanes per cycle) on eight different chunks
+__device__ __forceinline__ int pc_off(int row, int chunk) { return row * PC_C + 8 * (chunk ^ (((row & 3) << 1) | ((row >> 2) & 1))); }
+
+struct PairChainArgs {
+  const float* d_out;   // [B K K][64], the whole tensor
+  const float* amask;   // [B K][A]
+  const float* X[4];    // taped activations of the chunk: m2, m1, df, h1, [nrows][64]
+  const __bf16* wfrag;  // prep buffer (pair_chain_prep_kernel)
+  float* dC;            // [nrows][64]
+  float* dh1;           // [nrows][64]
+  float* gW[4];         // weight gradients (+=), rows ldg[.] floats apart
+  int ldg[4];
+  float* gb[4];         // bias gradients (+=)
+  int64_t row0, nrows;  // the chunk's rows inside d_out; nrows a multiple of 128
+  int K, A, ca;
+};
+
+// W_L[n][i] (rows ldw floats apart) -> A fragments of W_L^T for v_mfma_f32_16x16x32_bf16: fragment (L, ks, plane, mi), lane (l15, g):
+// the eight values W_L[32 ks + 8 g + c][16 mi + l15], c = 0..7
+__global__ void pair_chain_prep_kernel(const float* __restrict__ W0, int ld0, const float* __restrict__ W1, int ld1, const float* __restrict__ W2,
+                                       int ld2, const float* __restrict__ W3, int ld3, __bf16* __restrict__ out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (L, ks, mi, lane, c)
+  if (gid >= 4 * 2 * 4 * 64 * 8) return;
+  const int c = gid & 7, lane = (gid >> 3) & 63, mi = (gid >> 9) & 3, ks = (gid >> 11) & 1, L = gid >> 12;
+  const float* W = L == 0 ? W0 : L == 1 ? W1 : L == 2 ? W2 : W3;
+  const int ld = L == 0 ? ld0 : L == 1 ? ld1 : L == 2 ? ld2 : ld3;
+  const int n = 32 * ks + 8 * (lane >> 4) + c, i = 16 * mi + (lane & 15);
+  __bf16 h, m, l;
+  split3(W[n * ld + i], h, m, l);
+  const size_t base = ((static_cast<size_t>(L * 2 + ks) * 3) * 4 + mi) * 512 + lane * 8 + c;
+  out[base] = h;
+  out[base + 4 * 512] = m;
+  out[base + 8 * 512] = l;
+}
+
+__global__ __launch_bounds__(512) void pair_chain_bwd_kernel(PairChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 pc_lds[];
+  __bf16* Yp = pc_lds;                 // d y planes [3][128][64]
+  __bf16* Xp = pc_lds + 3 * PC_PLANE;  // x planes
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int ntiles = static_cast<int>(a.nrows / PC_ROWS);
+  // ---- staging: thread -> rows (tid >> 4) + 32 j, float4 column tid & 15 of a 128 x 64 tile
+  const int s_row = tid >> 4, s_c4 = tid & 15;
+  auto load_tile = [&](f32x4 (&r)[4], const float* src, int tile) {
+    const float* p = src + (static_cast<int64_t>(tile) * PC_ROWS + s_row) * PC_C + 4 * s_c4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * PC_C);
+  };
+  f32x4 csumA = {0.f, 0.f, 0.f, 0.f};  // bias gradient of layer 0: column sums of d A over this thread's rows
+  auto load_dA = [&](f32x4 (&r)[4], int tile) {
+    // a tile is 128 consecutive j of ONE (patch, i) (K is a multiple of 128): the divisions are per tile and wave-uniform
+    const int64_t t0 = a.row0 + static_cast<int64_t>(tile) * PC_ROWS;
+    const int64_t bi = t0 / a.K;  // b K + i
+    const int j0 = static_cast<int>(t0 - bi * a.K);
+    const int64_t bK = (bi / a.K) * a.K;
+    const float mi_ = a.amask[bi * a.A + a.ca];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rl = s_row + 32 * j;
+      const float mk = mi_ * a.amask[(bK + j0 + rl) * a.A + a.ca];
+      r[j] = *reinterpret_cast<const f32x4*>(a.d_out + (t0 + rl) * PC_C + 4 * s_c4) * mk;
+    }
+  };
+  auto stage = [&](__bf16* planes, const f32x4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __bf16 hh, mm, ll;
+        split3(r[j][c], hh, mm, ll);
+        h[c] = hh; m[c] = mm; l[c] = ll;
+      }
+      __bf16* dst = planes + pc_off(s_row + 32 * j, s_c4 >> 1) + 4 * (s_c4 & 1);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + PC_PLANE) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * PC_PLANE) = l;
+    }
+  };
+  // ---- d x product: wave = (column tile mi of the OUTPUT, row half ch): four 16 x 16 tiles D^T[i = 16 mi + 4 g + e][row 64 ch + 16 ct + l15]
+  const int mi = wv & 3, ch = wv >> 2;
+  // ---- weight gradient: wave = (n tile nt, i tiles 2 (wv >> 2) + t): D[n = 16 nt + 4 g + e][i = 16 it + l15], contraction over the tile's rows
+  const int nt = wv & 3, it0 = 2 * (wv >> 2);
+  const int q = l15 >> 2, pp = l15 & 3;
+  auto frag_tr = [&](const __bf16* plane, int kk, int cb) -> bf16x8 {  // rows 32 kk + 8 g + 4 rd + q, the 16-column block cb
+    const int r0 = 32 * kk + 8 * g + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0 + 4, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};  // (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+  // weight-gradient accumulators over all tiles of this work-group: in LDS (32 registers otherwise - the kernel spilled), each wave its
+  // own 16-byte slots [layer][wave][tile t][lane]
+  f32x4* gws = reinterpret_cast<f32x4*>(pc_lds + 6 * PC_PLANE);
+  auto gw_slot = [&](int L, int t) -> f32x4* { return gws + ((L * 8 + wv) * 2 + t) * 64 + lane; };
+#pragma unroll
+  for (int L = 0; L < 4; ++L)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) *gw_slot(L, t) = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 gbv[3];    // bias gradients of layers 1..3: this lane's four columns 16 mi + 4 g + e over its rows
+#pragma unroll
+  for (int L = 0; L < 3; ++L) gbv[L] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tile = blockIdx.x;
+  f32x4 RA[4], RX[4];
+  if (tile < ntiles) {
+    load_dA(RA, tile);
+    load_tile(RX, a.X[0], tile);
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) csumA += RA[j];
+    stage(Yp, RA);
+    stage(Xp, RX);
+    PC_FENCE();
+    __syncthreads();
+#pragma unroll
+    for (int L = 0; L < 4; ++L) {
+      // ---- requests of this phase: the weight fragments of the layer, the next layer's x (or the next tile's first two operands)
+      // (the fragment addresses do not depend on the tile: behind an opaque zero, or the compiler hoists all four layers' fragments - 96
+      // registers - out of the tile loop and spills)
+      int zoff = 0;
+      asm volatile("" : "+v"(zoff));
+      bf16x8 wf[2][3];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          wf[ks][p] = *reinterpret_cast<const bf16x8*>(a.wfrag + ((static_cast<size_t>(L * 2 + ks) * 3 + p) * 4 + mi) * 512 + lane * 8 + zoff);
+      const int tnext = tile + static_cast<int>(gridDim.x);
+      if (L < 3) load_tile(RX, a.X[L + 1], tile);
+      else if (tnext < ntiles) {
+        load_dA(RA, tnext);
+        load_tile(RX, a.X[0], tnext);
+      }
+      PC_FENCE();
+      // ---- weight gradient of the layer: d y^T x over the tile's 128 rows
+      f32x4 gw[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) gw[t] = *gw_slot(L, t);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 fa[3], fb[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[p] = frag_tr(Yp + p * PC_PLANE, kk, nt);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) fb[t][p] = frag_tr(Xp + p * PC_PLANE, kk, it0 + t);
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            gw[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[TA[term]], fb[t][TB[term]], gw[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) *gw_slot(L, t) = gw[t];
+      // ---- d x = d y W, masked by the ReLU below it
+      f32x4 o[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int r = 64 * ch + 16 * ct + l15;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 fy[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fy[p] = *reinterpret_cast<const bf16x8*>(Yp + p * PC_PLANE + pc_off(r, g + 4 * ks));
+#pragma unroll
+          for (int term = 0; term < 6; ++term) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][TA[term]], fy[TB[term]], acc, 0, 0, 0);
+        }
+        // columns 16 mi + 4 g .. + 3 of row r: x > 0 <=> its high piece > 0 (bf16 has fp32's exponent range)
+        const bf16x4 xh = *reinterpret_cast<const bf16x4*>(Xp + pc_off(r, 2 * mi + (g >> 1)) + 4 * (g & 1));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[ct][e] = static_cast<float>(xh[e]) > 0.0f ? acc[e] : 0.0f;
+      }
+      if (L < 3) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) gbv[L] += o[ct];
+      }
+      if (L == 1 || L == 3) {
+        float* out = (L == 1 ? a.dC : a.dh1) + (static_cast<int64_t>(tile) * PC_ROWS + 64 * ch + l15) * PC_C + 16 * mi + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(out + 16 * ct * PC_C) = o[ct];
+      }
+      PC_FENCE();
+      __syncthreads();  // every wave has read this layer's planes
+      if (L < 3) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int r = 64 * ch + 16 * ct + l15;
+          bf16x4 h, m, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            __bf16 hh, mm, ll;
+            split3(o[ct][e], hh, mm, ll);
+            h[e] = hh; m[e] = mm; l[e] = ll;
+          }
+          __bf16* dst = Yp + pc_off(r, 2 * mi + (g >> 1)) + 4 * (g & 1);
+          *reinterpret_cast<bf16x4*>(dst) = h;
+          *reinterpret_cast<bf16x4*>(dst + PC_PLANE) = m;
+          *reinterpret_cast<bf16x4*>(dst + 2 * PC_PLANE) = l;
+        }
+        stage(Xp, RX);
+        PC_FENCE();
+        __syncthreads();
+      }
+      // (L == 3: the loop head stages the next tile and holds the barrier)
+    }
+  }
+  // ---- the gradients of this work-group: weight tiles as atomics; bias sums through LDS (all planes are dead behind the last barrier)
+#pragma unroll
+  for (int L = 0; L < 4; ++L)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 gw = *gw_slot(L, t);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(a.gW[L] + static_cast<int64_t>(16 * nt + 4 * g + e) * a.ldg[L] + 16 * (it0 + t) + l15, gw[e]);
+    }
+  float* red = reinterpret_cast<float*>(pc_lds);  // [4 layers][64 columns]
+  if (tid < 256) red[tid] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) atomicAdd(red + 4 * s_c4 + c, csumA[c]);
+#pragma unroll
+  for (int L = 0; L < 3; ++L)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(red + 64 * (L + 1) + 16 * mi + 4 * g + e, gbv[L][e]);
+  __syncthreads();
+  if (tid < 256 && a.gb[tid >> 6] != nullptr) atomicAdd(a.gb[tid >> 6] + (tid & 63), red[tid]);
+}
+}  // namespace
+
+size_t pair_chain_bwd_prep_floats() { return PC_WFRAG / 2 + 64; }
+bool pair_chain_bwd_supported(int C, int K, int64_t nrows) { return C == PC_C && K % PC_ROWS == 0 && nrows % PC_ROWS == 0 && nrows >= PC_ROWS; }
+
+// W: {mlp[4].W, mlp[2].W, mlp[0].W[:, 2C:3C], distance_embedding[2].W} with their leading dimensions; X: {m2, m1, df, h1}; gW / ldg / gb:
+// the matching gradients.  prep: pair_chain_bwd_prep_floats() floats, 16-byte aligned, overwritten.
+int launch_pair_chain_bwd(const float* d_out, const float* amask, int K, int A, int ca, int64_t row0, int64_t nrows, const float* const* X,
+                          const float* const* W, const int* ldw, float* dC, float* dh1, float* const* gW, const int* ldg, float* const* gb,
+                          float* prep, hipStream_t st) {
+  DIFFAB_REQUIRE(d_out && amask && X && W && dC && dh1 && gW && gb && prep && (reinterpret_cast<uintptr_t>(prep) & 15) == 0 &&
+                     pair_chain_bwd_supported(PC_C, K, nrows) && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dC) & 15) == 0 && (reinterpret_cast<uintptr_t>(dh1) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_chain_bwd: unsupported operands");
+  PairChainArgs a{};
+  a.d_out = d_out;
+  a.amask = amask;
+  for (int i = 0; i < 4; ++i) {
+    DIFFAB_REQUIRE(X[i] && W[i] && gW[i] && (reinterpret_cast<uintptr_t>(X[i]) & 15) == 0, DIFFAB_ERR_ARG, "pair_chain_bwd: bad operand %d", i);
+    a.X[i] = X[i];
+    a.gW[i] = gW[i];
+    a.ldg[i] = ldg[i];
+    a.gb[i] = gb[i];
+  }
+  a.wfrag = reinterpret_cast<const __bf16*>(prep);
+  a.dC = dC;
+  a.dh1 = dh1;
+  a.row0 = row0;
+  a.nrows = nrows;
+  a.K = K;
+  a.A = A;
+  a.ca = ca;
+  hipLaunchKernelGGL(pair_chain_prep_kernel, dim3((4 * 2 * 4 * 64 * 8 + 255) / 256), dim3(256), 0, st, W[0], ldw[0], W[1], ldw[1], W[2], ldw[2],
+                     W[3], ldw[3], reinterpret_cast<__bf16*>(prep));
+  DIFFAB_LAUNCH_CHECK();
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t ntiles = nrows / PC_ROWS;
+  const int grid = static_cast<int>(ntiles < ncu ? ntiles : ncu);  // one work-group per CU (96 KiB of LDS), each walks its tiles
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       PC_LDS_BYTES));
+  hipLaunchKernelGGL(pair_chain_bwd_kernel, dim3(grid), dim3(512), PC_LDS_BYTES, st, a);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
+}  // namespace diffab

@@ -1057,6 +1057,13 @@ def test_fused_pair_embedding_k128_vs_unfused_and_oracle(hip):
         print("fused vs unfused PairEmbedding (%s): forward %.1e, worst gradient %s %.1e" % ("xyz" if distmat is None else "distmat",
                                                                                             maxrel(pf, pu), worst[0], worst[1]))
         assert worst[1] < 1e-4, worst
+        # round 6: the 64-wide tail of the backward as one launch per chunk (csrc/pair_chain_bwd.hip) against its separate launches
+        # (variant 64: mask kernel, four masked d x products, the four-product weight-gradient launch) - both fp32-accurate
+        ps, gs = run(distmat, 64)
+        assert torch.equal(pf, ps)
+        worst = max(((n, maxrel(gf[n], gs[n])) for n in names), key=lambda t_: t_[1])
+        print("  one-launch chain vs separate launches: worst gradient %s %.1e" % worst)
+        assert worst[1] < 2e-5, worst
     # the oracle (and its autograd) on patch 0, distances from the materialised tensor
     csd = {k: v.clone().requires_grad_(k.startswith("pair_context_embedding.")) for k, v in sd.items()}
     b1 = {k: (v[:1] if v.shape[0] == B else v) for k, v in cbc.items()}

@@ -1,6 +1,8 @@
 """Timing of DiffAb.encode_context at the benchmark model: B patches of K residues, A=15 atoms;
 with the materialised distance tensor (reference signature) and with distances taken from xyz inside the pair kernel.
-usage: encode_context_bench.py [B] [K] [--backward]   (--backward: forward + backward of both encoders from random cotangents, xyz form)"""
+usage: encode_context_bench.py [B] [K] [--backward] [--variant=N]
+(--backward: forward + backward of both encoders from random cotangents, xyz form; --variant: diffab_debug_set_attn_variant, e.g. 64 =
+the backward's 64-wide tail as separate launches)"""
 import os
 import sys
 import time
@@ -9,12 +11,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "diffab-pytorch_amd"))
 import torch  # noqa: E402
 
-from diffab_pytorch import DiffAb, synthetic as syn  # noqa: E402
+from diffab_pytorch import DiffAb, _hip, synthetic as syn  # noqa: E402
 
 BACKWARD = "--backward" in sys.argv
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(argv[0]) if len(argv) > 0 else 32
 K = int(argv[1]) if len(argv) > 1 else 128
+for a_ in sys.argv[1:]:
+    if a_.startswith("--variant="):
+        _hip.lib().diffab_debug_set_attn_variant(int(a_.split("=")[1]))
 d = syn.BENCH_DIMS
 model = DiffAb(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
 model.load_state_dict(syn.context_state_dict(d["D"], d["C"], 15, 32, seed=1), strict=False)
