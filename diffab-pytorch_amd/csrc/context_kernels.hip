@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void pair_cat_bwd_lds_kernel(const float* __re
 // The folded backward of mlp[0] (pair_embed_fused.hip): with g = d (mlp[0] pre-activation) [rows][C], the two embedding-table segments
 // of the concatenation need only G1[s_i 21 + s_j] += g and G2[rel] += same g (summed per work-group in LDS, flushed once); everything
 // about aa_pair_emb, relpos_emb and the first 2 C columns of mlp[0].weight follows from G1 / G2 by 441- and 65-row products.
-__global__ __launch_bounds__(256) void pair_table_scatter_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq,
+__global__ __launch_bounds__(1024) void pair_table_scatter_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq,
                                                                  const uint8_t* __restrict__ seq_m, const int64_t* __restrict__ resid,
                                                                  int resid_bstride, const int64_t* __restrict__ chain, int K, int C, int max_dist,
                                                                  int64_t row0, int64_t nrows, float* __restrict__ G1, float* __restrict__ G2) {
@@ -407,11 +407,12 @@ __global__ __launch_bounds__(256) void pair_table_scatter_kernel(const float* __
   // behind dependent index loads, one row per wave and pass, the index arithmetic was this kernel's time)
   const int64_t b00 = row0 / (static_cast<int64_t>(K) * K);
   const unsigned KK = static_cast<unsigned>(K) * static_cast<unsigned>(K), nr = static_cast<unsigned>(nrows);
-  const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;  // rows scattered per pass (4 at C = 64)
+  const int rpb = blockDim.x / C > 0 ? blockDim.x / C : 1;  // rows scattered per pass (16 at C = 64 with 1024 threads: the loop is bound by
+                                                            // the latency of its row loads, round 6: 300 -> us per chunk with 256 threads)
   const int c0 = threadIdx.x % C, rsub = threadIdx.x / C;
   for (unsigned blk = blockIdx.x * 256u; blk < nr; blk += gridDim.x * 256u) {
     __syncthreads();  // the previous block's constants are consumed (first trip: the tables are zero)
-    {  // lanes = rows: every thread the constants of one row (coalesced index loads)
+    if (threadIdx.x < 256) {  // lanes = rows: the first 256 threads take the constants of one row each (coalesced index loads)
       const unsigned lr = blk + threadIdx.x;
       if (lr < nr) {
         const unsigned bl = lr / KK, rem = lr - bl * KK;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void pair_table_scatter_kernel(const float* __
     }
     __syncthreads();
     if (rsub < rpb) {  // lanes = channels: rpb rows per pass, four passes' loads in flight
-#pragma unroll 4
+#pragma unroll 16
       for (int r = rsub; r < 256; r += rpb) {
         const unsigned lr = blk + r;
         if (lr < nr) {
@@ -441,10 +442,11 @@ __global__ __launch_bounds__(256) void pair_table_scatter_kernel(const float* __
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n_pair; i += blockDim.x)
-    if (tab[i] != 0.0f) atomicAdd(G1 + i, tab[i]);
-  for (int i = threadIdx.x; i < n_rel; i += blockDim.x)
-    if (tab[n_pair + i] != 0.0f) atomicAdd(G2 + i, tab[n_pair + i]);
+  // the work-group's tables -> its own slab G1[blockIdx.x][n_pair + n_rel] (G2 unused): 256 work-groups adding 32 384 values each to the
+  // same addresses were 8 M atomics per launch - most of this kernel's 296 us; launch_parts_reduce sums the slabs
+  float* slab = G1 + static_cast<size_t>(blockIdx.x) * (n_pair + n_rel);
+  (void)G2;
+  for (int i = threadIdx.x; i < n_pair + n_rel; i += blockDim.x) slab[i] = tab[i];
 }
 // enc[lr][0:18] = AngularEncoding(2) of the row's two pairwise dihedrals (what pair_cat_kernel puts behind the three C-wide segments), [18:20] = 0
 __global__ void pair_enc_kernel(const float* __restrict__ pdih, int64_t row0, int64_t nrows, float* __restrict__ enc) {
@@ -456,6 +458,37 @@ __global__ void pair_enc_kernel(const float* __restrict__ pdih, int64_t row0, in
   angular_encode(pdih[(row0 + lr) * 2 + t], 2, e);
   for (int k = 0; k < 9; ++k) enc[lr * 20 + t * 9 + k] = e[k];
   if (t == 1) { enc[lr * 20 + 18] = 0.0f; enc[lr * 20 + 19] = 0.0f; }
+}
+
+// gW[n][e] += sum_r g[r][n] enc[r][e], n < 64, e < NE (the dihedral-encoding columns of mlp[0].weight: 64 x 18 of 64 x 210).  As a tile
+// of the weight-gradient GEMM this product used 20 of 128 columns and took 166 us per chunk; here lane = n, the row index is
+// wave-uniform, so a row of enc arrives through the scalar cache and the products are NE v_fmac with a scalar operand per 256-byte
+// row of g: bound by the 126 MB read of g.
+template <int NE>
+__global__ __launch_bounds__(256) void pair_enc_tn_kernel(const float* __restrict__ g, const float* __restrict__ enc, int64_t nrows,
+                                                          float* __restrict__ gW, int ldg) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int nwaves = static_cast<int>(gridDim.x) * 4;
+  float acc[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) acc[e] = 0.0f;
+#pragma unroll 8
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const float v = g[r * 64 + lane];
+    const float* er = enc + r * NE;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = __builtin_fmaf(v, er[e], acc[e]);
+  }
+  __shared__ float red[4][NE][64];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) red[threadIdx.x >> 6][e][lane] = acc[e];
+  __syncthreads();
+  (void)ldg;
+  for (int i = threadIdx.x; i < NE * 64; i += 256) {  // -> the work-group's slab gW[blockIdx.x][n][e] (launch_parts_reduce sums the slabs)
+    const int n = i / NE, e = i % NE;
+    gW[static_cast<size_t>(blockIdx.x) * (NE * 64) + i] = (red[0][e][n] + red[1][e][n]) + (red[2][e][n] + red[3][e][n]);
+  }
 }
 
 // d softplus(coef)[si*21+sj][p] += ddin[row][p] * d din / d c,  din = exp(-c d^2) mask  =>  d din / d c = -d^2 din
@@ -796,11 +829,15 @@ static int fused_bwd_chunk_patches(const diffab_ctx_dims* d) {
   const size_t n = (static_cast<size_t>(2) << 30) / per_patch;  // ~2 GiB of row buffers at a time (30 K = 128 patches)
   return static_cast<int>(n < 1 ? 1 : (n > static_cast<size_t>(d->B) ? d->B : n));
 }
+static size_t fused_bwd_parts_floats(const diffab_ctx_dims* d) {
+  const size_t a = pair_chain_bwd_part_floats(), b = static_cast<size_t>(256) * (kAA * kAA + 2 * d->max_dist + 1) * d->C, c = 2048 * 20 * 64;
+  return (a > b ? (a > c ? a : c) : (b > c ? b : c)) + 64;
+}
 static size_t fused_bwd_workspace_floats(const diffab_ctx_dims* d) {
   const size_t R = static_cast<size_t>(fused_bwd_chunk_patches(d)) * d->K * d->K;
   const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
   return R * (9 * d->C + 2 * AA2p + 20) + 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + static_cast<size_t>(kAA) * kAA * d->A * d->A +
-         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + pair_chain_bwd_prep_floats() + 1024;
+         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + pair_chain_bwd_prep_floats() + fused_bwd_parts_floats(d) + 1024;
 }
 
 static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
@@ -833,6 +870,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
   float* G2 = G1 + static_cast<size_t>(kAA) * kAA * C;
   float* prep = cv.take<float>(pair_embed_fused_prep_floats(d));
   float* chain_prep = cv.take<float>(pair_chain_bwd_prep_floats());
+  float* parts = cv.take<float>(fused_bwd_parts_floats(d));  // per-work-group partial sums of the chain / scatter / narrow-product kernels
   auto mut = [](const float* p) { return const_cast<float*>(p); };
   hipLaunchKernelGGL(pad_rows_kernel, dim3((C * AA2p + 255) / 256), dim3(256), 0, st, w->dw0, AA2, C, dw0p, AA2p);
   hipLaunchKernelGGL(pad_rows_kernel, dim3((C * Wp + 255) / 256), dim3(256), 0, st, w->mw0, W, C, mw0p, Wp);
@@ -860,7 +898,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
       float* Gs[4] = {mut(g->mw4), mut(g->mw2), gmw0p + 2 * C, mut(g->dw2)};
       const int ldgs[4] = {C, C, Wp, C};
       float* gbs[4] = {mut(g->mb4), mut(g->mb2), mut(g->mb0), mut(g->db2)};
-      if (int rc = launch_pair_chain_bwd(d_out, atom_mask, d->K, d->A, kCA, row0, nrows, Xs, Wsrc, ldws, dC, dh1, Gs, ldgs, gbs, chain_prep, st))
+      if (int rc = launch_pair_chain_bwd(d_out, atom_mask, d->K, d->A, kCA, row0, nrows, Xs, Wsrc, ldws, dC, dh1, Gs, ldgs, gbs, chain_prep, parts, st))
         return rc;
     } else {
       // ---- mlp[4], mlp[2]
@@ -888,12 +926,26 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
     hipLaunchKernelGGL(pair_enc_kernel, dim3(static_cast<unsigned>((nrows * 2 + 255) / 256)), dim3(256), 0, st, pairwise_dihedrals, row0, nrows,
                        enc);
     DIFFAB_LAUNCH_CHECK();
-    if (int rc = bwd_gemm_tn(dC, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) return rc;
+    if (C == 64 && Wp - 3 * C == 20) {
+      hipLaunchKernelGGL(pair_enc_tn_kernel<20>, dim3(1024), dim3(256), 0, st, dC, enc, nrows, parts, 0);
+      DIFFAB_LAUNCH_CHECK();
+      PartsSegs sg{};
+      sg.nseg = 1; sg.off[0] = 0; sg.n[0] = 20 * 64; sg.cols[0] = 20; sg.ld[0] = Wp; sg.out[0] = gmw0p + 3 * C;
+      if (int rc = launch_parts_reduce(parts, 1024, 20 * 64, sg, st)) return rc;
+    } else if (int rc = bwd_gemm_tn(dC, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) {
+      return rc;
+    }
     DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_table_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          static_cast<int>(tab_bytes)));
-    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(256), tab_bytes, st, dC, seq_idx, sequence_context_mask, residue_idx,
-                       residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, G1, G2);
+    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(1024), tab_bytes, st, dC, seq_idx, sequence_context_mask, residue_idx,
+                       residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, parts, nullptr);
     DIFFAB_LAUNCH_CHECK();
+    {
+      const int n_tab = (kAA * kAA + 2 * d->max_dist + 1) * C;
+      PartsSegs sg{};
+      sg.nseg = 1; sg.off[0] = 0; sg.n[0] = n_tab; sg.cols[0] = n_tab; sg.ld[0] = n_tab; sg.out[0] = G1;  // (G1 | G2 adjacent)
+      if (int rc = launch_parts_reduce(parts, 256, n_tab, sg, st)) return rc;
+    }
     // ---- distance_embedding[0]: the only place the 225-wide features are materialised
     {
       const size_t gl_bytes = (static_cast<size_t>(d->K) * d->A * 4 + d->A * 4 + d->K) * sizeof(float);

@@ -198,11 +198,15 @@ int bwd_linear_masked(const float* dY, int ldy, const float* X, int ldx, const f
                       int N, int Kd, const float* relu_act, hipStream_t st);
 // pair_chain_bwd.hip: the four 64-wide layers at the end of the PairEmbedding backward as one launch per chunk of pair rows
 size_t pair_chain_bwd_prep_floats();
+size_t pair_chain_bwd_part_floats();
+// per-work-group partial sums -> their destinations: out[q][(i / cols[q]) ld[q] + i % cols[q]] += sum_p parts[p stride + off[q] + i], i < n[q]
+struct PartsSegs { int nseg; int off[8]; int n[8]; int cols[8]; int ld[8]; float* out[8]; };
+int launch_parts_reduce(const float* parts, int nparts, int64_t stride, const PartsSegs& sg, hipStream_t st);
 bool pair_chain_bwd_supported(int C, int K, int64_t nrows);
 bool pair_chain_bwd_enabled();  // false: diffab_debug_set_attn_variant bit 6 (64): the separate launches (A/B, tests)
 int launch_pair_chain_bwd(const float* d_out, const float* amask, int K, int A, int ca, int64_t row0, int64_t nrows, const float* const* X,
                           const float* const* W, const int* ldw, float* dC, float* dh1, float* const* gW, const int* ldg, float* const* gb,
-                          float* prep, hipStream_t st);
+                          float* prep, float* part, hipStream_t st);
 int bwd_gemm_nn_masked(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* relu_act,
                        hipStream_t st);
 // n <= 4 products C_p[64 x 64] (rows ldc_p apart) += A_p^T B_p of dense [M x 64] operands in one launch; db_p (nullable) += colsum A_p

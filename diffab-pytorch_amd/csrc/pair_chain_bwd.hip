@@ -39,6 +39,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int PC_C = 64, PC_ROWS = 128;
 constexpr int PC_PLANE = PC_ROWS * PC_C;                 // bf16 elements of one plane of one operand (16 KiB)
 constexpr int PC_LDS_BYTES = 2 * 3 * PC_PLANE * 2 + 4 * 64 * 64 * 4;  // d y planes | x planes | the four weight-gradient accumulators: 160 KiB
+constexpr int PC_PART = 4 * 64 * 64 + 4 * 64;            // floats of one work-group's partial sums: four 64 x 64 weight gradients | four biases
 constexpr int PC_WFRAG = 4 * 2 * 3 * 4 * 64 * 8;         // bf16 elements of the prep buffer: [layer][k step][plane][column tile][lane][8]
 // bf16 element offset of the 16-byte chunk `chunk` (8 columns) of row `row`: rows are 128 bytes = all 32 banks, so the chunk index is
 // swizzled with the row - four consecutive rows (a transposing read's 16-lane group) land on four different chunk PAIRS, eight
@@ -52,9 +53,7 @@ struct PairChainArgs {
   const __bf16* wfrag;  // prep buffer (pair_chain_prep_kernel)
   float* dC;            // [nrows][64]
   float* dh1;           // [nrows][64]
-  float* gW[4];         // weight gradients (+=), rows ldg[.] floats apart
-  int ldg[4];
-  float* gb[4];         // bias gradients (+=)
+  float* part;          // [work-groups][PC_PART]: this launch's weight- and bias-gradient sums of every work-group
   int64_t row0, nrows;  // the chunk's rows inside d_out; nrows a multiple of 128
   int K, A, ca;
 };
@@ -255,14 +254,17 @@ __global__ __launch_bounds__(512) void pair_chain_bwd_kernel(PairChainArgs a) {
       // (L == 3: the loop head stages the next tile and holds the barrier)
     }
   }
-  // ---- the gradients of this work-group: weight tiles as atomics; bias sums through LDS (all planes are dead behind the last barrier)
+  // ---- the gradients of this work-group -> its own slab of `part` (256 work-groups adding 16 640 values each to the same addresses
+  // cost more atomics time than the kernel's tiles; parts_reduce_kernel sums the slabs); bias sums through LDS first (all planes are
+  // dead behind the last barrier)
+  float* part = a.part + static_cast<size_t>(blockIdx.x) * PC_PART;
 #pragma unroll
   for (int L = 0; L < 4; ++L)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const f32x4 gw = *gw_slot(L, t);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(a.gW[L] + static_cast<int64_t>(16 * nt + 4 * g + e) * a.ldg[L] + 16 * (it0 + t) + l15, gw[e]);
+      for (int e = 0; e < 4; ++e) part[(L * 64 + 16 * nt + 4 * g + e) * 64 + 16 * (it0 + t) + l15] = gw[e];
     }
   float* red = reinterpret_cast<float*>(pc_lds);  // [4 layers][64 columns]
   if (tid < 256) red[tid] = 0.0f;
@@ -274,19 +276,51 @@ __global__ __launch_bounds__(512) void pair_chain_bwd_kernel(PairChainArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) atomicAdd(red + 64 * (L + 1) + 16 * mi + 4 * g + e, gbv[L][e]);
   __syncthreads();
-  if (tid < 256 && a.gb[tid >> 6] != nullptr) atomicAdd(a.gb[tid >> 6] + (tid & 63), red[tid]);
+  if (tid < 256) part[4 * 64 * 64 + tid] = red[tid];
+}
+
+// out_seg[row][col] += sum over the slabs of part[slab][off_seg + row cols_seg + col]: thread = element (slabs read coalesced),
+// blockIdx.y = a group of 16 slabs whose loads are all in flight at once; one atomic per (element, group)
+constexpr int PR_GROUP = 16;
+__global__ void parts_reduce_kernel(const float* __restrict__ parts, int nparts, int64_t stride, PartsSegs sg) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int q = 0;
+  while (q < sg.nseg && gid >= sg.off[q] + sg.n[q]) ++q;
+  if (q >= sg.nseg || gid < sg.off[q] || sg.out[q] == nullptr) return;
+  const int p0 = blockIdx.y * PR_GROUP;
+  float x[PR_GROUP];
+#pragma unroll
+  for (int i = 0; i < PR_GROUP; ++i) x[i] = p0 + i < nparts ? parts[(p0 + i) * stride + gid] : 0.0f;
+  float v = 0.0f;
+#pragma unroll
+  for (int i = 0; i < PR_GROUP; ++i) v += x[i];
+  const int idx = gid - sg.off[q];
+  atomicAdd(sg.out[q] + static_cast<int64_t>(idx / sg.cols[q]) * sg.ld[q] + idx % sg.cols[q], v);
 }
 }  // namespace
 
+int launch_parts_reduce(const float* parts, int nparts, int64_t stride, const PartsSegs& sg, hipStream_t st) {
+  int total = 0;
+  for (int q = 0; q < sg.nseg; ++q) {
+    DIFFAB_REQUIRE(sg.off[q] >= total && sg.n[q] >= 1 && sg.cols[q] >= 1, DIFFAB_ERR_ARG, "parts_reduce: segments must ascend");
+    total = sg.off[q] + sg.n[q];
+  }
+  hipLaunchKernelGGL(parts_reduce_kernel, dim3((total + 255) / 256, (nparts + PR_GROUP - 1) / PR_GROUP), dim3(256), 0, st, parts, nparts, stride,
+                     sg);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 size_t pair_chain_bwd_prep_floats() { return PC_WFRAG / 2 + 64; }
+size_t pair_chain_bwd_part_floats() { return static_cast<size_t>(256) * PC_PART; }
 bool pair_chain_bwd_supported(int C, int K, int64_t nrows) { return C == PC_C && K % PC_ROWS == 0 && nrows % PC_ROWS == 0 && nrows >= PC_ROWS; }
 
 // W: {mlp[4].W, mlp[2].W, mlp[0].W[:, 2C:3C], distance_embedding[2].W} with their leading dimensions; X: {m2, m1, df, h1}; gW / ldg / gb:
-// the matching gradients.  prep: pair_chain_bwd_prep_floats() floats, 16-byte aligned, overwritten.
+// the matching gradients (+=).  prep: pair_chain_bwd_prep_floats() floats, 16-byte aligned, overwritten; part: pair_chain_bwd_part_floats().
 int launch_pair_chain_bwd(const float* d_out, const float* amask, int K, int A, int ca, int64_t row0, int64_t nrows, const float* const* X,
                           const float* const* W, const int* ldw, float* dC, float* dh1, float* const* gW, const int* ldg, float* const* gb,
-                          float* prep, hipStream_t st) {
-  DIFFAB_REQUIRE(d_out && amask && X && W && dC && dh1 && gW && gb && prep && (reinterpret_cast<uintptr_t>(prep) & 15) == 0 &&
+                          float* prep, float* part, hipStream_t st) {
+  DIFFAB_REQUIRE(d_out && amask && X && W && dC && dh1 && gW && gb && prep && part && (reinterpret_cast<uintptr_t>(prep) & 15) == 0 &&
                      pair_chain_bwd_supported(PC_C, K, nrows) && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(dC) & 15) == 0 && (reinterpret_cast<uintptr_t>(dh1) & 15) == 0,
                  DIFFAB_ERR_ARG, "pair_chain_bwd: unsupported operands");
@@ -296,10 +330,8 @@ int launch_pair_chain_bwd(const float* d_out, const float* amask, int K, int A, 
   for (int i = 0; i < 4; ++i) {
     DIFFAB_REQUIRE(X[i] && W[i] && gW[i] && (reinterpret_cast<uintptr_t>(X[i]) & 15) == 0, DIFFAB_ERR_ARG, "pair_chain_bwd: bad operand %d", i);
     a.X[i] = X[i];
-    a.gW[i] = gW[i];
-    a.ldg[i] = ldg[i];
-    a.gb[i] = gb[i];
   }
+  a.part = part;
   a.wfrag = reinterpret_cast<const __bf16*>(prep);
   a.dC = dC;
   a.dh1 = dh1;
@@ -314,12 +346,19 @@ int launch_pair_chain_bwd(const float* d_out, const float* amask, int K, int A, 
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   const int64_t ntiles = nrows / PC_ROWS;
-  const int grid = static_cast<int>(ntiles < ncu ? ntiles : ncu);  // one work-group per CU (96 KiB of LDS), each walks its tiles
+  int grid = static_cast<int>(ntiles < ncu ? ntiles : ncu);  // one work-group per CU (160 KiB of LDS), each walks its tiles
+  grid = grid > 256 ? 256 : grid;                              // (the partial-sum slabs are sized for 256)
   DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        PC_LDS_BYTES));
   hipLaunchKernelGGL(pair_chain_bwd_kernel, dim3(grid), dim3(512), PC_LDS_BYTES, st, a);
   DIFFAB_LAUNCH_CHECK();
-  return DIFFAB_OK;
+  PartsSegs sg{};
+  sg.nseg = 8;
+  for (int i = 0; i < 4; ++i) {
+    sg.off[i] = i * 64 * 64; sg.n[i] = 64 * 64; sg.cols[i] = 64; sg.ld[i] = ldg[i]; sg.out[i] = gW[i];
+    sg.off[4 + i] = 4 * 64 * 64 + 64 * i; sg.n[4 + i] = 64; sg.cols[4 + i] = 64; sg.ld[4 + i] = 64; sg.out[4 + i] = gb[i];
+  }
+  return launch_parts_reduce(part, grid, PC_PART, sg, st);
 }
 
 }  // namespace diffab
