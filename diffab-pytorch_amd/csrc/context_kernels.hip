@@ -935,16 +935,23 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
     } else if (int rc = bwd_gemm_tn(dC, C, enc, 20, gmw0p + 3 * C, Wp, rows, C, Wp - 3 * C, nullptr, st)) {
       return rc;
     }
-    DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_table_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(tab_bytes)));
-    hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(1024), tab_bytes, st, dC, seq_idx, sequence_context_mask, residue_idx,
-                       residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, parts, nullptr);
-    DIFFAB_LAUNCH_CHECK();
-    {
-      const int n_tab = (kAA * kAA + 2 * d->max_dist + 1) * C;
-      PartsSegs sg{};
-      sg.nseg = 1; sg.off[0] = 0; sg.n[0] = n_tab; sg.cols[0] = n_tab; sg.ld[0] = n_tab; sg.out[0] = G1;  // (G1 | G2 adjacent)
-      if (int rc = launch_parts_reduce(parts, 256, n_tab, sg, st)) return rc;
+    if (pair_chain_bwd_enabled() && pair_table_mfma_supported(C, d->K, nrows, kAA, d->max_dist)) {
+      // the table sums as one-hot products on the matrix cores (pair_chain_bwd.hip): no LDS atomics
+      if (int rc = launch_pair_table_mfma(dC, seq_idx, sequence_context_mask, residue_idx, residue_idx_batch_stride, chain_idx, d->K, d->max_dist,
+                                          kAA, kUNK, row0, nrows, G1, parts, st))
+        return rc;
+    } else {
+      DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_table_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(tab_bytes)));
+      hipLaunchKernelGGL(pair_table_scatter_kernel, dim3(256), dim3(1024), tab_bytes, st, dC, seq_idx, sequence_context_mask, residue_idx,
+                         residue_idx_batch_stride, chain_idx, d->K, C, d->max_dist, row0, nrows, parts, nullptr);
+      DIFFAB_LAUNCH_CHECK();
+      {
+        const int n_tab = (kAA * kAA + 2 * d->max_dist + 1) * C;
+        PartsSegs sg{};
+        sg.nseg = 1; sg.off[0] = 0; sg.n[0] = n_tab; sg.cols[0] = n_tab; sg.ld[0] = n_tab; sg.out[0] = G1;  // (G1 | G2 adjacent)
+        if (int rc = launch_parts_reduce(parts, 256, n_tab, sg, st)) return rc;
+      }
     }
     // ---- distance_embedding[0]: the only place the 225-wide features are materialised
     {

@@ -199,6 +199,9 @@ int bwd_linear_masked(const float* dY, int ldy, const float* X, int ldx, const f
 // pair_chain_bwd.hip: the four 64-wide layers at the end of the PairEmbedding backward as one launch per chunk of pair rows
 size_t pair_chain_bwd_prep_floats();
 size_t pair_chain_bwd_part_floats();
+bool pair_table_mfma_supported(int C, int K, int64_t nrows, int n_aa, int max_dist);
+int launch_pair_table_mfma(const float* g, const int64_t* seq, const uint8_t* seq_m, const int64_t* resid, int resid_bstride, const int64_t* chain,
+                           int K, int max_dist, int n_aa, int unk, int64_t row0, int64_t nrows, float* G1, float* part, hipStream_t st);
 // per-work-group partial sums -> their destinations: out[q][(i / cols[q]) ld[q] + i % cols[q]] += sum_p parts[p stride + off[q] + i], i < n[q]
 struct PartsSegs { int nseg; int off[8]; int n[8]; int cols[8]; int ld[8]; float* out[8]; };
 int launch_parts_reduce(const float* parts, int nparts, int64_t stride, const PartsSegs& sg, hipStream_t st);

@@ -279,6 +279,149 @@ __global__ __launch_bounds__(512) void pair_chain_bwd_kernel(PairChainArgs a) {
   if (tid < 256) part[4 * 64 * 64 + tid] = red[tid];
 }
 
+// ================================================================== the embedding-table segments of mlp[0]'s backward as matrix products
+// G1[s_i 21 + s_j][c] += g[row][c] and G2[rel][c] += same g[row][c] (pair_table_scatter_kernel's sums) are products with one-hot
+// operands: G = OneHot^T g, contraction over the rows.  As LDS atomics they were this backward's slowest small kernel (290 us per chunk:
+// a 64-lane ds_add_f32 takes about 130 cycles; 48 us with the atomics taken out).  Here the matrix cores do the class reduction: the
+// g tile is staged as three bf16 planes (exact fp32 split, the chain kernel's layout and transposing reads), the one-hot A fragments
+// are built in registers from the rows' class ids (1.0 and small integers are exact in bf16: three partial products, no rounding
+// beyond the fp32 accumulation), and the 33 x 4 output tiles (441 -> 448 pair classes, 65 -> 80 relative positions, 64 channels) stay
+// in the accumulators of the work-group's eight waves over all its tiles.  No table in LDS, no atomics; the work-group's sums leave
+// as one slab for launch_parts_reduce.
+constexpr int PT_MT = 33;  // 16-class output tiles: 28 for the pair classes, 5 for the relative positions
+struct PairTableArgs {
+  const float* g;  // [nrows][64] (chunk-local)
+  const int64_t* seq; const uint8_t* seq_m; const int64_t* resid; const int64_t* chain;
+  float* part;  // [work-groups][(n_pair_rows + n_rel_rows) * 64]
+  int64_t row0, nrows;
+  int K, resid_bstride, max_dist, n_aa, unk;
+};
+__global__ __launch_bounds__(512) void pair_table_mfma_kernel(PairTableArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 pt_lds[];
+  __bf16* Gp = pt_lds;                                            // g planes [3][128][64]
+  int* cls = reinterpret_cast<int*>(pt_lds + 3 * PC_PLANE);       // [128] pair class of row j
+  int* rel = cls + PC_ROWS;                                       // [128] relative-position row
+  float* same = reinterpret_cast<float*>(rel + PC_ROWS);          // [128] chain_i chain_j
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int ntiles = static_cast<int>(a.nrows / PC_ROWS);
+  const int n_pair = a.n_aa * a.n_aa, n_rel = 2 * a.max_dist + 1;
+  const int s_row = tid >> 4, s_c4 = tid & 15;  // staging: rows (tid >> 4) + 32 j, float4 column tid & 15
+  const int q = l15 >> 2, pp = l15 & 3;
+  auto frag_tr = [&](const __bf16* plane, int kk, int cb) -> bf16x8 {
+    const int r0 = 32 * kk + 8 * g + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0 + 4, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  // this wave's class tiles: wv + 8 m (< 33); four channel tiles each
+  constexpr int PT_M = 5;
+  f32x4 acc[PT_M][4];
+#pragma unroll
+  for (int m = 0; m < PT_M; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 R[4];
+  auto load_g = [&](int tile) {
+    const float* p = a.g + (static_cast<int64_t>(tile) * PC_ROWS + s_row) * PC_C + 4 * s_c4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) R[j] = *reinterpret_cast<const f32x4*>(p + 32 * j * PC_C);
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_g(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    // ---- the tile's 128 rows are 128 consecutive j of one (patch, i): class ids of the rows, then the planes of g
+    if (tid < PC_ROWS) {
+      const int64_t t0 = a.row0 + static_cast<int64_t>(tile) * PC_ROWS;
+      const int64_t bi = t0 / a.K, b = bi / a.K;
+      const int i = static_cast<int>(bi - b * a.K), j = static_cast<int>(t0 - bi * a.K) + tid;
+      const int64_t ri = bi, rj = b * a.K + j;
+      const int64_t si = (a.seq_m && !a.seq_m[ri]) ? a.unk : a.seq[ri], sj = (a.seq_m && !a.seq_m[rj]) ? a.unk : a.seq[rj];
+      int64_t rl = a.resid[b * a.resid_bstride + i] - a.resid[b * a.resid_bstride + j];
+      rl = rl < -a.max_dist ? -a.max_dist : (rl > a.max_dist ? a.max_dist : rl);
+      cls[tid] = static_cast<int>(si * a.n_aa + sj);
+      rel[tid] = static_cast<int>(rl) + a.max_dist;
+      same[tid] = static_cast<float>(a.chain[ri] * a.chain[rj]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __bf16 hh, mm, ll;
+        split3(R[j][c], hh, mm, ll);
+        h[c] = hh; m[c] = mm; l[c] = ll;
+      }
+      __bf16* dst = Gp + pc_off(s_row + 32 * j, s_c4 >> 1) + 4 * (s_c4 & 1);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + PC_PLANE) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * PC_PLANE) = l;
+    }
+    PC_FENCE();
+    __syncthreads();
+    if (tile + static_cast<int>(gridDim.x) < ntiles) load_g(tile + static_cast<int>(gridDim.x));
+    PC_FENCE();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      // one-hot A fragments: lane (class 16 mt + l15, rows 32 kk + 8 g + c): the element order of the transposing reads of the B side
+      const int rb = 32 * kk + 8 * g;
+      int ci[8], ri_[8];
+      float sm[8];
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        const auto cv = *reinterpret_cast<const int __attribute__((ext_vector_type(4)))*>(cls + rb + 4 * h4);
+        const auto rv = *reinterpret_cast<const int __attribute__((ext_vector_type(4)))*>(rel + rb + 4 * h4);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(same + rb + 4 * h4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ci[4 * h4 + c] = cv[c]; ri_[4 * h4 + c] = rv[c]; sm[4 * h4 + c] = sv[c]; }
+      }
+      bf16x8 fa[PT_M];
+#pragma unroll
+      for (int m = 0; m < PT_M; ++m) {
+        const int mt = wv + 8 * m;
+        const int mine = (mt < 28 ? 16 * mt : 16 * (mt - 28)) + l15;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float v = mt < 28 ? (ci[c] == mine ? 1.0f : 0.0f) : (ri_[c] == mine ? sm[c] : 0.0f);
+          fa[m][c] = static_cast<__bf16>(v);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bf16x8 fb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fb[p] = frag_tr(Gp + p * PC_PLANE, kk, nt);
+#pragma unroll
+        for (int m = 0; m < PT_M; ++m) {
+          if (wv + 8 * m >= PT_MT) continue;  // (wave-uniform)
+#pragma unroll
+          for (int p = 2; p >= 0; --p) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m], fb[p], acc[m][nt], 0, 0, 0);
+        }
+      }
+    }
+    PC_FENCE();
+    __syncthreads();  // every wave has read the planes and the class ids
+  }
+  // ---- the work-group's sums: D row 4 g + e = class, column l15 = channel
+  float* part = a.part + static_cast<size_t>(blockIdx.x) * (static_cast<size_t>(n_pair + n_rel) * PC_C);
+#pragma unroll
+  for (int m = 0; m < PT_M; ++m) {
+    const int mt = wv + 8 * m;
+    if (mt >= PT_MT) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c_ = (mt < 28 ? 16 * mt : 16 * (mt - 28)) + 4 * g + e;
+      const bool ok = mt < 28 ? c_ < n_pair : c_ < n_rel;
+      if (!ok) continue;
+      float* dst = part + static_cast<size_t>(mt < 28 ? c_ : n_pair + c_) * PC_C + l15;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dst[16 * nt] = acc[m][nt][e];
+    }
+  }
+}
+
 // out_seg[row][col] += sum over the slabs of part[slab][off_seg + row cols_seg + col]: thread = element (slabs read coalesced),
 // blockIdx.y = a group of 16 slabs whose loads are all in flight at once; one atomic per (element, group)
 constexpr int PR_GROUP = 16;
@@ -309,6 +452,32 @@ int launch_parts_reduce(const float* parts, int nparts, int64_t stride, const Pa
                      sg);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
+}
+
+// G1[n_aa^2][64] | G2[2 max_dist + 1][64] (adjacent) += the one-hot products of g (pair_table_mfma_kernel); part: 256 slabs of the same size
+bool pair_table_mfma_supported(int C, int K, int64_t nrows, int n_aa, int max_dist) {
+  return C == PC_C && K % PC_ROWS == 0 && nrows % PC_ROWS == 0 && nrows >= PC_ROWS && n_aa * n_aa <= 28 * 16 && 2 * max_dist + 1 <= 5 * 16;
+}
+int launch_pair_table_mfma(const float* g, const int64_t* seq, const uint8_t* seq_m, const int64_t* resid, int resid_bstride, const int64_t* chain,
+                           int K, int max_dist, int n_aa, int unk, int64_t row0, int64_t nrows, float* G1, float* part, hipStream_t st) {
+  DIFFAB_REQUIRE(g && seq && resid && chain && G1 && part && pair_table_mfma_supported(PC_C, K, nrows, n_aa, max_dist) &&
+                     (reinterpret_cast<uintptr_t>(g) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_table_mfma: unsupported operands");
+  PairTableArgs a{};
+  a.g = g; a.seq = seq; a.seq_m = seq_m; a.resid = resid; a.chain = chain; a.part = part;
+  a.row0 = row0; a.nrows = nrows; a.K = K; a.resid_bstride = resid_bstride; a.max_dist = max_dist; a.n_aa = n_aa; a.unk = unk;
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t ntiles = nrows / PC_ROWS;
+  int grid = static_cast<int>(ntiles < ncu ? ntiles : ncu);
+  grid = grid > 256 ? 256 : grid;
+  const int lds = 3 * PC_PLANE * 2 + 3 * PC_ROWS * 4;
+  hipLaunchKernelGGL(pair_table_mfma_kernel, dim3(grid), dim3(512), lds, st, a);
+  DIFFAB_LAUNCH_CHECK();
+  const int n_tab = (n_aa * n_aa + 2 * max_dist + 1) * PC_C;
+  PartsSegs sg{};
+  sg.nseg = 1; sg.off[0] = 0; sg.n[0] = n_tab; sg.cols[0] = n_tab; sg.ld[0] = n_tab; sg.out[0] = G1;
+  return launch_parts_reduce(part, grid, n_tab, sg, st);
 }
 
 size_t pair_chain_bwd_prep_floats() { return PC_WFRAG / 2 + 64; }
