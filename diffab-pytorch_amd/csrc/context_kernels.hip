@@ -590,6 +590,8 @@ __global__ __launch_bounds__(1024) void pair_dist_bwd_group_kernel(const int64_t
 static int launch_pair_dist_bwd(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din,
                                 const float* ddin, int K, int A, int64_t row0, int64_t nrows, int ld, float* g_coef_sp, hipStream_t st) {
   const size_t lds = sizeof(float) * kAA * A * A;
+  if (pair_chain_bwd_enabled() && pair_dist_bwd_mfma_supported(K, A, row0, nrows, ld, kAA))  // the class sums on the matrix cores
+    return launch_pair_dist_bwd_mfma(seq, seq_m, distmat, xyz, din, ddin, K, A, kAA, kUNK, row0, nrows, ld, g_coef_sp, st);
   if (lds <= 160 * 1024 && nrows % K == 0 && row0 % K == 0) {
     if (lds > 64 * 1024)
       DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dist_bwd_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -422,6 +422,123 @@ __global__ __launch_bounds__(512) void pair_table_mfma_kernel(PairTableArgs a) {
   }
 }
 
+// ================================================================== d softplus(pair2distcoef): the class sums on the matrix cores
+// g_sp[s_i 21 + s_j][p] += sum over the rows of a (patch, i) group of E[row][p], E = d din (-d^2 din) (pair_dist_bwd_group_kernel's sum:
+// din = exp(-c d^2) mask, d din / d c = -d^2 din).  The group's rows share s_i; as LDS atomics on a [21][A A] table the class sum cost
+// 512 ds_add_f32 wave instructions per group (578 us per chunk).  Here it is OneHot(s_j)^T E on the matrix cores, 64 atom-pair columns
+// at a time: E is formed while the block is staged as three bf16 planes (the chain kernel's layout), the one-hot A fragments are built
+// from the rows' s_j, each of the eight waves owns one 16-class x 16-column tile, and a block's sums go straight to the table rows of
+// s_i (21 x 64 global atomics per block, as before).  K = 128 rows per group.
+struct PairDistBwdArgs {
+  const int64_t* seq; const uint8_t* seq_m; const float* distmat; const float* xyz; const float* din; const float* ddin;
+  float* g_sp;
+  int64_t row0;
+  int K, A, ld, n_aa, unk;
+};
+__global__ __launch_bounds__(512) void pair_dist_bwd_mfma_kernel(PairDistBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 pd_lds[];
+  __bf16* Ep = pd_lds;                                       // E planes [3][128][64]
+  int* sjs = reinterpret_cast<int*>(pd_lds + 3 * PC_PLANE);  // [128] s_j of the rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int AA2 = a.A * a.A;
+  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;  // first row of the group inside this launch (K = 128)
+  const int64_t grow0 = a.row0 + lrow0;                               // global pair row (b, i, 0)
+  const int64_t ri = grow0 / a.K;                                     // b K + i
+  const int64_t b = ri / a.K;
+  const int64_t si = (a.seq_m && !a.seq_m[ri]) ? a.unk : a.seq[ri];
+  if (tid < PC_ROWS) {
+    const int64_t rj = b * a.K + tid;
+    sjs[tid] = static_cast<int>((a.seq_m && !a.seq_m[rj]) ? a.unk : a.seq[rj]);
+  }
+  const int s_row = tid >> 4, s_c4 = tid & 15;  // staging: rows (tid >> 4) + 32 j, columns 4 (tid & 15) .. + 3 of the block
+  const int q = l15 >> 2, pp = l15 & 3;
+  auto frag_tr = [&](const __bf16* plane, int kk, int cb) -> bf16x8 {
+    const int r0 = 32 * kk + 8 * g + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0 + 4, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  const int mt = wv & 1, nt = wv >> 1;  // this wave's tile: classes 16 mt + 4 g + e, columns 16 nt + l15 of the block
+  const int nblk = (AA2 + 63) / 64;
+  for (int cb = 0; cb < nblk; ++cb) {
+    // ---- E of the block: rows s_row + 32 j, atom pairs p = 64 cb + 4 s_c4 + e
+    const int pbase = 64 * cb + 4 * s_c4;
+    float xa[4][3];
+    int a2s[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = pbase + e < AA2 ? pbase + e : 0;
+      const int a1 = p / a.A;
+      a2s[e] = p - a1 * a.A;
+      xa[e][0] = xa[e][1] = xa[e][2] = 0.0f;
+      if (!a.distmat) {
+        const float* pa = a.xyz + (ri * a.A + a1) * 3;
+        xa[e][0] = pa[0]; xa[e][1] = pa[1]; xa[e][2] = pa[2];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = s_row + 32 * j;
+      const int64_t lr = lrow0 + r, rj = b * a.K + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f, 0.f};
+      if (pbase + 3 < a.ld) {  // (ld is a multiple of 4: a float4 is inside the row or outside)
+        v = *reinterpret_cast<const f32x4*>(a.din + lr * a.ld + pbase);
+        gd = *reinterpret_cast<const f32x4*>(a.ddin + lr * a.ld + pbase);
+      }
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float E = 0.0f;
+        if (pbase + e < AA2 && v[e] != 0.0f) {  // v == 0: masked atom pair (or underflow), no gradient
+          float d;
+          if (a.distmat) {
+            d = a.distmat[(grow0 + r) * AA2 + pbase + e];
+          } else {
+            const float* pb = a.xyz + (rj * a.A + a2s[e]) * 3;
+            const float dx = xa[e][0] - pb[0], dy = xa[e][1] - pb[1], dz = xa[e][2] - pb[2];
+            d = sqrtf((dx * dx + dy * dy) + dz * dz);
+          }
+          E = gd[e] * (-(d * d) * v[e]);
+        }
+        __bf16 hh, mm, ll;
+        split3(E, hh, mm, ll);
+        h[e] = hh; m[e] = mm; l[e] = ll;
+      }
+      __bf16* dst = Ep + pc_off(r, s_c4 >> 1) + 4 * (s_c4 & 1);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + PC_PLANE) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * PC_PLANE) = l;
+    }
+    PC_FENCE();
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int rb = 32 * kk + 8 * g;
+      bf16x8 fa;
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        const auto cv = *reinterpret_cast<const int __attribute__((ext_vector_type(4)))*>(sjs + rb + 4 * h4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[4 * h4 + c] = static_cast<__bf16>(cv[c] == 16 * mt + l15 ? 1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int p = 2; p >= 0; --p) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, frag_tr(Ep + p * PC_PLANE, kk, nt), acc, 0, 0, 0);
+    }
+    const int pcol = 64 * cb + 16 * nt + l15;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int sj = 16 * mt + 4 * g + e;
+      if (sj < a.n_aa && pcol < AA2 && acc[e] != 0.0f) atomicAdd(a.g_sp + ((si * a.n_aa + sj) * AA2 + pcol), acc[e]);
+    }
+    PC_FENCE();
+    __syncthreads();  // every wave has read the planes
+  }
+}
+
 // out_seg[row][col] += sum over the slabs of part[slab][off_seg + row cols_seg + col]: thread = element (slabs read coalesced),
 // blockIdx.y = a group of 16 slabs whose loads are all in flight at once; one atomic per (element, group)
 constexpr int PR_GROUP = 16;
@@ -478,6 +595,24 @@ int launch_pair_table_mfma(const float* g, const int64_t* seq, const uint8_t* se
   PartsSegs sg{};
   sg.nseg = 1; sg.off[0] = 0; sg.n[0] = n_tab; sg.cols[0] = n_tab; sg.ld[0] = n_tab; sg.out[0] = G1;
   return launch_parts_reduce(part, grid, n_tab, sg, st);
+}
+
+// pair_dist_bwd_group_kernel's sums for whole (patch, i) groups of K = 128 rows (pair_dist_bwd_mfma_kernel); ld = leading dimension of din / ddin
+bool pair_dist_bwd_mfma_supported(int K, int A, int64_t row0, int64_t nrows, int ld, int n_aa) {
+  return K == PC_ROWS && nrows % K == 0 && row0 % K == 0 && ld % 4 == 0 && ld >= A * A && n_aa <= 32;
+}
+int launch_pair_dist_bwd_mfma(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din, const float* ddin,
+                              int K, int A, int n_aa, int unk, int64_t row0, int64_t nrows, int ld, float* g_sp, hipStream_t st) {
+  DIFFAB_REQUIRE(seq && din && ddin && g_sp && (distmat || xyz) && pair_dist_bwd_mfma_supported(K, A, row0, nrows, ld, n_aa) &&
+                     (reinterpret_cast<uintptr_t>(din) & 15) == 0 && (reinterpret_cast<uintptr_t>(ddin) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_dist_bwd_mfma: unsupported operands");
+  PairDistBwdArgs a{};
+  a.seq = seq; a.seq_m = seq_m; a.distmat = distmat; a.xyz = xyz; a.din = din; a.ddin = ddin; a.g_sp = g_sp;
+  a.row0 = row0; a.K = K; a.A = A; a.ld = ld; a.n_aa = n_aa; a.unk = unk;
+  const int lds = 3 * PC_PLANE * 2 + PC_ROWS * 4;
+  hipLaunchKernelGGL(pair_dist_bwd_mfma_kernel, dim3(static_cast<unsigned>(nrows / K)), dim3(512), lds, st, a);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
 }
 
 size_t pair_chain_bwd_prep_floats() { return PC_WFRAG / 2 + 64; }
