@@ -839,7 +839,7 @@ static size_t fused_bwd_workspace_floats(const diffab_ctx_dims* d) {
   const size_t R = static_cast<size_t>(fused_bwd_chunk_patches(d)) * d->K * d->K;
   const size_t AA2p = round4(d->A * d->A), Wp = round4(3 * d->C + 18);
   return R * (9 * d->C + 2 * AA2p + 20) + 2 * static_cast<size_t>(d->C) * (AA2p + Wp) + static_cast<size_t>(kAA) * kAA * d->A * d->A +
-         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + pair_chain_bwd_prep_floats() + fused_bwd_parts_floats(d) + 1024;
+         static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * d->C + pair_embed_fused_prep_floats(d) + 2 * pair_chain_bwd_prep_floats() + fused_bwd_parts_floats(d) + 1024;
 }
 
 static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
@@ -872,6 +872,7 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
   float* G2 = G1 + static_cast<size_t>(kAA) * kAA * C;
   float* prep = cv.take<float>(pair_embed_fused_prep_floats(d));
   float* chain_prep = cv.take<float>(pair_chain_bwd_prep_floats());
+  float* dist_prep = cv.take<float>(pair_chain_bwd_prep_floats());
   float* parts = cv.take<float>(fused_bwd_parts_floats(d));  // per-work-group partial sums of the chain / scatter / narrow-product kernels
   auto mut = [](const float* p) { return const_cast<float*>(p); };
   hipLaunchKernelGGL(pad_rows_kernel, dim3((C * AA2p + 255) / 256), dim3(256), 0, st, w->dw0, AA2, C, dw0p, AA2p);
@@ -964,8 +965,16 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
                          distmat, xyz, atom_mask, coef_sp, d->K, d->A, row0, din, AA2p);
       DIFFAB_LAUNCH_CHECK();
     }
-    if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
-    if (int rc = launch_pair_dist_bwd(seq_idx, sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, nrows, AA2p, g_sp, st)) return rc;
+    if (pair_chain_bwd_enabled() && pair_dist_bwd_mfma_supported(d->K, d->A, row0, nrows, AA2p, kAA) && AA2 <= 256) {
+      // weight / bias gradient as before; d din is formed inside the coefficient-gradient kernel and never written (pair_chain_bwd.hip)
+      if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), nullptr, AA2p, rows, C, AA2p, false, st)) return rc;
+      if (int rc = launch_pair_dist_bwd_fused(seq_idx, sequence_context_mask, distmat, xyz, din, dh1, dw0p, AA2p, d->K, d->A, kAA, kUNK, row0, nrows,
+                                              AA2p, g_sp, dist_prep, st))
+        return rc;
+    } else {
+      if (int rc = bwd_linear(dh1, C, din, AA2p, dw0p, gdw0p, mut(g->db0), ddin, AA2p, rows, C, AA2p, false, st)) return rc;
+      if (int rc = launch_pair_dist_bwd(seq_idx, sequence_context_mask, distmat, xyz, din, ddin, d->K, d->A, row0, nrows, AA2p, g_sp, st)) return rc;
+    }
   }
   // ---- the table segments: d aa_pair_emb += G1 W_a, d W_a += G1^T aa_pair_emb (W_a = mlp[0].weight[:, 0:C]); the same for relpos_emb / G2
   const int n1 = kAA * kAA, n2 = 2 * d->max_dist + 1;

@@ -199,6 +199,9 @@ int bwd_linear_masked(const float* dY, int ldy, const float* X, int ldx, const f
 // pair_chain_bwd.hip: the four 64-wide layers at the end of the PairEmbedding backward as one launch per chunk of pair rows
 size_t pair_chain_bwd_prep_floats();
 size_t pair_chain_bwd_part_floats();
+int launch_pair_dist_bwd_fused(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din, const float* dh1,
+                               const float* W, int ld_w, int K, int A, int n_aa, int unk, int64_t row0, int64_t nrows, int ld, float* g_sp,
+                               float* prep, hipStream_t st);
 bool pair_dist_bwd_mfma_supported(int K, int A, int64_t row0, int64_t nrows, int ld, int n_aa);
 int launch_pair_dist_bwd_mfma(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din, const float* ddin,
                               int K, int A, int n_aa, int unk, int64_t row0, int64_t nrows, int ld, float* g_sp, hipStream_t st);

@@ -60,16 +60,19 @@ struct PairChainArgs {
 
 // W_L[n][i] (rows ldw floats apart) -> A fragments of W_L^T for v_mfma_f32_16x16x32_bf16: fragment (L, ks, plane, mi), lane (l15, g):
 // the eight values W_L[32 ks + 8 g + c][16 mi + l15], c = 0..7
+// (columns i >= nc_L of layer L: zeros - the distance kernel's last 64-column block of a 228-wide weight)
 __global__ void pair_chain_prep_kernel(const float* __restrict__ W0, int ld0, const float* __restrict__ W1, int ld1, const float* __restrict__ W2,
-                                       int ld2, const float* __restrict__ W3, int ld3, __bf16* __restrict__ out) {
+                                       int ld2, const float* __restrict__ W3, int ld3, int nc0, int nc1, int nc2, int nc3,
+                                       __bf16* __restrict__ out) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // (L, ks, mi, lane, c)
   if (gid >= 4 * 2 * 4 * 64 * 8) return;
   const int c = gid & 7, lane = (gid >> 3) & 63, mi = (gid >> 9) & 3, ks = (gid >> 11) & 1, L = gid >> 12;
   const float* W = L == 0 ? W0 : L == 1 ? W1 : L == 2 ? W2 : W3;
   const int ld = L == 0 ? ld0 : L == 1 ? ld1 : L == 2 ? ld2 : ld3;
+  const int nc = L == 0 ? nc0 : L == 1 ? nc1 : L == 2 ? nc2 : nc3;
   const int n = 32 * ks + 8 * (lane >> 4) + c, i = 16 * mi + (lane & 15);
   __bf16 h, m, l;
-  split3(W[n * ld + i], h, m, l);
+  split3(i < nc ? W[n * ld + i] : 0.0f, h, m, l);
   const size_t base = ((static_cast<size_t>(L * 2 + ks) * 3) * 4 + mi) * 512 + lane * 8 + c;
   out[base] = h;
   out[base + 4 * 512] = m;
@@ -539,6 +542,162 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_mfma_kernel(PairDistBwdArgs
   }
 }
 
+// The same sums with d din formed HERE: d din = d h1 . distance_embedding[0].W (64 -> A A columns) was a GEMM launch of its own that wrote
+// 448 MB per chunk for pair_dist_bwd_mfma_kernel to read back.  The group's d h1 tile is staged once as split planes; per 64-column
+// block the product runs with the weights as the MFMA's A operand (the chain kernel's d x product: fragments from a prep buffer, a lane
+// ends with four consecutive atom pairs of one row), E = d din (-d^2 din) is formed in the accumulators' layout and written into the E
+// planes as 8-byte pieces, and the one-hot product follows as above.
+struct PairDistFusedArgs {
+  const int64_t* seq; const uint8_t* seq_m; const float* distmat; const float* xyz; const float* din; const float* dh1;
+  const __bf16* wfrag;  // pair_chain_prep_kernel's fragments of W[:, 64 cb .. 64 cb + 63], cb = 0..3
+  float* g_sp;
+  int64_t row0;
+  int K, A, ld, n_aa, unk;
+};
+__global__ __launch_bounds__(512) void pair_dist_bwd_fused_kernel(PairDistFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 pd_lds[];
+  __bf16* Yp = pd_lds;                                       // d h1 planes [3][128][64]
+  __bf16* Ep = pd_lds + 3 * PC_PLANE;                        // E planes
+  int* sjs = reinterpret_cast<int*>(pd_lds + 6 * PC_PLANE);  // [128] s_j of the rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int AA2 = a.A * a.A;
+  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;
+  const int64_t grow0 = a.row0 + lrow0;
+  const int64_t ri = grow0 / a.K;
+  const int64_t b = ri / a.K;
+  const int64_t si = (a.seq_m && !a.seq_m[ri]) ? a.unk : a.seq[ri];
+  if (tid < PC_ROWS) {
+    const int64_t rj = b * a.K + tid;
+    sjs[tid] = static_cast<int>((a.seq_m && !a.seq_m[rj]) ? a.unk : a.seq[rj]);
+  }
+  {  // d h1 tile -> planes
+    const int s_row = tid >> 4, s_c4 = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = s_row + 32 * j;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.dh1 + (lrow0 + r) * PC_C + 4 * s_c4);
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __bf16 hh, mm, ll;
+        split3(v[c], hh, mm, ll);
+        h[c] = hh; m[c] = mm; l[c] = ll;
+      }
+      __bf16* dst = Yp + pc_off(r, s_c4 >> 1) + 4 * (s_c4 & 1);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + PC_PLANE) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * PC_PLANE) = l;
+    }
+  }
+  PC_FENCE();
+  __syncthreads();
+  const int q = l15 >> 2, pp = l15 & 3;
+  auto frag_tr = [&](const __bf16* plane, int kk, int cb) -> bf16x8 {
+    const int r0 = 32 * kk + 8 * g + q;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(plane + pc_off(r0 + 4, 2 * cb + (pp >> 1)) + 4 * (pp & 1)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+  const int mi = wv & 3, ch = wv >> 2;  // d din product: columns 16 mi + 4 g + e of the block, rows 64 ch + 16 ct + l15
+  const int mt = wv & 1, nt = wv >> 1;  // one-hot product: classes 16 mt + 4 g + e, columns 16 nt + l15 of the block
+  const int nblk = (AA2 + 63) / 64;
+  for (int cb = 0; cb < nblk; ++cb) {
+    bf16x8 wf[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        wf[ks][p] = *reinterpret_cast<const bf16x8*>(a.wfrag + ((static_cast<size_t>(cb * 2 + ks) * 3 + p) * 4 + mi) * 512 + lane * 8);
+    const int p0 = 64 * cb + 16 * mi + 4 * g;  // this lane's four atom pairs
+    f32x4 dn[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int r = 64 * ch + 16 * ct + l15;
+      dn[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p0 + 3 < a.ld) dn[ct] = *reinterpret_cast<const f32x4*>(a.din + (lrow0 + r) * a.ld + p0);
+    }
+    float xa[4][3];
+    int a2s[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = p0 + e < AA2 ? p0 + e : 0;
+      const int a1 = p / a.A;
+      a2s[e] = p - a1 * a.A;
+      xa[e][0] = xa[e][1] = xa[e][2] = 0.0f;
+      if (!a.distmat) {
+        const float* pa = a.xyz + (ri * a.A + a1) * 3;
+        xa[e][0] = pa[0]; xa[e][1] = pa[1]; xa[e][2] = pa[2];
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int r = 64 * ch + 16 * ct + l15;
+      const int64_t rj = b * a.K + r;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fy[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fy[p] = *reinterpret_cast<const bf16x8*>(Yp + p * PC_PLANE + pc_off(r, g + 4 * ks));
+#pragma unroll
+        for (int term = 0; term < 6; ++term) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][TA[term]], fy[TB[term]], acc, 0, 0, 0);
+      }
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float E = 0.0f;
+        const float v = dn[ct][e];
+        if (p0 + e < AA2 && v != 0.0f) {  // v == 0: masked atom pair (or underflow), no gradient
+          float d;
+          if (a.distmat) {
+            d = a.distmat[(grow0 + r) * AA2 + p0 + e];
+          } else {
+            const float* pb = a.xyz + (rj * a.A + a2s[e]) * 3;
+            const float dx = xa[e][0] - pb[0], dy = xa[e][1] - pb[1], dz = xa[e][2] - pb[2];
+            d = sqrtf((dx * dx + dy * dy) + dz * dz);
+          }
+          E = acc[e] * (-(d * d) * v);
+        }
+        __bf16 hh, mm, ll;
+        split3(E, hh, mm, ll);
+        h[e] = hh; m[e] = mm; l[e] = ll;
+      }
+      __bf16* dst = Ep + pc_off(r, 2 * mi + (g >> 1)) + 4 * (g & 1);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + PC_PLANE) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * PC_PLANE) = l;
+    }
+    PC_FENCE();
+    __syncthreads();
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int rb = 32 * kk + 8 * g;
+      bf16x8 fa;
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        const auto cv = *reinterpret_cast<const int __attribute__((ext_vector_type(4)))*>(sjs + rb + 4 * h4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[4 * h4 + c] = static_cast<__bf16>(cv[c] == 16 * mt + l15 ? 1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int p = 2; p >= 0; --p) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, frag_tr(Ep + p * PC_PLANE, kk, nt), acc1, 0, 0, 0);
+    }
+    const int pcol = 64 * cb + 16 * nt + l15;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int sj = 16 * mt + 4 * g + e;
+      if (sj < a.n_aa && pcol < AA2 && acc1[e] != 0.0f) atomicAdd(a.g_sp + ((si * a.n_aa + sj) * AA2 + pcol), acc1[e]);
+    }
+    PC_FENCE();
+    __syncthreads();  // every wave has read the E planes
+  }
+}
+
 // out_seg[row][col] += sum over the slabs of part[slab][off_seg + row cols_seg + col]: thread = element (slabs read coalesced),
 // blockIdx.y = a group of 16 slabs whose loads are all in flight at once; one atomic per (element, group)
 constexpr int PR_GROUP = 16;
@@ -615,6 +774,29 @@ int launch_pair_dist_bwd_mfma(const int64_t* seq, const uint8_t* seq_m, const fl
   return DIFFAB_OK;
 }
 
+// ... with d din = d h1 W formed in the kernel (W: distance_embedding[0].weight padded to ld_w columns, [64][ld_w]); prep as for the chain
+int launch_pair_dist_bwd_fused(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din, const float* dh1,
+                               const float* W, int ld_w, int K, int A, int n_aa, int unk, int64_t row0, int64_t nrows, int ld, float* g_sp,
+                               float* prep, hipStream_t st) {
+  DIFFAB_REQUIRE(seq && din && dh1 && W && g_sp && prep && (distmat || xyz) && pair_dist_bwd_mfma_supported(K, A, row0, nrows, ld, n_aa) &&
+                     A * A <= 256 && ld_w >= A * A && (reinterpret_cast<uintptr_t>(din) & 15) == 0 && (reinterpret_cast<uintptr_t>(dh1) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(prep) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_dist_bwd_fused: unsupported operands");
+  auto nc = [&](int cb) { const int n = ld_w - 64 * cb; return n < 0 ? 0 : (n > 64 ? 64 : n); };
+  auto wp = [&](int cb) { return nc(cb) > 0 ? W + 64 * cb : W; };
+  hipLaunchKernelGGL(pair_chain_prep_kernel, dim3((4 * 2 * 4 * 64 * 8 + 255) / 256), dim3(256), 0, st, wp(0), ld_w, wp(1), ld_w, wp(2), ld_w, wp(3),
+                     ld_w, nc(0), nc(1), nc(2), nc(3), reinterpret_cast<__bf16*>(prep));
+  DIFFAB_LAUNCH_CHECK();
+  PairDistFusedArgs a{};
+  a.seq = seq; a.seq_m = seq_m; a.distmat = distmat; a.xyz = xyz; a.din = din; a.dh1 = dh1; a.wfrag = reinterpret_cast<const __bf16*>(prep);
+  a.g_sp = g_sp; a.row0 = row0; a.K = K; a.A = A; a.ld = ld; a.n_aa = n_aa; a.unk = unk;
+  const int lds = 6 * PC_PLANE * 2 + PC_ROWS * 4;
+  DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dist_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(pair_dist_bwd_fused_kernel, dim3(static_cast<unsigned>(nrows / K)), dim3(512), lds, st, a);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 size_t pair_chain_bwd_prep_floats() { return PC_WFRAG / 2 + 64; }
 size_t pair_chain_bwd_part_floats() { return static_cast<size_t>(256) * PC_PART; }
 bool pair_chain_bwd_supported(int C, int K, int64_t nrows) { return C == PC_C && K % PC_ROWS == 0 && nrows % PC_ROWS == 0 && nrows >= PC_ROWS; }
@@ -645,7 +827,7 @@ int launch_pair_chain_bwd(const float* d_out, const float* amask, int K, int A, 
   a.A = A;
   a.ca = ca;
   hipLaunchKernelGGL(pair_chain_prep_kernel, dim3((4 * 2 * 4 * 64 * 8 + 255) / 256), dim3(256), 0, st, W[0], ldw[0], W[1], ldw[1], W[2], ldw[2],
-                     W[3], ldw[3], reinterpret_cast<__bf16*>(prep));
+                     W[3], ldw[3], 64, 64, 64, 64, reinterpret_cast<__bf16*>(prep));
   DIFFAB_LAUNCH_CHECK();
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
