@@ -559,6 +559,8 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_fused_kernel(PairDistFusedA
   __bf16* Yp = pd_lds;                                       // d h1 planes [3][128][64]
   __bf16* Ep = pd_lds + 3 * PC_PLANE;                        // E planes
   int* sjs = reinterpret_cast<int*>(pd_lds + 6 * PC_PLANE);  // [128] s_j of the rows
+  float* xj = reinterpret_cast<float*>(sjs + PC_ROWS);       // [128][A][3] the patch's atoms (xyz form): 48 scattered reads per lane and
+                                                             // column block come from LDS instead of the vector-memory pipe
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int AA2 = a.A * a.A;
   const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;
@@ -570,6 +572,8 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_fused_kernel(PairDistFusedA
     const int64_t rj = b * a.K + tid;
     sjs[tid] = static_cast<int>((a.seq_m && !a.seq_m[rj]) ? a.unk : a.seq[rj]);
   }
+  if (!a.distmat)
+    for (int idx = tid; idx < PC_ROWS * a.A * 3; idx += 512) xj[idx] = a.xyz[b * a.K * a.A * 3 + idx];
   {  // d h1 tile -> planes
     const int s_row = tid >> 4, s_c4 = tid & 15;
 #pragma unroll
@@ -636,7 +640,6 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_fused_kernel(PairDistFusedA
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       const int r = 64 * ch + 16 * ct + l15;
-      const int64_t rj = b * a.K + r;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_fused_kernel(PairDistFusedA
           if (a.distmat) {
             d = a.distmat[(grow0 + r) * AA2 + p0 + e];
           } else {
-            const float* pb = a.xyz + (rj * a.A + a2s[e]) * 3;
+            const float* pb = xj + (r * a.A + a2s[e]) * 3;
             const float dx = xa[e][0] - pb[0], dy = xa[e][1] - pb[1], dz = xa[e][2] - pb[2];
             d = sqrtf((dx * dx + dy * dy) + dz * dz);
           }
@@ -790,7 +793,7 @@ int launch_pair_dist_bwd_fused(const int64_t* seq, const uint8_t* seq_m, const f
   PairDistFusedArgs a{};
   a.seq = seq; a.seq_m = seq_m; a.distmat = distmat; a.xyz = xyz; a.din = din; a.dh1 = dh1; a.wfrag = reinterpret_cast<const __bf16*>(prep);
   a.g_sp = g_sp; a.row0 = row0; a.K = K; a.A = A; a.ld = ld; a.n_aa = n_aa; a.unk = unk;
-  const int lds = 6 * PC_PLANE * 2 + PC_ROWS * 4;
+  const int lds = 6 * PC_PLANE * 2 + PC_ROWS * 4 + PC_ROWS * A * 3 * 4;
   DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dist_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(pair_dist_bwd_fused_kernel, dim3(static_cast<unsigned>(nrows / K)), dim3(512), lds, st, a);
   DIFFAB_LAUNCH_CHECK();
