@@ -845,16 +845,18 @@ static size_t fused_bwd_workspace_floats(const diffab_ctx_dims* d) {
 static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
                                     const int64_t* seq_idx, const float* distmat, const float* xyz, const float* pairwise_dihedrals,
                                     const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
-                                    const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, float* ws, hipStream_t st) {
+                                    const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, float* ws, hipStream_t st,
+                                    const float* tape = nullptr) {
+  // tape (diffab_pair_embedding_fwd_taped): h1 | df | m1 | m2 of ALL rows, [B K K][C] each - no recompute per chunk
   const int C = d->C, AA2 = d->A * d->A, W = 3 * C + 18, AA2p = round4(AA2), Wp = round4(W);
   const int bc = fused_bwd_chunk_patches(d);
   const int64_t per_patch = static_cast<int64_t>(d->K) * d->K;
   const size_t R = static_cast<size_t>(bc) * per_patch;
   Carver cv(ws);
-  float* h1 = cv.take<float>(R * C);
-  float* df = cv.take<float>(R * C);
-  float* m1 = cv.take<float>(R * C);
-  float* m2 = cv.take<float>(R * C);
+  float* h1w = cv.take<float>(R * C);
+  float* dfw = cv.take<float>(R * C);
+  float* m1w = cv.take<float>(R * C);
+  float* m2w = cv.take<float>(R * C);
   float* dA = cv.take<float>(R * C);
   float* dB = cv.take<float>(R * C);
   float* dC = cv.take<float>(R * C);
@@ -884,14 +886,25 @@ static int pair_embedding_bwd_fused(const diffab_ctx_dims* d, const diffab_pair_
   const size_t tab_bytes = static_cast<size_t>(kAA * kAA + 2 * d->max_dist + 1) * C * sizeof(float) + 3 * 256 * sizeof(float);
   DIFFAB_REQUIRE(tab_bytes <= 150 * 1024, DIFFAB_ERR_UNSUPPORTED, "pair_embedding_bwd: embedding tables too large for the LDS scatter");
   const float* coef_sp = nullptr;
+  const size_t total_rows = static_cast<size_t>(d->B) * per_patch;
+  if (tape != nullptr) {  // only the softplus table of the recompute's preparation is needed (the 225-wide features below)
+    float* csp = prep;
+    if (int rc = launch_softplus_table(w->pair2distcoef, kAA * kAA * AA2, csp, st)) return rc;
+    coef_sp = csp;
+  }
   for (int b0 = 0; b0 < d->B; b0 += bc) {
     const int nb = (d->B - b0) < bc ? (d->B - b0) : bc;
     const int64_t row0 = b0 * per_patch, nrows = nb * per_patch;
     const int rows = static_cast<int>(nrows);
-    // ---- forward recompute: one launch, the hidden activations (after their ReLUs) on the tape
-    if (int rc = launch_pair_embed_fused(d, w, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx,
-                                         atom_mask, sequence_context_mask, nullptr, prep, h1, df, m1, m2, row0, nrows, st, &coef_sp))
+    const float* h1 = h1w; const float* df = dfw; const float* m1 = m1w; const float* m2 = m2w;
+    if (tape != nullptr) {
+      h1 = tape + row0 * C; df = tape + total_rows * C + row0 * C; m1 = tape + 2 * total_rows * C + row0 * C; m2 = tape + 3 * total_rows * C + row0 * C;
+    } else if (int rc = launch_pair_embed_fused(d, w, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride,
+                                                chain_idx, atom_mask, sequence_context_mask, nullptr, prep, h1w, dfw, m1w, m2w, row0, nrows, st,
+                                                &coef_sp)) {
+      // ---- forward recompute: one launch, the hidden activations (after their ReLUs) on the tape
       return rc;
+    }
     if (pair_chain_bwd_enabled() && pair_chain_bwd_supported(C, d->K, nrows)) {
       // ---- the atom-mask product, the four 64 x 64 layers' d x chain and their weight / bias gradients: ONE launch, a 128-row tile stays
       //      on the CU from d out to d h1 (pair_chain_bwd.hip); d C and d h1 leave for the steps below
@@ -1128,6 +1141,57 @@ int diffab_pair_embedding_xyz_fwd(const diffab_ctx_dims* d, const diffab_pair_em
   DIFFAB_REQUIRE(xyz != nullptr, DIFFAB_ERR_ARG, "pair_embedding_xyz_fwd: xyz is null");
   return pair_embedding_impl(d, w, seq_idx, nullptr, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
                              sequence_context_mask, out, workspace, workspace_bytes, stream);
+}
+
+// ---- taped form (round 6): the forward leaves the four hidden activations of every pair row, the backward reads them instead of
+// recomputing the forward chunk by chunk.  4 B K K C floats (8.6 GB at B = 128, K = 128, C = 64): what 288 GB of HBM are for.
+size_t diffab_pair_embedding_tape_bytes(const diffab_ctx_dims* d) {
+  if (check_ctx(d, "pair_embedding_tape_bytes") || !pair_embed_fused_supported(d)) return 0;
+  return static_cast<size_t>(4) * d->B * d->K * d->K * d->C * sizeof(float);
+}
+int diffab_pair_embedding_fwd_taped(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
+                                    const float* xyz, const float* pairwise_dihedrals, const int64_t* residue_idx,
+                                    int32_t residue_idx_batch_stride, const int64_t* chain_idx, const float* atom_mask,
+                                    const uint8_t* sequence_context_mask, float* out, float* tape, size_t tape_bytes, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
+  if (int rc = check_ctx(d, "pair_embedding_fwd_taped")) return rc;
+  DIFFAB_REQUIRE(pair_embed_fused_supported(d), DIFFAB_ERR_UNSUPPORTED,
+                 "pair_embedding_fwd_taped: no taped form for these dims (diffab_pair_embedding_tape_bytes returns 0): use the plain entry points");
+  DIFFAB_REQUIRE(w && w->aa_pair_emb && w->relpos_emb && w->pair2distcoef && w->dw0 && w->db0 && w->dw2 && w->db2 && w->mw0 && w->mb0 &&
+                     w->mw2 && w->mb2 && w->mw4 && w->mb4,
+                 DIFFAB_ERR_ARG, "pair_embedding_fwd_taped: null weight");
+  DIFFAB_REQUIRE(seq_idx && ((distmat != nullptr) != (xyz != nullptr)) && pairwise_dihedrals && residue_idx && chain_idx && atom_mask && out &&
+                     tape && workspace && (reinterpret_cast<uintptr_t>(tape) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_embedding_fwd_taped: null pointer (exactly one of distmat / xyz), or a tape that is not 16-byte aligned");
+  DIFFAB_REQUIRE(tape_bytes >= diffab_pair_embedding_tape_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_fwd_taped: tape");
+  DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_fwd_taped: workspace");
+  const int64_t rows = static_cast<int64_t>(d->B) * d->K * d->K;
+  return launch_pair_embed_fused(d, w, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
+                                 sequence_context_mask, out, static_cast<float*>(workspace), tape, tape + rows * d->C, tape + 2 * rows * d->C,
+                                 tape + 3 * rows * d->C, 0, rows, as_stream(stream), nullptr);
+}
+int diffab_pair_embedding_bwd_taped(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
+                                    const int64_t* seq_idx, const float* distmat, const float* xyz, const float* pairwise_dihedrals,
+                                    const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                                    const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, const float* tape,
+                                    size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  StreamOrder order_(stream);
+  if (int rc = check_ctx(d, "pair_embedding_bwd_taped")) return rc;
+  DIFFAB_REQUIRE(pair_embed_fused_supported(d), DIFFAB_ERR_UNSUPPORTED, "pair_embedding_bwd_taped: no taped form for these dims");
+  DIFFAB_REQUIRE(w && w->aa_pair_emb && w->relpos_emb && w->pair2distcoef && w->dw0 && w->db0 && w->dw2 && w->db2 && w->mw0 && w->mb0 &&
+                     w->mw2 && w->mb2 && w->mw4 && w->mb4,
+                 DIFFAB_ERR_ARG, "pair_embedding_bwd_taped: null weight");
+  DIFFAB_REQUIRE(g && g->aa_pair_emb && g->relpos_emb && g->pair2distcoef && g->dw0 && g->db0 && g->dw2 && g->db2 && g->mw0 && g->mb0 &&
+                     g->mw2 && g->mb2 && g->mw4 && g->mb4,
+                 DIFFAB_ERR_ARG, "pair_embedding_bwd_taped: null gradient buffer");
+  DIFFAB_REQUIRE(seq_idx && (distmat || xyz) && pairwise_dihedrals && residue_idx && chain_idx && atom_mask && d_out && tape && workspace &&
+                     (reinterpret_cast<uintptr_t>(tape) & 15) == 0,
+                 DIFFAB_ERR_ARG, "pair_embedding_bwd_taped: null pointer");
+  DIFFAB_REQUIRE(tape_bytes >= diffab_pair_embedding_tape_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_bwd_taped: tape");
+  DIFFAB_REQUIRE(workspace_bytes >= diffab_pair_embedding_bwd_workspace_bytes(d), DIFFAB_ERR_WORKSPACE, "pair_embedding_bwd_taped: workspace");
+  return pair_embedding_bwd_fused(d, w, g, seq_idx, distmat, xyz, pairwise_dihedrals, residue_idx, residue_idx_batch_stride, chain_idx, atom_mask,
+                                  sequence_context_mask, d_out, static_cast<float*>(workspace), as_stream(stream), tape);
 }
 
 }  // extern "C"

@@ -138,6 +138,13 @@ SYMBOLS = {
     "diffab_pair_embedding_bwd_workspace_bytes": (_sz, [C.POINTER(CtxDims)]),
     "diffab_pair_embedding_bwd": (C.c_int, [C.POINTER(CtxDims), C.POINTER(PairEmbWeights), C.POINTER(PairEmbWeights), _fp, _fp, _fp, _fp, _fp,
                                             _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "diffab_pair_embedding_tape_bytes": (_sz, [C.POINTER(CtxDims)]),
+    # (d, w, seq, distmat, xyz, pdih, resid, stride, chain, amask, mask, out, tape, tape_bytes, ws, ws_bytes, stream)
+    "diffab_pair_embedding_fwd_taped": (C.c_int, [C.POINTER(CtxDims), C.POINTER(PairEmbWeights), _fp, _fp, _fp, _fp, _fp, _i32, _fp, _fp, _fp,
+                                                  _fp, _fp, _sz, _fp, _sz, _fp]),
+    # (d, w, g, seq, distmat, xyz, pdih, resid, stride, chain, amask, mask, d_out, tape, tape_bytes, ws, ws_bytes, stream)
+    "diffab_pair_embedding_bwd_taped": (C.c_int, [C.POINTER(CtxDims), C.POINTER(PairEmbWeights), C.POINTER(PairEmbWeights), _fp, _fp, _fp, _fp,
+                                                  _fp, _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp, _sz, _fp]),
     "diffab_featurize_xyz": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
     "diffab_orientation_loss": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp]),
     "diffab_orientation_loss_bwd": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _fp, _fp, _fp]),

@@ -15,6 +15,7 @@ DiffAb.training_step on a reference batch dict trains all 2 538 468 parameters.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -568,10 +569,22 @@ class _PairEmbeddingFn(torch.autograd.Function):
         w = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in ts])
         ws = _hip.workspace(lib.diffab_pair_embedding_workspace_bytes(C.byref(dims)))
         out = torch.empty(dims.B, dims.K, dims.K, dims.C, dtype=torch.float32, device=seq.device)
-        entry = lib.diffab_pair_embedding_xyz_fwd if from_xyz else lib.diffab_pair_embedding_fwd
-        _hip.check(entry(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri), ri_stride, _hip.ptr(ch),
-                         _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
-                   "diffab_pair_embedding_xyz_fwd" if from_xyz else "diffab_pair_embedding_fwd")
+        # Taped form (C ABI "Taped form of the PairEmbedding pair"): when a backward will follow and the device has the room, the forward
+        # leaves its four hidden activations (8.6 GB at B = 128, K = 128) and the backward does not recompute it.  DIFFAB_PAIR_TAPE=0: off.
+        ctx.tape = None
+        tape_bytes = lib.diffab_pair_embedding_tape_bytes(C.byref(dims))
+        if (tape_bytes and any(p.requires_grad for p in params) and os.environ.get("DIFFAB_PAIR_TAPE", "1") != "0"
+                and torch.cuda.mem_get_info(seq.device)[0] > 2 * tape_bytes):
+            ctx.tape = torch.empty(tape_bytes // 4, dtype=torch.float32, device=seq.device)
+            _hip.check(lib.diffab_pair_embedding_fwd_taped(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(None if from_xyz else dm),
+                                                           _hip.ptr(dm if from_xyz else None), _hip.ptr(dh), _hip.ptr(ri), ri_stride, _hip.ptr(ch),
+                                                           _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ctx.tape), tape_bytes, _hip.ptr(ws),
+                                                           ws.numel(), _hip.stream_ptr()), "diffab_pair_embedding_fwd_taped")
+        else:
+            entry = lib.diffab_pair_embedding_xyz_fwd if from_xyz else lib.diffab_pair_embedding_fwd
+            _hip.check(entry(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(dm), _hip.ptr(dh), _hip.ptr(ri), ri_stride, _hip.ptr(ch),
+                             _hip.ptr(am), _hip.ptr(qm), _hip.ptr(out), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
+                       "diffab_pair_embedding_xyz_fwd" if from_xyz else "diffab_pair_embedding_fwd")
         ctx.dims, ctx.from_xyz, ctx.ri_stride, ctx.qm = dims, from_xyz, ri_stride, qm
         ctx.p_devs = [p.device for p in params]
         ctx.save_for_backward(seq, dm, dh, ri, ch, am, *ts)
@@ -588,10 +601,19 @@ class _PairEmbeddingFn(torch.autograd.Function):
         g = _hip.PairEmbWeights(*[_hip.ptr(t_) for t_ in grads])
         ws = _hip.workspace(lib.diffab_pair_embedding_bwd_workspace_bytes(C.byref(dims)))
         do = _hip.dev_f32(d_out)
-        _hip.check(lib.diffab_pair_embedding_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(seq), _hip.ptr(None if ctx.from_xyz else dm),
-                                                 _hip.ptr(dm if ctx.from_xyz else None), _hip.ptr(dh), _hip.ptr(ri), ctx.ri_stride, _hip.ptr(ch),
-                                                 _hip.ptr(am), _hip.ptr(ctx.qm), _hip.ptr(do), _hip.ptr(ws), ws.numel(), _hip.stream_ptr()),
-                   "diffab_pair_embedding_bwd")
+        if ctx.tape is not None:
+            tape, ctx.tape = ctx.tape, None
+            _hip.check(lib.diffab_pair_embedding_bwd_taped(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(seq),
+                                                           _hip.ptr(None if ctx.from_xyz else dm), _hip.ptr(dm if ctx.from_xyz else None),
+                                                           _hip.ptr(dh), _hip.ptr(ri), ctx.ri_stride, _hip.ptr(ch), _hip.ptr(am), _hip.ptr(ctx.qm),
+                                                           _hip.ptr(do), _hip.ptr(tape), tape.numel() * 4, _hip.ptr(ws), ws.numel(),
+                                                           _hip.stream_ptr()), "diffab_pair_embedding_bwd_taped")
+            del tape
+        else:
+            _hip.check(lib.diffab_pair_embedding_bwd(C.byref(dims), C.byref(w), C.byref(g), _hip.ptr(seq),
+                                                     _hip.ptr(None if ctx.from_xyz else dm), _hip.ptr(dm if ctx.from_xyz else None), _hip.ptr(dh),
+                                                     _hip.ptr(ri), ctx.ri_stride, _hip.ptr(ch), _hip.ptr(am), _hip.ptr(ctx.qm), _hip.ptr(do),
+                                                     _hip.ptr(ws), ws.numel(), _hip.stream_ptr()), "diffab_pair_embedding_bwd")
         return (None,) * 11 + tuple(gr.to(dv) for gr, dv in zip(grads, ctx.p_devs))
 
 

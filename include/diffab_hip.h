@@ -450,6 +450,23 @@ int diffab_pair_embedding_bwd(const diffab_ctx_dims* d, const diffab_pair_emb_we
                               const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
                               const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out /* (B,K,K,C) */,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* Taped form of the PairEmbedding pair (round 6; where diffab_pair_embedding_tape_bytes(d) > 0: C = 64, K a multiple of 128, A <= 16):
+ * the forward also leaves the four hidden activations of every pair row on `tape` (4 x B K K C floats: 8.6 GB at B = 128, K = 128 - the
+ * 288 GB of an MI355X hold it), and the backward reads them instead of recomputing the forward chunk by chunk (-2 ms of 12 at B = 128).
+ * Same arguments and results as diffab_pair_embedding_fwd / _xyz_fwd (exactly one of distmat / xyz non-null) and diffab_pair_embedding_bwd;
+ * the tape must be 16-byte aligned and stay untouched between the two calls.  Reference: autograd's saved tensors of
+ * PairEmbedding.forward, diffab_pytorch.py:186-312. */
+size_t diffab_pair_embedding_tape_bytes(const diffab_ctx_dims* d);
+int diffab_pair_embedding_fwd_taped(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const int64_t* seq_idx, const float* distmat,
+                                    const float* xyz, const float* pairwise_dihedrals, const int64_t* residue_idx,
+                                    int32_t residue_idx_batch_stride, const int64_t* chain_idx, const float* atom_mask,
+                                    const uint8_t* sequence_context_mask, float* out, float* tape, size_t tape_bytes, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+int diffab_pair_embedding_bwd_taped(const diffab_ctx_dims* d, const diffab_pair_emb_weights* w, const diffab_pair_emb_weights* g,
+                                    const int64_t* seq_idx, const float* distmat, const float* xyz, const float* pairwise_dihedrals,
+                                    const int64_t* residue_idx, int32_t residue_idx_batch_stride, const int64_t* chain_idx,
+                                    const float* atom_mask, const uint8_t* sequence_context_mask, const float* d_out, const float* tape,
+                                    size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- reverse process (build-defined; reference stub diffab_pytorch.py:770-776) -- */
 /* One update t -> t-1 from denoiser outputs with explicit noise (z (B,K,3), rotvec (B,K,3), u_seq (B,K)),

@@ -3,6 +3,8 @@ through ctypes into libdiffab_hip.so) against the oracle on the same seeded inpu
 vectors generated from the real reference.  Tolerances are max|a-b|/max|b| in fp32; BASELINE.json's bar is
 1e-4 for aa-type logits and translations - the tests hold every tensor to that or tighter."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -1064,6 +1066,17 @@ def test_fused_pair_embedding_k128_vs_unfused_and_oracle(hip):
         worst = max(((n, maxrel(gf[n], gs[n])) for n in names), key=lambda t_: t_[1])
         print("  one-launch chain vs separate launches: worst gradient %s %.1e" % worst)
         assert worst[1] < 2e-5, worst
+        # the taped form (the default when a backward follows: diffab_pair_embedding_fwd_taped / _bwd_taped) against the recomputing one:
+        # the same activations, read from the tape instead of recomputed per chunk - equal up to the order of the gradient atomics
+        os.environ["DIFFAB_PAIR_TAPE"] = "0"
+        try:
+            pr, gr = run(distmat, 0)
+        finally:
+            del os.environ["DIFFAB_PAIR_TAPE"]
+        assert torch.equal(pf, pr)
+        worst = max(((n, maxrel(gf[n], gr[n])) for n in names), key=lambda t_: t_[1])
+        print("  taped vs recomputing backward: worst gradient %s %.1e" % worst)
+        assert worst[1] < 2e-6, worst
     # the oracle (and its autograd) on patch 0, distances from the materialised tensor
     csd = {k: v.clone().requires_grad_(k.startswith("pair_context_embedding.")) for k, v in sd.items()}
     b1 = {k: (v[:1] if v.shape[0] == B else v) for k, v in cbc.items()}
