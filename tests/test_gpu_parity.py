@@ -1095,6 +1095,46 @@ def test_fused_pair_embedding_k128_vs_unfused_and_oracle(hip):
         assert r < 2e-4, (n, r)
 
 
+def test_pair_embedding_backward_k256_matrix_core_kernels_vs_separate_launches(hip):
+    """K = 256 (two 128-row tiles per (patch, i) group: the second tile starts at j = 128): the round-6 backward kernels
+    (csrc/pair_chain_bwd.hip: chain, one-hot table sums; the coefficient gradient takes its K = 128 form only, so here the per-group LDS
+    kernel runs behind the chain) against the separate launches (variant 64) that the K = 128 test pins to the oracle's autograd, taped
+    and recomputing."""
+    from diffab_pytorch import DiffAb
+
+    d = syn.BENCH_DIMS
+    B, K, A_ = 1, 256, 15
+    model = DiffAb(d["D"], d["C"], 1, d["DS"], d["PQ"], d["PV"], d["H"]).cuda()
+    sd = syn.context_state_dict(d["D"], d["C"], A_, 32, seed=21)
+    sd["pair_context_embedding.pair2distcoef.weight"] = 0.3 * torch.randn(441, A_ * A_, generator=torch.Generator().manual_seed(6))
+    model.load_state_dict(sd, strict=False)
+    cb = {k: v.cuda() for k, v in syn.context_batch(B, K, A_, seed=22).items()}
+    Gp = torch.randn(B, K, K, d["C"], device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    names = [n for n, _ in model.named_parameters() if n.startswith("pair_context_embedding.")]
+
+    def run(variant, tape):
+        hip.diffab_debug_set_attn_variant(variant)
+        os.environ["DIFFAB_PAIR_TAPE"] = tape
+        try:
+            model.zero_grad()
+            _, pair = model.encode_context(cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], None, cb["pairwise_dihedrals"],
+                                           cb["atom_mask"], cb["chain_idx"], cb["residue_idx"], cb["generation_mask"], cb["residue_mask"])
+            (pair * Gp).sum().backward()
+            return pair.detach().clone(), {n: dict(model.named_parameters())[n].grad.detach().clone() for n in names}
+        finally:
+            hip.diffab_debug_set_attn_variant(0)
+            del os.environ["DIFFAB_PAIR_TAPE"]
+
+    p0, g0 = run(0, "1")
+    for variant, tape in ((64, "0"), (0, "0")):
+        p1, g1 = run(variant, tape)
+        assert torch.equal(p0, p1)
+        worst = max(((n, maxrel(g0[n], g1[n])) for n in names), key=lambda t_: t_[1])
+        print(f"K = 256, variant {variant}, tape {tape}: worst gradient {worst[0]} {worst[1]:.1e}")
+        assert worst[1] < 2e-5, worst
+    assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in g0.values())
+
+
 def test_full_training_step_updates_every_parameter(hip):
     """DiffAb.training_step on the reference's batch dict (no precomputed contexts): encode_context is part of the graph, so one
     Adam step moves all parameters - the 559 641 of the two context encoders included."""
