@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void pair_table_mfma_kernel(PairTableArgs a) {
 // 512 ds_add_f32 wave instructions per group (578 us per chunk).  Here it is OneHot(s_j)^T E on the matrix cores, 64 atom-pair columns
 // at a time: E is formed while the block is staged as three bf16 planes (the chain kernel's layout), the one-hot A fragments are built
 // from the rows' s_j, each of the eight waves owns one 16-class x 16-column tile, and a block's sums go straight to the table rows of
-// s_i (21 x 64 global atomics per block, as before).  K = 128 rows per group.
+// s_i (21 x 64 global atomics per block, as before).  One work-group per 128 consecutive j of a (patch, i): K a multiple of 128.
 struct PairDistBwdArgs {
   const int64_t* seq; const uint8_t* seq_m; const float* distmat; const float* xyz; const float* din; const float* ddin;
   float* g_sp;
@@ -444,13 +444,14 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_mfma_kernel(PairDistBwdArgs
   int* sjs = reinterpret_cast<int*>(pd_lds + 3 * PC_PLANE);  // [128] s_j of the rows
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int AA2 = a.A * a.A;
-  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;  // first row of the group inside this launch (K = 128)
-  const int64_t grow0 = a.row0 + lrow0;                               // global pair row (b, i, 0)
+  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;  // first row of the tile inside this launch: 128 consecutive j of one (b, i)
+  const int64_t grow0 = a.row0 + lrow0;                               // global pair row (b, i, j0)
   const int64_t ri = grow0 / a.K;                                     // b K + i
+  const int j0 = static_cast<int>(grow0 - ri * a.K);                  // (K a multiple of 128)
   const int64_t b = ri / a.K;
   const int64_t si = (a.seq_m && !a.seq_m[ri]) ? a.unk : a.seq[ri];
   if (tid < PC_ROWS) {
-    const int64_t rj = b * a.K + tid;
+    const int64_t rj = b * a.K + j0 + tid;
     sjs[tid] = static_cast<int>((a.seq_m && !a.seq_m[rj]) ? a.unk : a.seq[rj]);
   }
   const int s_row = tid >> 4, s_c4 = tid & 15;  // staging: rows (tid >> 4) + 32 j, columns 4 (tid & 15) .. + 3 of the block
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_mfma_kernel(PairDistBwdArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = s_row + 32 * j;
-      const int64_t lr = lrow0 + r, rj = b * a.K + r;
+      const int64_t lr = lrow0 + r, rj = b * a.K + j0 + r;
       f32x4 v = {0.f, 0.f, 0.f, 0.f}, gd = {0.f, 0.f, 0.f, 0.f};
       if (pbase + 3 < a.ld) {  // (ld is a multiple of 4: a float4 is inside the row or outside)
         v = *reinterpret_cast<const f32x4*>(a.din + lr * a.ld + pbase);
@@ -563,17 +564,18 @@ __global__ __launch_bounds__(512) void pair_dist_bwd_fused_kernel(PairDistFusedA
                                                              // column block come from LDS instead of the vector-memory pipe
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int AA2 = a.A * a.A;
-  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;
+  const int64_t lrow0 = static_cast<int64_t>(blockIdx.x) * PC_ROWS;  // the tile: 128 consecutive j of one (b, i) (K a multiple of 128)
   const int64_t grow0 = a.row0 + lrow0;
   const int64_t ri = grow0 / a.K;
+  const int j0 = static_cast<int>(grow0 - ri * a.K);
   const int64_t b = ri / a.K;
   const int64_t si = (a.seq_m && !a.seq_m[ri]) ? a.unk : a.seq[ri];
   if (tid < PC_ROWS) {
-    const int64_t rj = b * a.K + tid;
+    const int64_t rj = b * a.K + j0 + tid;
     sjs[tid] = static_cast<int>((a.seq_m && !a.seq_m[rj]) ? a.unk : a.seq[rj]);
   }
   if (!a.distmat)
-    for (int idx = tid; idx < PC_ROWS * a.A * 3; idx += 512) xj[idx] = a.xyz[b * a.K * a.A * 3 + idx];
+    for (int idx = tid; idx < PC_ROWS * a.A * 3; idx += 512) xj[idx] = a.xyz[(b * a.K + j0) * a.A * 3 + idx];
   {  // d h1 tile -> planes
     const int s_row = tid >> 4, s_c4 = tid & 15;
 #pragma unroll
@@ -761,7 +763,7 @@ int launch_pair_table_mfma(const float* g, const int64_t* seq, const uint8_t* se
 
 // pair_dist_bwd_group_kernel's sums for whole (patch, i) groups of K = 128 rows (pair_dist_bwd_mfma_kernel); ld = leading dimension of din / ddin
 bool pair_dist_bwd_mfma_supported(int K, int A, int64_t row0, int64_t nrows, int ld, int n_aa) {
-  return K == PC_ROWS && nrows % K == 0 && row0 % K == 0 && ld % 4 == 0 && ld >= A * A && n_aa <= 32;
+  return K % PC_ROWS == 0 && nrows % K == 0 && row0 % K == 0 && ld % 4 == 0 && ld >= A * A && n_aa <= 32;
 }
 int launch_pair_dist_bwd_mfma(const int64_t* seq, const uint8_t* seq_m, const float* distmat, const float* xyz, const float* din, const float* ddin,
                               int K, int A, int n_aa, int unk, int64_t row0, int64_t nrows, int ld, float* g_sp, hipStream_t st) {
@@ -772,7 +774,7 @@ int launch_pair_dist_bwd_mfma(const int64_t* seq, const uint8_t* seq_m, const fl
   a.seq = seq; a.seq_m = seq_m; a.distmat = distmat; a.xyz = xyz; a.din = din; a.ddin = ddin; a.g_sp = g_sp;
   a.row0 = row0; a.K = K; a.A = A; a.ld = ld; a.n_aa = n_aa; a.unk = unk;
   const int lds = 3 * PC_PLANE * 2 + PC_ROWS * 4;
-  hipLaunchKernelGGL(pair_dist_bwd_mfma_kernel, dim3(static_cast<unsigned>(nrows / K)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(pair_dist_bwd_mfma_kernel, dim3(static_cast<unsigned>(nrows / PC_ROWS)), dim3(512), lds, st, a);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
@@ -795,7 +797,7 @@ int launch_pair_dist_bwd_fused(const int64_t* seq, const uint8_t* seq_m, const f
   a.g_sp = g_sp; a.row0 = row0; a.K = K; a.A = A; a.ld = ld; a.n_aa = n_aa; a.unk = unk;
   const int lds = 6 * PC_PLANE * 2 + PC_ROWS * 4 + PC_ROWS * A * 3 * 4;
   DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dist_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(pair_dist_bwd_fused_kernel, dim3(static_cast<unsigned>(nrows / K)), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(pair_dist_bwd_fused_kernel, dim3(static_cast<unsigned>(nrows / PC_ROWS)), dim3(512), lds, st, a);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }

@@ -1097,8 +1097,8 @@ def test_fused_pair_embedding_k128_vs_unfused_and_oracle(hip):
 
 def test_pair_embedding_backward_k256_matrix_core_kernels_vs_separate_launches(hip):
     """K = 256 (two 128-row tiles per (patch, i) group: the second tile starts at j = 128): the round-6 backward kernels
-    (csrc/pair_chain_bwd.hip: chain, one-hot table sums; the coefficient gradient takes its K = 128 form only, so here the per-group LDS
-    kernel runs behind the chain) against the separate launches (variant 64) that the K = 128 test pins to the oracle's autograd, taped
+    (csrc/pair_chain_bwd.hip: chain, one-hot table sums, coefficient gradient with d din formed in the kernel - all walk 128-row tiles of
+    consecutive j) against the separate launches (variant 64) that the K = 128 test pins to the oracle's autograd, taped
     and recomputing."""
     from diffab_pytorch import DiffAb
 
