@@ -193,7 +193,9 @@ int diffab_debug_set_attn_variant(int32_t v); /* A/B switches (tests, tools; pro
                                                  projections and to_out as six-term bf16 split products (rounds 3-4) instead of the
                                                  three-term fp16 ones (and with them the backward's d feat and weight-gradient products) -
                                                  per-layer launches only, bit 5 (32) = only the weight-gradient products of the training
-                                                 backward in the six-term bf16 form, bit 4 (16) = value planes: a pass after the
+                                                 backward in the six-term bf16 form, bit 6 (64) = the PairEmbedding backward's matrix-core
+                                                 kernels (csrc/pair_chain_bwd.hip: 64-wide chain, one-hot table / coefficient sums) as the
+                                                 separate launches they replaced, bit 4 (16) = value planes: a pass after the
                                                  projections cuts the value side (v_s, global value points) into two fp16 planes and phase 3
                                                  of the attention tile (P x V) runs on the f16 matrix cores (parity-green, measured slower
                                                  overall: profiles/r06_attention.md).  0 = defaults. */
