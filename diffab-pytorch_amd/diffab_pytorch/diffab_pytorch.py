@@ -573,7 +573,7 @@ class _PairEmbeddingFn(torch.autograd.Function):
         # leaves its four hidden activations (8.6 GB at B = 128, K = 128) and the backward does not recompute it.  DIFFAB_PAIR_TAPE=0: off.
         ctx.tape = None
         tape_bytes = lib.diffab_pair_embedding_tape_bytes(C.byref(dims))
-        if (tape_bytes and any(p.requires_grad for p in params) and os.environ.get("DIFFAB_PAIR_TAPE", "1") != "0"
+        if (tape_bytes and getattr(owner, "_tape_wanted", False) and any(ctx.needs_input_grad) and os.environ.get("DIFFAB_PAIR_TAPE", "1") != "0"
                 and torch.cuda.mem_get_info(seq.device)[0] > 2 * tape_bytes):
             ctx.tape = torch.empty(tape_bytes // 4, dtype=torch.float32, device=seq.device)
             _hip.check(lib.diffab_pair_embedding_fwd_taped(C.byref(dims), C.byref(w), _hip.ptr(seq), _hip.ptr(None if from_xyz else dm),
@@ -683,6 +683,8 @@ class PairEmbedding(nn.Module):
         p = _named(self)
         if ri.shape[0] not in (1, B):
             raise ValueError("residue_idx must be (1, K) or (B, K)")
+        # (the grad mode is read HERE: inside an autograd Function's forward it is always off, and needs_input_grad ignores it)
+        self._tape_wanted = torch.is_grad_enabled()
         out = _PairEmbeddingFn.apply(self, dims, from_xyz, seq, dm, dh, ri, K if ri.shape[0] == B else 0, ch, am, qm,
                                      *[p[k] for k in _PAIR_KEYS])
         return out.to(out_dev)

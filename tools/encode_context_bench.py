@@ -26,14 +26,16 @@ model.load_state_dict(syn.context_state_dict(d["D"], d["C"], 15, 32, seed=1), st
 cb = {k: v.cuda() for k, v in syn.context_batch(B, K, 15, seed=1).items()}
 args = lambda dm: (cb["seq_idx"], cb["xyz"], cb["orientations"], cb["backbone_dihedrals"], dm, cb["pairwise_dihedrals"], cb["atom_mask"],
                    cb["chain_idx"], cb["residue_idx"], cb["generation_mask"], cb["residue_mask"])
-for name, dm in (("distmat", cb["distmat"]), ("xyz", None)):
-    for _ in range(2):
-        model.encode_context(*args(dm))
+for name, dm in (("distmat", cb["distmat"]), ("xyz", None)):  # (inference form: no graph, so no tape is written)
+    with torch.no_grad():
+        for _ in range(2):
+            model.encode_context(*args(dm))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 5
-    for _ in range(n):
-        model.encode_context(*args(dm))
+    with torch.no_grad():
+        for _ in range(n):
+            model.encode_context(*args(dm))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"encode_context[{name}] B={B} K={K}: {dt*1e3:.2f} ms = {dt*1e3/B:.4f} ms/patch; distmat stream {B*K*K*225*4/dt/1e9:.0f} GB/s-equivalent")
