@@ -1,19 +1,28 @@
-// pair_chain_bwd.hip - the 64-wide tail of the PairEmbedding backward as ONE launch per chunk of pair rows (round 6).
+// pair_chain_bwd.hip - the PairEmbedding backward on the matrix cores (round 6): four kernels + a slab reduce, one set per chunk of pair rows.
 //
-// Reference: autograd of PairEmbedding.forward, /root/reference/diffab_pytorch/diffab_pytorch.py:186-312 (distance_embedding[2] and its
-// ReLU :212-217, the three Linear layers of `mlp` :219-229, the atom-mask product at the end of forward).  With the hidden activations
-// of a chunk on the tape (pair_embed_fused_kernel<true>) the backward of those four 64 x 64 layers was a mask kernel, four masked d x
-// products, and a four-product weight-gradient launch: 11 passes over 126 MB row buffers per chunk of 30 patches (2.7 GB, 875 us).
+// Reference: autograd of PairEmbedding.forward, /root/reference/diffab_pytorch/diffab_pytorch.py:186-312 (distance_embedding :212-217,
+// the three Linear layers of `mlp` :219-229, the embedding tables and pair2distcoef :190-210, the atom-mask product at the end of
+// forward).  With the hidden activations of a chunk available (recomputed by pair_embed_fused_kernel<true>, or read from the forward's
+// tape: diffab_pair_embedding_fwd_taped) the backward was a chain of small launches bound by row-buffer traffic and by LDS atomics.
+//
+//   pair_chain_bwd_kernel        the 64-wide tail: atom mask, four masked d x products, their weight and bias gradients (below)
+//   pair_table_mfma_kernel       G1[s_i 21 + s_j] += g, G2[rel] += same g as one-hot products (was: LDS atomics)
+//   pair_dist_bwd_mfma_kernel    d softplus(pair2distcoef) class sums from a materialised d din (the unfused backward's form)
+//   pair_dist_bwd_fused64_kernel ... with d din = d h1 W formed in the kernel (the fused backward's form)
+//   parts_reduce_kernel          per-work-group partial sums -> their destinations
+//
+// ---- pair_chain_bwd_kernel.  The backward of the four 64 x 64 layers was a mask kernel, four masked d x products, and a four-product
+// weight-gradient launch: 11 passes over 126 MB row buffers per chunk of 30 patches (2.7 GB, 875 us).
 // Here a work-group walks 128-row tiles and keeps a tile on the CU through the whole chain:
 //
 //   d A   = d out * atom_mask_i[CA] * atom_mask_j[CA]                                   (pair_mask_bwd_kernel)
 //   layer 0: d mlp[4].W += d A^T  m2,   d B   = (d A   mlp[4].W)          * [m2 > 0]
-//   layer 1: d mlp[2].W += d B^T  m1,   d C   = (d B   mlp[2].W)          * [m1 > 0]     -> global (the table scatter and the dihedral
+//   layer 1: d mlp[2].W += d B^T  m1,   d C   = (d B   mlp[2].W)          * [m1 > 0]     -> global (the table sums and the dihedral
 //   layer 2: d mlp[0].W[:, 2C:3C] += d C^T df,  d df = (d C mlp[0].W[:, 2C:3C]) * [df > 0]                  columns read it)
 //   layer 3: d dist[2].W += d df^T h1,  d h1  = (d df  dist[2].W)         * [h1 > 0]     -> global (distance_embedding[0]'s backward)
 //   and the four bias gradients = column sums of d A, d B, d C, d df.
 //
-// It reads d out and the four taped activations once (5 x 32 KiB per tile) and writes d C and d h1 (2 x 32 KiB): 880 MB per chunk.
+// It reads d out and the four activations once (5 x 32 KiB per tile) and writes d C and d h1 (2 x 32 KiB): 880 MB per chunk, 254 us.
 // Arithmetic: bf16 x 6 split products (three exact bf16 pieces per operand, six partial products, fp32 accumulation - gemm_bf16x6.hip):
 // fp32 accuracy without any scale bookkeeping for gradients that span decades.  Per layer a tile's d y and x sit in LDS as split
 // planes [128 rows][64 columns] in ONE orientation that serves three reads: the d x product takes d y rows as the MFMA's B operand
@@ -21,7 +30,8 @@
 // into the planes as 8-byte pieces, mlp_chain_tile.h's arrangement), the weight gradient contracts over the ROWS and takes both
 // operands through the transposing read ds_read_b64_tr_b16 (gemm_tn_b6_kernel's arrangement), the ReLU mask is the sign of x's high
 // plane.  Weight fragments come pre-split and fragment-ordered from a 96 KiB prep buffer (L2-resident), one layer at a time.  The
-// weight and bias gradients stay in registers over all tiles of the work-group and leave as one set of atomics at the end.
+// weight-gradient accumulators of all tiles of a work-group live in LDS (64 KiB; as registers the kernel spilled), the bias sums in
+// registers; both leave as one slab per work-group for parts_reduce_kernel.  LDS: 96 KiB of planes + 64 KiB = all 160 KiB of a CU.
 #include "common.h"
 #include "denoiser_internal.h"
 #include "rowgemm_b6_tile.h"
