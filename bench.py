@@ -434,7 +434,7 @@ def train_bench(args, model, dims, rank, world, dist):
             "metric": "CDR-residue training-steps/sec (K=128 patch, forward + backward + Adam)", "value": value, "unit": "residue-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x6 split-precision dense products, fp32 accumulate; fp32-accurate, DESIGN section 4)", "data": "synthetic",
+            "dtype": "f32 (fp16x3 / bf16x6 split-precision dense products on the 16-bit matrix cores, fp32 accumulate; fp32-accurate, DESIGN section 4)", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: training step, batch={B}/GPU synthetic K={K} patches, benchmark model NL=6; noise + taped "
                                    "forward + 3 losses + HIP backward incl. d pair_ctx + gradient all-reduce (RCCL, in-place buckets) + Adam; "
                                    "contexts given as grad-requiring inputs (SURVEY 8d)",
