@@ -584,6 +584,90 @@ int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P,
   return DIFFAB_OK;
 }
 
+// ================================================================== d pair_ctx of ALL layers in one pass (round 6)
+// de[i][j][c] += sum_l sum_h (P_l[h][i][j] do_e_l[i][h][c] + g_l[h][i][j] w_bias_l[h][c]).  Inside ipa_pair_stream_bwd_kernel the term costs
+// a read-modify-write of the whole (B, K, K, C) gradient PER LAYER (250 of that kernel's 450 us at B = 128: 1.5 ms of an 8.3 ms step).
+// With g_l and do_e_l of every layer kept (workspace) and P_l on the tape, one kernel at the end of the backward takes the same MFMA
+// product over all layers - K = 16 "heads" (8 x P, 8 x g) per layer, up to 96 - and touches d pair_ctx once.  Same wave / lane layout
+// as B' above: wave = RPW query rows, lane (l15, q); the A fragments of every layer (do_e of the row | w_bias) stay in registers over
+// the row's key tiles, the [P ; g] tile of a layer is re-oriented through 1.25 KiB of the wave's LDS.
+constexpr int DE_NL = 6;  // layers per launch (NL = 6: one launch)
+struct DeLayers {
+  const float* P[DE_NL]; const float* G[DE_NL]; const float* doe[DE_NL]; const float* Wb[DE_NL];
+  int nl;
+};
+template <int NT, int RPW>
+__global__ __launch_bounds__(512) void ipa_pair_de_layers_kernel(DeLayers L, float* __restrict__ de, int rows_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: [16 h'][PGLD]
+  constexpr int K = 16 * NT, PGLD = 20;
+  const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
+  const int l15 = lane0 & 15, q = lane0 >> 4, h = l15 & 7;
+  float* pg = lds + wv * (16 * PGLD);
+  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 8 + wv) * RPW;
+#pragma unroll 1
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int64_t row = row_first + rr;
+    if (row >= rows_total) break;
+    const int64_t off = ((row / K) * AH * K + static_cast<int64_t>(h) * K + row % K) * K + 4 * q;  // [b][h][i][j], keys 4 q ..
+    // A fragments: lane (l15, q) holds M_l[h' = 4 q + s][c = 16 ct + l15]; h' < 8: do_e_l of the row, h' >= 8: w_bias_l
+    float af[DE_NL][4][4];
+#pragma unroll
+    for (int l = 0; l < DE_NL; ++l) {
+      // (ONE load per element through a per-lane base pointer: as `q < 2 ? doe[..] : Wb[..]` both loads were issued - 192 registers in flight)
+      const int lc = l < L.nl ? l : 0;
+      const float* bp = q < 2 ? L.doe[lc] + row * (AH * AC) + 4 * q * AC : L.Wb[lc] + 4 * (q - 2) * AC;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) af[l][ct][s] = bp[s * AC + 16 * ct + l15];
+    }
+    float* derow = de + (row * K + l15) * AC + 4 * q;  // + 16 jt keys, + 16 ct channels
+#pragma unroll 1
+    for (int jt = 0; jt < NT; ++jt) {
+      f32x4 dacc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) dacc[ct] = *reinterpret_cast<const f32x4*>(derow + static_cast<int64_t>(jt) * 16 * AC + 16 * ct);
+#pragma unroll
+      for (int l = 0; l < DE_NL; ++l) {
+        if (l >= L.nl) break;
+        if (l15 < 8) {
+          *reinterpret_cast<f32x4*>(pg + h * PGLD + 4 * q) = *reinterpret_cast<const f32x4*>(L.P[l] + off + jt * 16);
+          *reinterpret_cast<f32x4*>(pg + (8 + h) * PGLD + 4 * q) = *reinterpret_cast<const f32x4*>(L.G[l] + off + jt * 16);
+        }
+        MEM_FENCE();  // (wave-private tile; a wave's LDS operations complete in order)
+        float bf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[s] = pg[(4 * q + s) * PGLD + l15];  // B[h' = 4 q + s][key 16 jt + l15]
+        MEM_FENCE();
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[l][ct][s], bf[s], dacc[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(derow + static_cast<int64_t>(jt) * 16 * AC + 16 * ct) = dacc[ct];
+    }
+  }
+}
+
+// P / G: [B][8][K][K] per layer; doe: [B K][8 * 64] per layer (the o_e columns of that layer's d feat); Wb: [8][64] per layer
+int launch_pair_de_layers(const diffab_dims* d, int nl, const float* const* P, const float* const* G, const float* const* doe,
+                          const float* const* Wb, float* de, hipStream_t st) {
+  const int K = d->K, rows = d->B * K;
+  DIFFAB_REQUIRE(attention_split_supported(d) && nl >= 1 && nl <= DE_NL && de != nullptr, DIFFAB_ERR_UNSUPPORTED,
+                 "pair_de_layers: K must be 64 or 128, 1 <= layers <= %d", DE_NL);
+  DeLayers L{};
+  L.nl = nl;
+  for (int l = 0; l < nl; ++l) { L.P[l] = P[l]; L.G[l] = G[l]; L.doe[l] = doe[l]; L.Wb[l] = Wb[l]; }
+  constexpr int RPW = 2;
+  const size_t lds_b = static_cast<size_t>(8) * 16 * 20 * sizeof(float);
+  const dim3 grid((rows + 8 * RPW - 1) / (8 * RPW));
+  if (K == 128) hipLaunchKernelGGL((ipa_pair_de_layers_kernel<8, RPW>), grid, dim3(512), lds_b, st, L, de, rows);
+  else hipLaunchKernelGGL((ipa_pair_de_layers_kernel<4, RPW>), grid, dim3(512), lds_b, st, L, de, rows);
+  DIFFAB_LAUNCH_CHECK();
+  return DIFFAB_OK;
+}
+
 // ------------------------------------------------------------------ host side
 bool attention_split_supported(const diffab_dims* d) { return d->K == 64 || d->K == 128; }
 

@@ -1723,6 +1723,8 @@ size_t train_bwd_workspace_floats(const diffab_dims* d) {
   return rows * (d->V + 3 + 3) + rows * (D + 3) + 6 * rows * D + 2 * rows * D + rows * F + 2 * rows * NP + rows * 2 * D + 64 + 2 * HKK +
          rows * d->H * d->PV * 3 + rows * (d->H * d->C + d->H) + 64 +
          ((fast_path_supported(d) && attention_split_supported(d)) ? 3 * HKK : 0) +  // probabilities / g, squared distances, dA_kv
+         ((fast_path_supported(d) && attention_split_supported(d) && d->NL <= kDeLayersMax)
+              ? static_cast<size_t>(d->NL) * (HKK + rows * d->H * d->C) + 64 : 0) +  // g and d o_e of every layer (d pair_ctx in one pass)
          bwd_planes_floats(d);
 }
 
@@ -1769,6 +1771,17 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
   float* Pn = mfma_probs ? take(HKK) : nullptr;
   float* D2g = mfma_probs ? take(HKK) : nullptr;
   float* dAkv = mfma_probs ? take(HKK) : nullptr;
+  // d pair_ctx in ONE pass behind the layer loop (launch_pair_de_layers) instead of a read-modify-write of the whole gradient per layer:
+  // needs g and the o_e columns of d feat of every layer kept, and the probabilities of every layer on the tape
+  bool defer_de = mfma_probs && d_pair_ctx != nullptr && mode != BWD_LAYER && d->NL <= kDeLayersMax && C == 64 && H == 8 &&
+                  fast_path_supported(d) && attention_split_supported(d);
+  for (int l = 0; l < d->NL && defer_de; ++l) defer_de = tp.sp[l] != nullptr;
+  float* g_keep = nullptr;
+  float* doe_keep = nullptr;
+  if (mfma_probs && fast_path_supported(d) && attention_split_supported(d) && d->NL <= kDeLayersMax) {  // (the slots exist either way: the size
+    g_keep = take(static_cast<size_t>(d->NL) * HKK);                                                     //  function does not know d_pair_ctx)
+    doe_keep = take(static_cast<size_t>(d->NL) * rows * H * C + 64);
+  }
   void* planes = nullptr;  // bf16x6 input-gradient products (D = 128): the transposed weights as split planes, one operand at a time
   if (bwd_planes_floats(d) > 0 && use_b6_gemm())
     planes = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(take(bwd_planes_floats(d))) + 255) & ~static_cast<uintptr_t>(255));
@@ -1861,24 +1874,29 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
         } else if (int rc = launch_attention_probs(d, proj, pair_ctx, lw->w_bias, lw->gamma, Pn, D2g, st)) {
           return rc;
         }
-        hipLaunchKernelGGL(ipa_attn_bwd_dakv_mfma_kernel, grid_km, dim3(256), lds_km, st, proj, dfeat, dogbuf, dAkv, d->K);
+        float* Gl = defer_de ? g_keep + static_cast<size_t>(l) * HKK : dAkv;  // d A_kv, then g, of this layer
+        hipLaunchKernelGGL(ipa_attn_bwd_dakv_mfma_kernel, grid_km, dim3(256), lds_km, st, proj, dfeat, dogbuf, Gl, d->K);
         DIFFAB_LAUNCH_CHECK();
-        // dAkv holds g afterwards; d pair_ctx is accumulated there too (MFMA), so the row pass below only writes the transposed copies
-        if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, dAkv, D2g, dfeat, wb_part, lw->w_bias, d_pair_ctx, st)) return rc;
+        // Gl holds g afterwards.  d pair_ctx: accumulated by the same kernel (a read-modify-write of the whole gradient per layer), or -
+        // defer_de - left to ONE pass behind the layer loop, for which this layer's g (Gl is its own slot) and d o_e are kept
+        if (int rc = launch_pair_stream_bwd(d, pair_ctx, Pn, Gl, D2g, dfeat, wb_part, lw->w_bias, defer_de ? nullptr : d_pair_ctx, st)) return rc;
+        if (defer_de)
+          DIFFAB_HIP_CHECK(hipMemcpy2DAsync(doe_keep + static_cast<size_t>(l) * rows * H * C, sizeof(float) * H * C, dfeat + H * DS,
+                                            sizeof(float) * F, sizeof(float) * H * C, rows, hipMemcpyDeviceToDevice, st));
         keys_done = true;
         DIFFAB_REQUIRE(rows % 32 == 0, DIFFAB_ERR_UNSUPPORTED, "attention backward (MFMA path): B K = %d must be a multiple of 32", rows);
         wb_rows = rows / 32;  // one partial row per 32 query rows (launch_pair_stream_bwd)
         // key side straight from the [b][h][i][j] images (g in dAkv, P in Pn): no transposed copies, no VALU row pass at all
         if (d->K == 128) {  // bf16 matrix cores: d k and d v (transposed products), d q
-          hipLaunchKernelGGL(ipa_attn_bwd_keys_tn_b6_kernel, dim3(d->B * H * 2), dim3(256), 0, st, proj, lw->gamma, dfeat, dAkv, Pn, dogbuf,
+          hipLaunchKernelGGL(ipa_attn_bwd_keys_tn_b6_kernel, dim3(d->B * H * 2), dim3(256), 0, st, proj, lw->gamma, dfeat, Gl, Pn, dogbuf,
                              dproj, d->B);
-          hipLaunchKernelGGL(ipa_attn_bwd_keys_nn_b6_kernel, dim3(d->B * H), dim3(256), 0, st, proj, lw->gamma, dAkv, dproj, d->B);
+          hipLaunchKernelGGL(ipa_attn_bwd_keys_nn_b6_kernel, dim3(d->B * H), dim3(256), 0, st, proj, lw->gamma, Gl, dproj, d->B);
         } else {
-        hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<0, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf,
+        hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<0, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Gl, dogbuf,
                            dproj, d->K);
         hipLaunchKernelGGL((ipa_attn_bwd_keys_mfma_kernel<1, false>), grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Pn, dogbuf,
                            dproj, d->K);
-        hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, dAkv, dogbuf, dproj, d->K);
+        hipLaunchKernelGGL(ipa_attn_bwd_keys_mfma_kernel<2>, grid_km, dim3(256), lds_km, st, proj, lw->gamma, dfeat, Gl, dogbuf, dproj, d->K);
         }
       } else {
         DIFFAB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_bwd_rows_mr_kernel<RRm, 0>),
@@ -1963,6 +1981,19 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
       }
     }
     float* tmp = dcur; dcur = dnxt; dnxt = tmp;
+  }
+  if (defer_de) {  // d pair_ctx += the pair-bias and o_e terms of all layers, one pass (attention_split.hip)
+    const float* Ps[kDeLayersMax];
+    const float* Gs[kDeLayersMax];
+    const float* Es[kDeLayersMax];
+    const float* Wbs[kDeLayersMax];
+    for (int l = 0; l < d->NL; ++l) {
+      Ps[l] = tp.sp[l];
+      Gs[l] = g_keep + static_cast<size_t>(l) * HKK;
+      Es[l] = doe_keep + static_cast<size_t>(l) * rows * H * C;
+      Wbs[l] = w->layers[l].w_bias;
+    }
+    if (int rc = launch_pair_de_layers(d, d->NL, Ps, Gs, Es, Wbs, d_pair_ctx, st)) return rc;
   }
   if (mode == BWD_LAYER) {
     DIFFAB_HIP_CHECK(hipMemcpyAsync(layer_dx, dcur, sizeof(float) * rows * D, hipMemcpyDeviceToDevice, st));

@@ -147,6 +147,10 @@ size_t attention_split_workspace_floats(const diffab_dims* d);
 int launch_ipa_logits(const diffab_dims* d, const float* proj, const float* gamma, float* SP, hipStream_t st);  // S[b][h][i][j] only
 int launch_attention_probs(const diffab_dims* d, const float* proj, const float* e, const float* Wb, const float* gamma, float* P,
                            float* D2, hipStream_t st);  // training backward: normalised probabilities + squared point distances
+// d pair_ctx of all layers in one pass (attention_split.hip): P / G [B][8][K][K], doe [B K][512], Wb [8][64] per layer
+constexpr int kDeLayersMax = 6;
+int launch_pair_de_layers(const diffab_dims* d, int nl, const float* const* P, const float* const* G, const float* const* doe,
+                          const float* const* Wb, float* de, hipStream_t st);
 int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P, float* G /* in dA_kv, out g */, const float* D2,
                            const float* dfeat, float* wb_part, const float* Wb, float* de /* nullable: += d pair_ctx */,
                            hipStream_t st);  // training backward: g, d gamma / d w_bias partials, d e
