@@ -597,13 +597,13 @@ struct DeLayers {
   int nl;
 };
 template <int NT, int RPW>
-__global__ __launch_bounds__(512) void ipa_pair_de_layers_kernel(DeLayers L, float* __restrict__ de, int rows_total) {
+__global__ __launch_bounds__(256) void ipa_pair_de_layers_kernel(DeLayers L, float* __restrict__ de, int rows_total) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: [16 h'][PGLD]
   constexpr int K = 16 * NT, PGLD = 20;
   const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
   const int l15 = lane0 & 15, q = lane0 >> 4, h = l15 & 7;
   float* pg = lds + wv * (16 * PGLD);
-  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 8 + wv) * RPW;
+  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 4 + wv) * RPW;  // four-wave work-groups: 164 VGPRs, three groups per CU
 #pragma unroll 1
   for (int rr = 0; rr < RPW; ++rr) {
     const int64_t row = row_first + rr;
@@ -660,10 +660,10 @@ int launch_pair_de_layers(const diffab_dims* d, int nl, const float* const* P, c
   L.nl = nl;
   for (int l = 0; l < nl; ++l) { L.P[l] = P[l]; L.G[l] = G[l]; L.doe[l] = doe[l]; L.Wb[l] = Wb[l]; }
   constexpr int RPW = 2;
-  const size_t lds_b = static_cast<size_t>(8) * 16 * 20 * sizeof(float);
-  const dim3 grid((rows + 8 * RPW - 1) / (8 * RPW));
-  if (K == 128) hipLaunchKernelGGL((ipa_pair_de_layers_kernel<8, RPW>), grid, dim3(512), lds_b, st, L, de, rows);
-  else hipLaunchKernelGGL((ipa_pair_de_layers_kernel<4, RPW>), grid, dim3(512), lds_b, st, L, de, rows);
+  const size_t lds_b = static_cast<size_t>(4) * 16 * 20 * sizeof(float);
+  const dim3 grid((rows + 4 * RPW - 1) / (4 * RPW));
+  if (K == 128) hipLaunchKernelGGL((ipa_pair_de_layers_kernel<8, RPW>), grid, dim3(256), lds_b, st, L, de, rows);
+  else hipLaunchKernelGGL((ipa_pair_de_layers_kernel<4, RPW>), grid, dim3(256), lds_b, st, L, de, rows);
   DIFFAB_LAUNCH_CHECK();
   return DIFFAB_OK;
 }
