@@ -590,7 +590,7 @@ int launch_pair_stream_bwd(const diffab_dims* d, const float* e, const float* P,
 // With g_l and do_e_l of every layer kept (workspace) and P_l on the tape, one kernel at the end of the backward takes the same MFMA
 // product over all layers - K = 16 "heads" (8 x P, 8 x g) per layer, up to 96 - and touches d pair_ctx once.  Same wave / lane layout
 // as B' above: wave = RPW query rows, lane (l15, q); the A fragments of every layer (do_e of the row | w_bias) stay in registers over
-// the row's key tiles, the [P ; g] tile of a layer is re-oriented through 1.25 KiB of the wave's LDS.
+// the row's key tiles, the [P ; g] B fragments come straight from the [b][h][i][j] images (sixteen consecutive keys per 16-lane group).
 constexpr int DE_NL = 6;  // layers per launch (NL = 6: one launch)
 struct DeLayers {
   const float* P[DE_NL]; const float* G[DE_NL]; const float* doe[DE_NL]; const float* Wb[DE_NL];
@@ -598,24 +598,26 @@ struct DeLayers {
 };
 template <int NT, int RPW>
 __global__ __launch_bounds__(256) void ipa_pair_de_layers_kernel(DeLayers L, float* __restrict__ de, int rows_total) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // per wave: [16 h'][PGLD]
-  constexpr int K = 16 * NT, PGLD = 20;
+  constexpr int K = 16 * NT;
   const int tid = threadIdx.x, lane0 = tid & 63, wv = tid >> 6;
-  const int l15 = lane0 & 15, q = lane0 >> 4, h = l15 & 7;
-  float* pg = lds + wv * (16 * PGLD);
-  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 4 + wv) * RPW;  // four-wave work-groups: 164 VGPRs, three groups per CU
+  const int l15 = lane0 & 15, q = lane0 >> 4;
+  const int64_t row_first = (static_cast<int64_t>(blockIdx.x) * 4 + wv) * RPW;  // four-wave work-groups: three groups per CU
 #pragma unroll 1
   for (int rr = 0; rr < RPW; ++rr) {
     const int64_t row = row_first + rr;
     if (row >= rows_total) break;
-    const int64_t off = ((row / K) * AH * K + static_cast<int64_t>(h) * K + row % K) * K + 4 * q;  // [b][h][i][j], keys 4 q ..
+    // B fragments straight from the [b][h][i][j] images: lane (key l15, q) takes B[h' = 4 q + s][key] = P (h' < 8: lanes q < 2) or g
+    // (lanes q >= 2) of head (4 q + s) & 7 - sixteen consecutive keys per 16-lane group, no re-orientation through LDS
+    const int64_t boff = ((row / K) * AH * K + static_cast<int64_t>((4 * q) & 7) * K + row % K) * K + l15;  // + s K K heads, + 16 jt keys
     // A fragments: lane (l15, q) holds M_l[h' = 4 q + s][c = 16 ct + l15]; h' < 8: do_e_l of the row, h' >= 8: w_bias_l
     float af[DE_NL][4][4];
+    const float* bsrc[DE_NL];
 #pragma unroll
     for (int l = 0; l < DE_NL; ++l) {
       // (ONE load per element through a per-lane base pointer: as `q < 2 ? doe[..] : Wb[..]` both loads were issued - 192 registers in flight)
       const int lc = l < L.nl ? l : 0;
       const float* bp = q < 2 ? L.doe[lc] + row * (AH * AC) + 4 * q * AC : L.Wb[lc] + 4 * (q - 2) * AC;
+      bsrc[l] = (q < 2 ? L.P[lc] : L.G[lc]) + boff;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -624,25 +626,21 @@ __global__ __launch_bounds__(256) void ipa_pair_de_layers_kernel(DeLayers L, flo
     float* derow = de + (row * K + l15) * AC + 4 * q;  // + 16 jt keys, + 16 ct channels
 #pragma unroll 1
     for (int jt = 0; jt < NT; ++jt) {
+      float bf[DE_NL][4];
+#pragma unroll
+      for (int l = 0; l < DE_NL; ++l)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[l][s] = bsrc[l][static_cast<int64_t>(s) * K * K + jt * 16];
       f32x4 dacc[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) dacc[ct] = *reinterpret_cast<const f32x4*>(derow + static_cast<int64_t>(jt) * 16 * AC + 16 * ct);
 #pragma unroll
       for (int l = 0; l < DE_NL; ++l) {
         if (l >= L.nl) break;
-        if (l15 < 8) {
-          *reinterpret_cast<f32x4*>(pg + h * PGLD + 4 * q) = *reinterpret_cast<const f32x4*>(L.P[l] + off + jt * 16);
-          *reinterpret_cast<f32x4*>(pg + (8 + h) * PGLD + 4 * q) = *reinterpret_cast<const f32x4*>(L.G[l] + off + jt * 16);
-        }
-        MEM_FENCE();  // (wave-private tile; a wave's LDS operations complete in order)
-        float bf[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bf[s] = pg[(4 * q + s) * PGLD + l15];  // B[h' = 4 q + s][key 16 jt + l15]
-        MEM_FENCE();
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) dacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[l][ct][s], bf[s], dacc[ct], 0, 0, 0);
+          for (int s = 0; s < 4; ++s) dacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[l][ct][s], bf[l][s], dacc[ct], 0, 0, 0);
       }
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(derow + static_cast<int64_t>(jt) * 16 * AC + 16 * ct) = dacc[ct];
@@ -660,7 +658,7 @@ int launch_pair_de_layers(const diffab_dims* d, int nl, const float* const* P, c
   L.nl = nl;
   for (int l = 0; l < nl; ++l) { L.P[l] = P[l]; L.G[l] = G[l]; L.doe[l] = doe[l]; L.Wb[l] = Wb[l]; }
   constexpr int RPW = 2;
-  const size_t lds_b = static_cast<size_t>(4) * 16 * 20 * sizeof(float);
+  const size_t lds_b = 0;
   const dim3 grid((rows + 4 * RPW - 1) / (4 * RPW));
   if (K == 128) hipLaunchKernelGGL((ipa_pair_de_layers_kernel<8, RPW>), grid, dim3(256), lds_b, st, L, de, rows);
   else hipLaunchKernelGGL((ipa_pair_de_layers_kernel<4, RPW>), grid, dim3(256), lds_b, st, L, de, rows);
