@@ -1913,9 +1913,17 @@ static int run_backward(int mode, const diffab_dims* d, const diffab_denoiser_we
     }
     DIFFAB_LAUNCH_CHECK();
     // d w_bias[h][c] += sum_rows partial, d gamma[h] += sum_rows partial (one column sum over the [rows][H*C + H] partials)
-    if (C > 0)  // (use_pair_bias = False: no pair bias, no d w_bias)
-      if (int rc = colsum(wb_part, H * C + H, wb_rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
-    if (int rc = colsum(wb_part + H * C, H * C + H, wb_rows, H, const_cast<float*>(lg->gamma), st)) return rc;
+    if (keys_done && C > 0) {  // both sums in ONE launch (per-work-group partial rows -> two destinations; two colsum launches of 12.5 us before)
+      PartsSegs sg{};
+      sg.nseg = 2;
+      sg.off[0] = 0; sg.n[0] = H * C; sg.cols[0] = H * C; sg.ld[0] = H * C; sg.out[0] = const_cast<float*>(lg->w_bias);
+      sg.off[1] = H * C; sg.n[1] = H; sg.cols[1] = H; sg.ld[1] = H; sg.out[1] = const_cast<float*>(lg->gamma);
+      if (int rc = launch_parts_reduce(wb_part, wb_rows, H * C + H, sg, st)) return rc;
+    } else {
+      if (C > 0)  // (use_pair_bias = False: no pair bias, no d w_bias)
+        if (int rc = colsum(wb_part, H * C + H, wb_rows, H * C, const_cast<float*>(lg->w_bias), st)) return rc;
+      if (int rc = colsum(wb_part + H * C, H * C + H, wb_rows, H, const_cast<float*>(lg->gamma), st)) return rc;
+    }
     const size_t lds2 = 2 * static_cast<size_t>(H) * d->K * sizeof(float);
     constexpr int JJm = 4;  // keys per work-group of the multi-key kernel
     if (keys_done) {
